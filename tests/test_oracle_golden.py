@@ -1,0 +1,99 @@
+"""CPU: the oracle (oracle/gom_oracle.py) against the fixtures produced by the reference's own
+modules (oracle/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gomatching_amd.synth import make_clip
+from gomatching_amd.weights import synth_state_dict
+from oracle import gom_oracle as O
+from helpers import mini_cfg, golden, e2e_state_dict, t
+
+TOL = 2e-5
+
+
+@pytest.mark.parametrize("case", ["enc", "dec", "oob"])
+def test_msda_op(case):
+    g = golden("msda.npz")
+    out = O.ms_deform_attn_forward(t(g[case + "_value"]), t(g[case + "_shapes"]), t(g[case + "_lsi"]),
+                                   t(g[case + "_loc"]), t(g[case + "_w"]))
+    np.testing.assert_allclose(out.numpy(), g[case + "_out"], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("builtin,tag,voc", [("icdar15", "ic15", None), ("bovtext", "voc96", 96)])
+def test_deepsolo_mini(builtin, tag, voc):
+    g = golden("deepsolo_%s.npz" % tag)
+    cfg = mini_cfg(builtin, voc=voc)
+    sd = synth_state_dict(cfg, seed=7)
+    feats = [t(g["feat%d" % i]) for i in range(3)]
+    masks = [torch.zeros(f.shape[0], f.shape[2], f.shape[3], dtype=torch.bool) for f in feats]
+    T = cfg.MODEL.TRANSFORMER
+    pos = [O.pos_encoding_2d(m, T.HIDDEN_DIM // 2, T.TEMPERATURE) for m in masks]
+    for i in range(3):
+        np.testing.assert_allclose(pos[i].numpy(), g["pos%d" % i], atol=1e-6, rtol=0)
+    with torch.no_grad():
+        out = O.deepsolo_forward(sd, cfg, feats, masks, pos)
+    for k in ("pred_logits", "pred_text_logits", "pred_ctrl_points", "pred_bd_points", "query_features"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], atol=TOL, rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
+def test_matcher_heads(builtin, tag):
+    g = golden("matcher_%s.npz" % tag)
+    cfg = mini_cfg(builtin)
+    sd = synth_state_dict(cfg, seed=7)
+    with torch.no_grad():
+        for n in (1, 7, 20):
+            x = t(g["fc_in_%d" % n]).flatten(1)
+            for k in range(2):
+                x = torch.relu(O.linear(x, sd, "roi_heads.asso_head.fc%d" % (k + 1)))
+            np.testing.assert_allclose(x.numpy(), g["fc_out_%d" % n], atol=TOL, rtol=0)
+        for ci in range(5):
+            n_t = [int(v) for v in g["asso%d_nt" % ci]]
+            k, short = int(g["asso%d_k" % ci][0]), bool(g["asso%d_k" % ci][1])
+            out = O.asso_scores(sd, cfg, t(g["asso%d_reid" % ci]), n_t, k, short)
+            np.testing.assert_allclose(out.numpy(), g["asso%d_out" % ci], atol=TOL, rtol=0)
+
+
+def _tracker_inputs(g):
+    size = tuple(int(v) for v in g["image_size"])
+    frames = int(g["num_frames"][0])
+    return [O.Inst(size, reid_features=t(g["reid_%d" % f]).clone(), pred_boxes=t(g["boxes_%d" % f]).clone())
+            for f in range(frames)], frames
+
+
+@pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
+def test_tracker_trace(builtin, tag):
+    """16-frame trace incl. an empty frame, births, drop-outs, long-term re-association, id_count quirk."""
+    g = golden("tracker_%s.npz" % tag)
+    cfg = mini_cfg(builtin)
+    sd = synth_state_dict(cfg, seed=7)
+    insts, frames = _tracker_inputs(g)
+    with torch.no_grad():
+        res, id_count = O.track_clip(sd, cfg, insts)
+    assert int(id_count) == int(g["id_count"][0])
+    for f in range(frames):
+        assert res[f]["track_ids"].tolist() == g["ids_%d" % f].tolist(), f
+    kept = O.remove_short_track(cfg, res)
+    for f in range(frames):
+        assert kept[f]["track_ids"].tolist() == g["kept_ids_%d" % f].tolist(), f
+
+
+@pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
+def test_end_to_end_mini_clip(builtin, tag):
+    """Whole path on 8 tiny frames: Bezier/boundary points within 1e-3 px-scaled, identical recs and ids."""
+    g = golden("e2e_%s.npz" % tag)
+    cfg = mini_cfg(builtin)
+    sd = e2e_state_dict(cfg, g)
+    hw = tuple(int(v) for v in g["hw"])
+    frames = int(g["num_frames"][0])
+    clip = make_clip(frames, hw[0], hw[1], clip_id=1)
+    images = [torch.as_tensor(f.astype("float32").transpose(2, 0, 1)) for f in clip]
+    res, id_count = O.run_clip(sd, cfg, images)
+    assert int(id_count) == int(g["id_count"][0])
+    for f in range(frames):
+        r = res[f]["instances"]
+        assert r["track_ids"].tolist() == g["track_ids_%d" % f].tolist()
+        assert r["recs"].tolist() == g["recs_%d" % f].tolist()
+        for k in ("scores", "bd", "ctrl_points", "pred_boxes"):
+            np.testing.assert_allclose(r[k].numpy(), g["%s_%d" % (k, f)], atol=1e-3, rtol=0, err_msg=k)
