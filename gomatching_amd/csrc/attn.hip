@@ -1,0 +1,164 @@
+// Softmax attention core for the short sequences of the GoMatching path (fp32, exact softmax):
+//   * DeepSolo decoder intra-instance attention  (25 points  x batch nq,  8 heads x 32)
+//   * DeepSolo decoder inter-instance attention  (nq queries x batch 25,  8 heads x 32)
+//     (deformable_transformer.py:386-404, nn.MultiheadAttention core)
+//   * matcher transformers (N <= 6*nq detections, 8 heads x 128)   (roi_heads/transformer.py:208,287)
+// Projections are done by gom_gemm_f32; this kernel is  O = softmax(Q K^T) V  per (batch, head) with
+// generic element strides so the seq-first / batch-swapped views of the reference need no copies.
+// One workgroup = QT query rows x all keys; the score rows live in LDS (no HBM round trip).
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 64;  // keys per staged tile
+
+template <int HD, int QT>
+__global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, float* __restrict__ o,
+                                                       int Lq, int Lk, int inner, long q_bo, long q_bi, long q_ss,
+                                                       long k_bo, long k_bi, long k_ss, long v_bo, long v_bi,
+                                                       long v_ss, long o_bo, long o_bi, long o_ss, float scale) {
+    constexpr int KS = HD + 4;  // padded K-tile row (conflict-free ds_read_b128 across keys)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Lkp = (Lk + KT - 1) / KT * KT;
+    float* Qs = smem;                       // [QT][HD]
+    float* KVs = Qs + QT * HD;              // [KT][KS]
+    float* Ss = KVs + KT * KS;              // [QT][Lkp]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.z * QT, h = blockIdx.y;
+    const long bo = blockIdx.x / inner, bi = blockIdx.x % inner;   // batch = outer x inner, two strides each
+    const float* qb = q + bo * q_bo + bi * q_bi + h * HD;
+    const float* kb = k + bo * k_bo + bi * k_bi + h * HD;
+    const float* vb = v + bo * v_bo + bi * v_bi + h * HD;
+    float* ob = o + bo * o_bo + bi * o_bi + h * HD;
+
+    for (int u = tid; u < QT * HD / 4; u += 256) {
+        const int r = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (i0 + r < Lq) x = *reinterpret_cast<const f32x4*>(qb + (i0 + r) * q_ss + d4) * scale;
+        *reinterpret_cast<f32x4*>(Qs + r * HD + d4) = x;
+    }
+
+    // ---- S = (scale*Q) K^T -------------------------------------------------------------------
+    constexpr int RPT = QT / 4;  // score rows per thread (rows wave, wave+4, ...)
+    for (int kt = 0; kt < Lkp; kt += KT) {
+        __syncthreads();
+        for (int u = tid; u < KT * HD / 4; u += 256) {
+            const int r = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (kt + r < Lk) x = *reinterpret_cast<const f32x4*>(kb + (kt + r) * k_ss + d4);
+            *reinterpret_cast<f32x4*>(KVs + r * KS + d4) = x;
+        }
+        __syncthreads();
+        float acc[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) acc[r] = 0.f;
+#pragma unroll 4
+        for (int d = 0; d < HD; d += 4) {
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(KVs + lane * KS + d);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(Qs + (wave + 4 * r) * HD + d);
+                acc[r] = fmaf(qv[0], kv[0], acc[r]);
+                acc[r] = fmaf(qv[1], kv[1], acc[r]);
+                acc[r] = fmaf(qv[2], kv[2], acc[r]);
+                acc[r] = fmaf(qv[3], kv[3], acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) Ss[(wave + 4 * r) * Lkp + kt + lane] = (kt + lane < Lk) ? acc[r] : -INFINITY;
+    }
+    __syncthreads();
+
+    // ---- row softmax (exact: exp(x - max) / sum) ----------------------------------------------
+    for (int r = wave; r < QT; r += 4) {
+        float* row = Ss + r * Lkp;
+        float mx = -INFINITY;
+        for (int j = lane; j < Lk; j += 64) mx = fmaxf(mx, row[j]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < Lk; j += 64) {
+            const float e = expf(row[j] - mx);
+            row[j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int j = lane; j < Lkp; j += 64) row[j] = (j < Lk) ? row[j] * inv : 0.f;
+    }
+
+    // ---- O = P V ---------------------------------------------------------------------------------
+    constexpr int ROWS_PER_PASS = 256 / HD;          // distinct rows covered by the block at once
+    constexpr int OPT = QT / ROWS_PER_PASS;          // outputs per thread
+    const int d = tid % HD, rg = tid / HD;
+    float oacc[OPT];
+#pragma unroll
+    for (int r = 0; r < OPT; ++r) oacc[r] = 0.f;
+    for (int kt = 0; kt < Lkp; kt += KT) {
+        __syncthreads();
+        for (int u = tid; u < KT * HD / 4; u += 256) {
+            const int r = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (kt + r < Lk) x = *reinterpret_cast<const f32x4*>(vb + (kt + r) * v_ss + d4);
+            *reinterpret_cast<f32x4*>(KVs + r * KS + d4) = x;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int j = 0; j < KT; ++j) {
+            const float vv = KVs[j * KS + d];
+#pragma unroll
+            for (int r = 0; r < OPT; ++r) oacc[r] = fmaf(Ss[(rg + r * ROWS_PER_PASS) * Lkp + kt + j], vv, oacc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < OPT; ++r) {
+        const int i = i0 + rg + r * ROWS_PER_PASS;
+        if (i < Lq) ob[i * o_ss + d] = oacc[r];
+    }
+}
+
+template <int HD, int QT>
+int launch(const float* q, const float* k, const float* v, float* o, int outer, int inner, int heads, int Lq, int Lk,
+           const long* st, float scale, hipStream_t s, bool* fits) {
+    const int Lkp = (Lk + KT - 1) / KT * KT;
+    const size_t lds = sizeof(float) * ((size_t)QT * HD + (size_t)KT * (HD + 4) + (size_t)QT * Lkp);
+    *fits = lds <= 160 * 1024;
+    if (!*fits) return GOM_OK;
+    auto kern = mha_core_kernel<HD, QT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(outer * inner), (unsigned)heads, (unsigned)cdiv(Lq, QT)), dim3(256), lds, s,
+                       q, k, v, o, Lq, Lk, inner, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9],
+                       st[10], st[11], scale);
+    return gom_launch_status();
+}
+
+}  // namespace
+
+extern "C" int gom_mha_core_f32(const float* q, const float* k, const float* v, float* o, int batch_outer,
+                                int batch_inner, int heads, int head_dim, int Lq, int Lk, const long* strides,
+                                void* stream) {
+    GOM_CHECK_ARG(q && k && v && o && strides);
+    GOM_CHECK_ARG(batch_outer >= 0 && batch_inner > 0 && heads > 0 && Lq >= 0 && Lk >= 0);
+    GOM_CHECK_ARG(head_dim == 32 || head_dim == 128);
+    for (int i = 0; i < 9; ++i) GOM_CHECK_ARG((strides[i] % 4) == 0);        // q, k, v rows are read as float4
+    if (batch_outer == 0 || Lq == 0) return GOM_OK;
+    GOM_CHECK_ARG(Lk > 0);
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    hipStream_t s = (hipStream_t)stream;
+    bool fits = false;
+    int rc;
+#define TRY(HD, QT)                                                                                             \
+    rc = launch<HD, QT>(q, k, v, o, batch_outer, batch_inner, heads, Lq, Lk, strides, scale, s, &fits);        \
+    if (rc != GOM_OK || fits) return rc;
+    if (head_dim == 32) {
+        TRY(32, 32) TRY(32, 8)
+    } else {
+        TRY(128, 32) TRY(128, 8)
+    }
+#undef TRY
+    return GOM_ERR_UNSUPPORTED;  // more keys than one workgroup's LDS can hold
+}

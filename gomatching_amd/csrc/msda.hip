@@ -1,0 +1,136 @@
+// Multi-scale deformable attention sampling (forward) for gfx950.
+//
+// Drop-in for the reference's only native op, `adet._C.ms_deform_attn_forward`
+// (/root/reference/third_party/adet/layers/csrc/DeformAttn/ms_deform_attn.h:20-39, kernel
+// ms_deform_im2col_cuda.cuh:237-299, bilinear :33-84):
+//     out[b,q,m,:] = sum_{l,p} w[b,q,m,l,p] * bilinear(value_l[b,:,m,:], loc[b,q,m,l,p])
+// with zero padding outside the level map and the kernel's (-1,H)x(-1,W) acceptance window.
+//
+// The reference maps one thread to one output ELEMENT (block 1024), so the 32 threads of a head
+// re-read the same loc/weight and gather 4-byte corners.  Here one wavefront owns one query: 8
+// lanes per head, each lane 4 channels, so every corner fetch is a 16-byte load, a head's corner
+// is one 128-byte line, and the query's 256 outputs leave as one contiguous 1 KiB store.  The op
+// is gather-bound (HBM/L2), not MFMA work.
+#include "common.h"
+
+namespace {
+
+constexpr int HEADS = 8, CH = 32, LEVELS = 4;
+
+template <int POINTS>
+__global__ __launch_bounds__(256) void msda_fwd_kernel(const float* __restrict__ value,
+                                                       const int64_t* __restrict__ shapes,
+                                                       const int64_t* __restrict__ lsi,
+                                                       const float* __restrict__ loc,
+                                                       const float* __restrict__ attw, float* __restrict__ out,
+                                                       int B, int S, int Lq) {
+    const long q_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per (b, q)
+    if (q_global >= (long)B * Lq) return;
+    const int lane = threadIdx.x & 63;
+    const int m = lane >> 3;            // head
+    const int c4 = (lane & 7) * 4;      // first of this lane's 4 channels
+    const int b = (int)(q_global / Lq);
+
+    const float* vb = value + (size_t)b * S * (HEADS * CH) + m * CH + c4;
+    const float* lp = loc + ((size_t)q_global * HEADS + m) * (LEVELS * POINTS * 2);
+    const float* wp = attw + ((size_t)q_global * HEADS + m) * (LEVELS * POINTS);
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < LEVELS; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const float* vl = vb + (size_t)lsi[l] * (HEADS * CH);
+#pragma unroll
+        for (int p = 0; p < POINTS; ++p) {
+            const float lx = lp[(l * POINTS + p) * 2], ly = lp[(l * POINTS + p) * 2 + 1];
+            const float w = wp[l * POINTS + p];
+            const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+            if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+                const float lh = h_im - h_low, lw = w_im - w_low;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const bool y0 = h_low >= 0, y1 = h_low + 1 <= H - 1;
+                const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
+                const float* base = vl + ((size_t)h_low * W + w_low) * (HEADS * CH);
+                f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
+                if (y0 && x0) v1 = *reinterpret_cast<const f32x4*>(base);
+                if (y0 && x1) v2 = *reinterpret_cast<const f32x4*>(base + HEADS * CH);
+                if (y1 && x0) v3 = *reinterpret_cast<const f32x4*>(base + (size_t)W * (HEADS * CH));
+                if (y1 && x1) v4 = *reinterpret_cast<const f32x4*>(base + (size_t)(W + 1) * (HEADS * CH));
+                const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                acc += val * w;
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)q_global * (HEADS * CH) + m * CH + c4) = acc;
+}
+
+// sampling-location arithmetic + softmax of ms_deform_attn.py:136-145, fused in one pass:
+//   raw [Q, 8*(L*P*2) offsets | 8*(L*P) logits] (one GEMM output row) , ref [Q, L, 2]
+//   -> loc [Q,8,L,P,2], w [Q,8,L,P]
+template <int POINTS>
+__global__ __launch_bounds__(256) void msda_prep_kernel(const float* __restrict__ raw, int ld_raw,
+                                                        const float* __restrict__ ref, int ref_levels,
+                                                        const int64_t* __restrict__ shapes,
+                                                        float* __restrict__ loc, float* __restrict__ attw, long Q) {
+    constexpr int LP = LEVELS * POINTS;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (q, head)
+    if (idx >= Q * HEADS) return;
+    const long q = idx / HEADS;
+    const int m = (int)(idx % HEADS);
+    const float* off = raw + q * ld_raw + m * (LP * 2);
+    const float* lg = raw + q * ld_raw + HEADS * LP * 2 + m * LP;
+    float e[LP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { e[i] = lg[i]; mx = fmaxf(mx, e[i]); }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { e[i] = expf(e[i] - mx); sum += e[i]; }
+    float* wo = attw + idx * LP;
+    float* lo = loc + idx * (LP * 2);
+#pragma unroll
+    for (int l = 0; l < LEVELS; ++l) {
+        const float Hf = (float)shapes[2 * l], Wf = (float)shapes[2 * l + 1];
+        const float* r = ref + (q * ref_levels + (ref_levels == 1 ? 0 : l)) * 2;
+        const float rx = r[0], ry = r[1];
+#pragma unroll
+        for (int p = 0; p < POINTS; ++p) {
+            const int i = l * POINTS + p;
+            wo[i] = e[i] / sum;
+            lo[2 * i] = rx + off[2 * i] / Wf;
+            lo[2 * i + 1] = ry + off[2 * i + 1] / Hf;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gom_ms_deform_attn_forward(const float* value, const int64_t* spatial_shapes,
+                                          const int64_t* level_start_index, const float* sampling_loc,
+                                          const float* attn_weight, float* output, int batch, int spatial_size,
+                                          int num_heads, int channels, int num_levels, int num_query,
+                                          int num_point, void* stream) {
+    GOM_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && output);
+    // the shape the whole DeepSolo family uses; anything else is refused loudly rather than run slowly
+    GOM_CHECK_ARG(num_heads == HEADS && channels == CH && num_levels == LEVELS && num_point == 4);
+    GOM_CHECK_ARG(batch > 0 && spatial_size > 0 && num_query > 0);
+    const long nq = (long)batch * num_query;
+    hipLaunchKernelGGL((msda_fwd_kernel<4>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
+                       spatial_shapes, level_start_index, sampling_loc, attn_weight, output, batch, spatial_size,
+                       num_query);
+    return gom_launch_status();
+}
+
+extern "C" int gom_msda_prepare(const float* raw, int ld_raw, const float* ref, int ref_levels,
+                                const int64_t* spatial_shapes, float* sampling_loc, float* attn_weight,
+                                long num_query_total, void* stream) {
+    GOM_CHECK_ARG(raw && ref && spatial_shapes && sampling_loc && attn_weight);
+    GOM_CHECK_ARG(ld_raw >= HEADS * LEVELS * 4 * 3 && (ref_levels == 1 || ref_levels == LEVELS));
+    if (num_query_total == 0) return GOM_OK;
+    hipLaunchKernelGGL((msda_prep_kernel<4>), dim3((unsigned)cdiv(num_query_total * HEADS, 256)), dim3(256), 0,
+                       (hipStream_t)stream, raw, ld_raw, ref, ref_levels, spatial_shapes, sampling_loc,
+                       attn_weight, num_query_total);
+    return gom_launch_status();
+}

@@ -1,0 +1,109 @@
+// Association-score kernels of the LST-Matcher tracker (gfx950).  Latency-bound, tiny tensors: the
+// float arithmetic of run_short_term_match / run_long_term_match runs here, the integer id
+// bookkeeping and the assignment problem stay on the host exactly as in the reference.
+//   lstmatcher.py:373-381            _activate_asso (per-frame softmax with a zero background logit)
+//   gom_lstmatcher.py:429-445,510-547 trajectory score, last-box IoU, time decay, centre-distance gate
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows,
+                                                          float* __restrict__ out, int n, int d4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)n * d4) return;
+    const int r = (int)(i / d4), c = (int)(i % d4);
+    *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(src + ((size_t)rows[r] * d4 + c) * 4);
+}
+
+// one wave per (query row, frame segment)
+__global__ __launch_bounds__(256) void asso_activate_kernel(const float* __restrict__ logits, int ld,
+                                                            const int* __restrict__ offs, int T, int n_k,
+                                                            float* __restrict__ out, int ld_out) {
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long)n_k * T) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(w / T), t = (int)(w % T);
+    const int lo = offs[t], hi = offs[t + 1];
+    const float* row = logits + (size_t)i * ld;
+    float mx = 0.f;                                          // the appended background logit
+    for (int j = lo + lane; j < hi; j += 64) mx = fmaxf(mx, row[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lo + lane; j < hi; j += 64) sum += expf(row[j] - mx);
+    sum = wave_sum(sum) + expf(0.f - mx);
+    for (int j = lo + lane; j < hi; j += 64) out[(size_t)i * ld_out + j] = expf(row[j] - mx) / sum;
+}
+
+// meta layout (int32): nonk[Np] | col_of[Np] | last_idx[M] | k_inds[n_k]
+__global__ __launch_bounds__(256) void track_score_kernel(const float* __restrict__ act, int ld,
+                                                          const int* __restrict__ meta, const float* __restrict__ decay,
+                                                          const float* __restrict__ boxes, float img_w, float img_h,
+                                                          int n_k, int Np, int M, int with_iou, float max_center_dist,
+                                                          float* __restrict__ traj) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_k * M) return;
+    const int i = idx / M, m = idx % M;
+    const int* nonk = meta;
+    const int* col_of = meta + Np;
+    const int* last_idx = meta + 2 * Np;
+    const int* k_inds = meta + 2 * Np + M;
+    const float* kb = boxes + (size_t)k_inds[i] * 4;
+    const float kx0 = kb[0] / img_w, ky0 = kb[1] / img_h, kx1 = kb[2] / img_w, ky1 = kb[3] / img_h;
+    float s = 0.f;
+    bool any_valid = false;
+    const float kcx = (kx0 + kx1) / 2.f, kcy = (ky0 + ky1) / 2.f;
+    const float ks = (kx1 - kx0) * (kx1 - kx0) + (ky1 - ky0) * (ky1 - ky0);
+    for (int j = 0; j < Np; ++j) {
+        if (col_of[j] != m) continue;
+        float a = act[(size_t)i * ld + nonk[j]];
+        if (decay) a *= decay[j];
+        s += a;
+        if (max_center_dist > 0.f) {
+            const float* nb = boxes + (size_t)nonk[j] * 4;
+            const float nx0 = nb[0] / img_w, ny0 = nb[1] / img_h, nx1 = nb[2] / img_w, ny1 = nb[3] / img_h;
+            const float dx = kcx - (nx0 + nx1) / 2.f, dy = kcy - (ny0 + ny1) / 2.f;
+            if ((dx * dx + dy * dy) / (ks + 1e-8f) < max_center_dist) any_valid = true;
+        }
+    }
+    if (with_iou) {
+        const float* lb = boxes + (size_t)nonk[last_idx[m]] * 4;
+        const float lx0 = lb[0] / img_w, ly0 = lb[1] / img_h, lx1 = lb[2] / img_w, ly1 = lb[3] / img_h;
+        const float w = fmaxf(fminf(kx1, lx1) - fmaxf(kx0, lx0), 0.f);
+        const float h = fmaxf(fminf(ky1, ly1) - fmaxf(ky0, ly0), 0.f);
+        const float inter = w * h;
+        const float a1 = (kx1 - kx0) * (ky1 - ky0), a2 = (lx1 - lx0) * (ly1 - ly0);
+        const float iou = inter > 0.f ? inter / (a1 + a2 - inter) : 0.f;
+        s = fmaxf(s, iou);
+    }
+    if (max_center_dist > 0.f && !any_valid) s = 0.f;
+    traj[idx] = s;
+}
+
+}  // namespace
+
+extern "C" int gom_gather_rows_f32(const float* src, const int* rows, float* out, int n, int dim, void* stream) {
+    GOM_CHECK_ARG(src && rows && out && n >= 0 && dim > 0 && (dim % 4) == 0);
+    if (n == 0) return GOM_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv((long)n * dim / 4, 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, rows, out, n, dim / 4);
+    return gom_launch_status();
+}
+
+extern "C" int gom_asso_activate_f32(const float* logits, int ld, const int* frame_offsets, int num_frames, int n_k,
+                                     float* out, int ld_out, void* stream) {
+    GOM_CHECK_ARG(logits && frame_offsets && out && num_frames > 0 && n_k >= 0);
+    if (n_k == 0) return GOM_OK;
+    hipLaunchKernelGGL(asso_activate_kernel, dim3((unsigned)cdiv((long)n_k * num_frames, 4)), dim3(256), 0,
+                       (hipStream_t)stream, logits, ld, frame_offsets, num_frames, n_k, out, ld_out);
+    return gom_launch_status();
+}
+
+extern "C" int gom_track_score_f32(const float* act, int ld, const int* meta, const float* decay, const float* boxes,
+                                   float img_w, float img_h, int n_k, int Np, int M, int with_iou,
+                                   float max_center_dist, float* traj, void* stream) {
+    GOM_CHECK_ARG(act && meta && boxes && traj && n_k >= 0 && Np >= 0 && M >= 0);
+    if (n_k == 0 || M == 0) return GOM_OK;
+    hipLaunchKernelGGL(track_score_kernel, dim3((unsigned)cdiv((long)n_k * M, 256)), dim3(256), 0, (hipStream_t)stream,
+                       act, ld, meta, decay, boxes, img_w, img_h, n_k, Np, M, with_iou, max_center_dist, traj);
+    return gom_launch_status();
+}

@@ -1,0 +1,80 @@
+"""ctypes binding of libgomatching_hip.so (the C ABI in include/gomatching_hip.h).
+
+The product path has NO fallback: if the shared library is missing or cannot be loaded, importing
+the ops raises.  torch is used for device memory and streams only.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_long, c_float, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgomatching_hip.so")
+
+GOM_OK = 0
+_ERR = {1: "GOM_ERR_INVALID_ARG (violated precondition)", 2: "GOM_ERR_UNSUPPORTED"}
+
+P = c_void_p
+I = c_int
+L = c_long
+F = c_float
+
+# name -> (restype, argtypes); must list every symbol declared in include/gomatching_hip.h
+SIGNATURES = {
+    "gom_abi_version": (I, []),
+    "gom_built_for_arch": (ctypes.c_char_p, []),
+    "gom_ms_deform_attn_forward": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "gom_msda_prepare": (I, [P, I, P, I, P, P, P, L, P]),
+    "gom_gemm_f32": (I, [P, P, P, I, P, I, P, P, P, I, I, P, I, I, I, I, P]),
+    "gom_conv2d_nhwc_f32": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P]),
+    "gom_layernorm_f32": (I, [P, P, P, P, P, L, I, F, P]),
+    "gom_groupnorm32_nhwc_f32": (I, [P, P, P, P, P, L, I, I, I, F, P]),
+    "gom_mha_core_f32": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.POINTER(c_long), P]),
+    "gom_preprocess_nchw_to_nhwc4": (I, [P, ctypes.POINTER(c_float), ctypes.POINTER(c_float), P, I, I, I, P]),
+    "gom_maxpool3x3s2_nhwc_f32": (I, [P, P, I, I, I, I, P]),
+    "gom_pos_encoding_2d_f32": (I, [P, P, P, I, I, P]),
+    "gom_point_pos_embed_f32": (I, [P, P, P, L, P]),
+    "gom_ref_sigmoid_f32": (I, [P, I, P, P, L, I, P]),
+    "gom_proposal_valid": (I, [P, P, I, P, L, P]),
+    "gom_encoder_reference_points": (I, [P, P, I, P, L, P]),
+    "gom_bezier_reference_points": (I, [P, P, P, P, I, P, P, I, L, I, I, P]),
+    "gom_add_f32": (I, [P, P, P, L, P]),
+    "gom_broadcast_rows_f32": (I, [P, P, L, I, P]),
+    "gom_topk_workspace_bytes": (L, [I, L, I]),
+    "gom_topk_tokens": (I, [P, I, P, P, I, L, I, P, P, P]),
+    "gom_argmax_rows_f32": (I, [P, I, I, L, P, P]),
+    "gom_detect_post": (I, [P, I, P, I, P, P, P, I, I, I, F, F, F, F, F, P, P, P, P, P, P, P, P]),
+    "gom_gather_rows_f32": (I, [P, P, P, I, I, P]),
+    "gom_asso_activate_f32": (I, [P, I, P, I, I, P, I, P]),
+    "gom_track_score_f32": (I, [P, I, P, P, P, F, F, I, I, I, I, F, P, P]),
+    "gom_linear_sum_assignment": (I, [ctypes.POINTER(ctypes.c_double), L, L, ctypes.POINTER(c_long),
+                                      ctypes.POINTER(c_long)]),
+}
+
+_lib = None
+
+
+class GomError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise loudly when it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GomError("libgomatching_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(expected at %s)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != GOM_OK:
+        msg = _ERR.get(rc, "HIP error %d" % (rc - 1000) if rc >= 1000 else "error %d" % rc)
+        raise GomError("%s failed: %s" % (what or "libgomatching_hip call", msg))

@@ -1,0 +1,294 @@
+"""Tensor-level wrappers over the C ABI (torch = device memory + stream plumbing only).
+
+Every function launches hand-written HIP kernels from libgomatching_hip.so on torch's current stream;
+none has a CPU or torch-op fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib_mod
+from .lib import check
+
+_f32 = torch.float32
+
+
+def _L():
+    return _lib_mod.load()
+
+
+def _p(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if t.dtype != _f32 or not t.is_cuda or not t.is_contiguous():
+            raise _lib_mod.GomError("expected a contiguous float32 CUDA tensor, got %s %s contiguous=%s" % (
+                t.dtype, t.device, t.is_contiguous()))
+
+
+def empty(shape, like=None, dtype=_f32, device=None):
+    return torch.empty(shape, dtype=dtype, device=device if device is not None else like.device)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, out=None, M=None):
+    """C = act((A[+A2])[M,K] @ W[N,K]^T * scale + bias + R).  A may be a 2-D row-strided view
+    (stride(1) == 1); W likewise (row slices of a weight matrix)."""
+    assert A.dim() == 2 and W.dim() == 2 and A.stride(1) == 1 and W.stride(1) == 1
+    K = A.shape[1]
+    assert W.shape[1] == K
+    N = W.shape[0]
+    if M is None:
+        M = A.shape[0] if rows is None else rows.numel()
+    lda, ldw = A.stride(0) if A.shape[0] > 1 else K, W.stride(0) if N > 1 else K
+    if A2 is not None:
+        assert A2.shape == A.shape and A2.stride() == A.stride()
+    if out is None:
+        out = torch.empty((M, N), dtype=_f32, device=A.device)
+    assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] == N
+    ldc = out.stride(0) if out.shape[0] > 1 else N
+    ldr = 0
+    if R is not None:
+        assert R.dim() == 2 and R.stride(1) == 1 and R.shape[1] == N
+        ldr = R.stride(0) if R.shape[0] > 1 else N
+    if rows is not None:
+        assert rows.dtype == torch.int32 and rows.is_contiguous()
+    check(_L().gom_gemm_f32(_p(A), _p(A2), _p(rows), lda, _p(W), ldw, _p(scale), _p(bias), _p(R), ldr,
+                            1 if relu else 0, _p(out), ldc, M, N, K, _stream()), "gom_gemm_f32")
+    return out
+
+
+def conv2d_nhwc(x, w_ohwi, scale=None, shift=None, R=None, relu=False, stride=1, pad=0):
+    """x [B,H,W,Cin] -> [B,OH,OW,Cout]; w [Cout,KH,KW,Cin]."""
+    _chk_f32(x, w_ohwi, scale, shift, R)
+    B, H, Wd, Cin = x.shape
+    Cout, KH, KW, Cin2 = w_ohwi.shape
+    assert Cin == Cin2
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (Wd + 2 * pad - KW) // stride + 1
+    y = torch.empty((B, OH, OW, Cout), dtype=_f32, device=x.device)
+    if R is not None:
+        assert R.shape == y.shape
+    check(_L().gom_conv2d_nhwc_f32(_p(x), _p(w_ohwi), _p(scale), _p(shift), _p(R), 1 if relu else 0, _p(y), B, H, Wd,
+                                   Cin, Cout, KH, KW, stride, pad, _stream()), "gom_conv2d_nhwc_f32")
+    return y
+
+
+# ------------------------------------------------------------------------------------------ norms
+def layernorm(x, gamma, beta, residual=None, eps=1e-5, out=None):
+    _chk_f32(x, gamma, beta, residual)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    if out is None:
+        out = torch.empty_like(x)
+    check(_L().gom_layernorm_f32(_p(x), _p(residual), _p(gamma), _p(beta), _p(out), rows, D, eps, _stream()),
+          "gom_layernorm_f32")
+    return out
+
+
+def groupnorm32_into(x, gamma, beta, out_view, out_batch_stride, eps=1e-5):
+    """x [B,HW,256] -> out_view (pointer to out[0, offset, 0] of a [B,S,256] buffer)."""
+    _chk_f32(x, gamma, beta)
+    B, HW, C = x.shape
+    ws = torch.empty((B * 64,), dtype=torch.float64, device=x.device)
+    check(_L().gom_groupnorm32_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(ws), _p(out_view), out_batch_stride, B, HW, C,
+                                        eps, _stream()), "gom_groupnorm32_nhwc_f32")
+
+
+# ------------------------------------------------------------------------------------------ MSDA
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    """Same signature as the reference's adet._C.ms_deform_attn_forward (im2col_step accepted, unused)."""
+    _chk_f32(value, sampling_loc, attn_weight)
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise _lib_mod.GomError("spatial_shapes / level_start_index must be int64")
+    if not (spatial_shapes.is_cuda and level_start_index.is_cuda and spatial_shapes.is_contiguous()
+            and level_start_index.is_contiguous()):
+        raise _lib_mod.GomError("spatial_shapes / level_start_index must be contiguous CUDA tensors")
+    B, S, M, D = value.shape
+    _, Lq, _, Lv, Pn, _ = sampling_loc.shape
+    out = torch.empty((B, Lq, M * D), dtype=_f32, device=value.device)
+    check(_L().gom_ms_deform_attn_forward(_p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_loc),
+                                          _p(attn_weight), _p(out), B, S, M, D, Lv, Lq, Pn, _stream()),
+          "gom_ms_deform_attn_forward")
+    return out
+
+
+def msda_prepare(raw, ref, spatial_shapes, ref_levels=1):
+    """raw [Q, >=384] (offsets | logits), ref [Q, ref_levels, 2] -> loc [Q,8,4,4,2], w [Q,8,4,4]."""
+    _chk_f32(ref)
+    Q = raw.shape[0]
+    loc = torch.empty((Q, 8, 4, 4, 2), dtype=_f32, device=raw.device)
+    w = torch.empty((Q, 8, 4, 4), dtype=_f32, device=raw.device)
+    check(_L().gom_msda_prepare(_p(raw), raw.stride(0), _p(ref), ref_levels, _p(spatial_shapes), _p(loc), _p(w), Q,
+                                _stream()), "gom_msda_prepare")
+    return loc, w
+
+
+# ------------------------------------------------------------------------------------------ attention
+def mha_core(q, k, v, out, outer, inner, heads, head_dim, Lq, Lk, strides):
+    arr = (ctypes.c_long * 12)(*[int(s) for s in strides])
+    check(_L().gom_mha_core_f32(_p(q), _p(k), _p(v), _p(out), outer, inner, heads, head_dim, Lq, Lk, arr, _stream()),
+          "gom_mha_core_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ glue
+def preprocess(images, mean, std):
+    _chk_f32(images)
+    B, C, H, W = images.shape
+    assert C == 3
+    out = torch.empty((B, H, W, 4), dtype=_f32, device=images.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    check(_L().gom_preprocess_nchw_to_nhwc4(_p(images), m, s, _p(out), B, H, W, _stream()), "gom_preprocess")
+    return out
+
+
+def maxpool3x3s2(x):
+    _chk_f32(x)
+    B, H, W, C = x.shape
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((B, OH, OW, C), dtype=_f32, device=x.device)
+    check(_L().gom_maxpool3x3s2_nhwc_f32(_p(x), _p(y), B, H, W, C, _stream()), "gom_maxpool3x3s2")
+    return y
+
+
+def pos_encoding_into(dim_t, level_embed_row, out_view, H, W):
+    check(_L().gom_pos_encoding_2d_f32(_p(dim_t), _p(level_embed_row), _p(out_view), H, W, _stream()),
+          "gom_pos_encoding_2d_f32")
+
+
+def point_pos_embed(pts, dim_t):
+    _chk_f32(pts, dim_t)
+    Q = pts.numel() // 2
+    out = torch.empty((Q, 256), dtype=_f32, device=pts.device)
+    check(_L().gom_point_pos_embed_f32(_p(pts), _p(dim_t), _p(out), Q, _stream()), "gom_point_pos_embed_f32")
+    return out
+
+
+def ref_sigmoid(delta, ref, C):
+    _chk_f32(ref)
+    Q = ref.numel() // 2
+    out = torch.empty((Q, C), dtype=_f32, device=ref.device)
+    check(_L().gom_ref_sigmoid_f32(_p(delta), delta.stride(0), _p(ref), _p(out), Q, C, _stream()),
+          "gom_ref_sigmoid_f32")
+    return out
+
+
+def proposal_valid(shapes, lsi, S):
+    out = torch.empty((S,), dtype=torch.uint8, device=shapes.device)
+    check(_L().gom_proposal_valid(_p(shapes), _p(lsi), shapes.shape[0], _p(out), S, _stream()), "gom_proposal_valid")
+    return out
+
+
+def encoder_reference_points(shapes, lsi, S):
+    out = torch.empty((S, 2), dtype=_f32, device=shapes.device)
+    check(_L().gom_encoder_reference_points(_p(shapes), _p(lsi), shapes.shape[0], _p(out), S, _stream()),
+          "gom_encoder_reference_points")
+    return out
+
+
+def bezier_reference_points(coord_raw, topk_idx, shapes, lsi, bern, B, S, nq, P):
+    _chk_f32(coord_raw, bern)
+    out = torch.empty((B, nq, P, 2), dtype=_f32, device=coord_raw.device)
+    check(_L().gom_bezier_reference_points(_p(coord_raw), _p(topk_idx), _p(shapes), _p(lsi), shapes.shape[0],
+                                           _p(bern), _p(out), B, S, nq, P, _stream()), "gom_bezier_reference_points")
+    return out
+
+
+def add(a, b):
+    _chk_f32(a, b)
+    out = torch.empty_like(a)
+    check(_L().gom_add_f32(_p(a), _p(b), _p(out), a.numel(), _stream()), "gom_add_f32")
+    return out
+
+
+def broadcast_rows(src, B):
+    _chk_f32(src)
+    out = torch.empty((B,) + tuple(src.shape), dtype=_f32, device=src.device)
+    check(_L().gom_broadcast_rows_f32(_p(src), _p(out), src.numel(), B, _stream()), "gom_broadcast_rows_f32")
+    return out
+
+
+def topk_tokens(logits, B, S, k, valid=None, invalid_logit=None):
+    """logits: [B*S, ld] (column 0 used) -> int32 [B,k] sorted by value desc."""
+    nbytes = _L().gom_topk_workspace_bytes(B, S, k)
+    ws = torch.empty((max(nbytes, 8),), dtype=torch.uint8, device=logits.device)
+    idx = torch.empty((B, k), dtype=torch.int32, device=logits.device)
+    check(_L().gom_topk_tokens(_p(logits), logits.stride(0), _p(valid), _p(invalid_logit), B, S, k, _p(ws), _p(idx),
+                               _stream()), "gom_topk_tokens")
+    return idx
+
+
+def argmax_rows(x):
+    rows, V = x.shape
+    out = torch.empty((rows,), dtype=torch.int32, device=x.device)
+    check(_L().gom_argmax_rows_f32(_p(x), x.stride(0), V, rows, _p(out), _stream()), "gom_argmax_rows_f32")
+    return out
+
+
+def detect_post(cls, recls, ctrl, bd, recs, B, nq, P, img_h, img_w, det_thr, nms_thr, asso_thr):
+    dev = cls.device
+    out = {
+        "count": torch.zeros((B,), dtype=torch.int32, device=dev),
+        "keep_idx": torch.zeros((B, nq), dtype=torch.int32, device=dev),
+        "scores": torch.zeros((B, nq), dtype=_f32, device=dev),
+        "boxes": torch.zeros((B, nq, 4), dtype=_f32, device=dev),
+        "ctrl": torch.zeros((B, nq, P * 2), dtype=_f32, device=dev),
+        "bd": torch.zeros((B, nq, P, 4), dtype=_f32, device=dev),
+        "recs": torch.zeros((B, nq, P), dtype=torch.int64, device=dev),
+    }
+    check(_L().gom_detect_post(_p(cls), cls.stride(0), _p(recls), recls.stride(0) if recls is not None else 0,
+                               _p(ctrl), _p(bd), _p(recs), B, nq, P, float(img_h), float(img_w), float(det_thr),
+                               float(nms_thr), float(asso_thr), _p(out["count"]), _p(out["keep_idx"]),
+                               _p(out["scores"]), _p(out["boxes"]), _p(out["ctrl"]), _p(out["bd"]), _p(out["recs"]),
+                               _stream()), "gom_detect_post")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ tracker
+def gather_rows(src, rows):
+    n, D = rows.numel(), src.shape[1]
+    out = torch.empty((n, D), dtype=_f32, device=src.device)
+    check(_L().gom_gather_rows_f32(_p(src), _p(rows), _p(out), n, D, _stream()), "gom_gather_rows_f32")
+    return out
+
+
+def asso_activate(logits, offsets, T):
+    n_k, N = logits.shape
+    out = torch.empty_like(logits)
+    check(_L().gom_asso_activate_f32(_p(logits), logits.stride(0) if n_k > 1 else N, _p(offsets), T, n_k, _p(out),
+                                     N, _stream()), "gom_asso_activate_f32")
+    return out
+
+
+def track_score(act, meta, decay, boxes, img_w, img_h, n_k, Np, M, with_iou, max_center_dist):
+    traj = torch.empty((n_k, M), dtype=_f32, device=act.device)
+    check(_L().gom_track_score_f32(_p(act), act.shape[1], _p(meta), _p(decay), _p(boxes), float(img_w), float(img_h),
+                                   n_k, Np, M, 1 if with_iou else 0, float(max_center_dist), _p(traj), _stream()),
+          "gom_track_score_f32")
+    return traj
+
+
+def linear_sum_assignment(cost):
+    """Host LSA with SciPy-compatible tie-breaking; cost: 2-D numpy array."""
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    nr, nc = cost.shape
+    n = min(nr, nc)
+    ri = (ctypes.c_long * max(n, 1))()
+    ci = (ctypes.c_long * max(n, 1))()
+    rc = _L().gom_linear_sum_assignment(cost.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), nr, nc, ri, ci)
+    if rc < 0:
+        raise _lib_mod.GomError("gom_linear_sum_assignment failed (%d): cost matrix is infeasible or invalid" % rc)
+    return np.asarray(ri[:rc], dtype=np.int64), np.asarray(ci[:rc], dtype=np.int64)

@@ -1,0 +1,146 @@
+/* gomatching_hip.h -- C ABI of libgomatching_hip.so: the MI355X (gfx950) GoMatching inference hot path.
+ *
+ * Drop-in boundary.  The reference (Hxyz-123/GoMatching) has exactly one native
+ * interface on this path, the pybind module `adet._C` (third_party/adet/layers/csrc/vision.cpp:52-55); its
+ * forward entry is replaced 1:1 by gom_ms_deform_attn_forward below.  Everything else on the path is
+ * stock torch.nn in the reference; here those ops are hand-written HIP kernels behind the remaining entry
+ * points, which the Python mirror of the reference's META_ARCH / ROI_HEADS classes
+ * (gomatching_amd/modeling) binds through ctypes.  INTEGRATION.md shows the reference-side stubs.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every tensor pointer is DEVICE memory unless marked [host];
+ *   - tensors are dense row-major fp32, channels-last (NHWC / token-major), 16-byte aligned;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous and capture-safe
+ *     (no allocation, no synchronisation) unless stated;
+ *   - return value: GOM_OK, GOM_ERR_INVALID_ARG for a violated precondition (the reference raises a
+ *     RuntimeError from AT_ASSERTM there, ms_deform_attn_cuda.cu:28-52), GOM_ERR_UNSUPPORTED, or
+ *     GOM_ERR_HIP_BASE + hipError_t for a launch failure (the reference only printf()s those,
+ *     ms_deform_im2col_cuda.cuh:948-952).
+ */
+#ifndef GOMATCHING_HIP_H_
+#define GOMATCHING_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOM_OK 0
+#define GOM_ERR_INVALID_ARG 1
+#define GOM_ERR_UNSUPPORTED 2
+#define GOM_ERR_HIP_BASE 1000
+
+#define GOM_ABI_VERSION 1
+int gom_abi_version(void);
+/* gfx arch string of device 0's code object target, e.g. "gfx950" (static storage). */
+const char* gom_built_for_arch(void);
+
+/* ---- A7: multi-scale deformable attention, forward --------------------------------------------
+ * Replaces at::Tensor ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc,
+ * attn_weight, im2col_step)  (third_party/adet/layers/csrc/DeformAttn/ms_deform_attn.h:20-39 ->
+ * ms_deform_attn_cuda.cu:20-80 -> ms_deform_im2col_cuda.cuh:237-299).
+ *   value [batch, spatial_size, num_heads, channels] ; spatial_shapes [num_levels,2] (H,W) int64 ;
+ *   level_start_index [num_levels] int64 ; sampling_loc [batch, num_query, heads, levels, points, 2] ;
+ *   attn_weight [batch, num_query, heads, levels, points] ; output [batch, num_query, heads*channels]
+ * The caller owns `output` (the reference allocates it with at::zeros; every element is written here).
+ * im2col_step has no equivalent: the whole batch is one launch. */
+int gom_ms_deform_attn_forward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const float* sampling_loc, const float* attn_weight, float* output, int batch,
+                               int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                               int num_point, void* stream);
+
+/* Sampling-location + softmax arithmetic of MSDeformAttn.forward (ms_deform_attn.py:136-145).
+ * raw [Q, ld_raw]: columns [0,256) = sampling_offsets output, [256,384) = attention_weights logits;
+ * ref [Q, ref_levels, 2] (ref_levels 1 = same point on every level, the unpadded case). */
+int gom_msda_prepare(const float* raw, int ld_raw, const float* ref, int ref_levels, const int64_t* spatial_shapes,
+                     float* sampling_loc, float* attn_weight, long num_query_total, void* stream);
+
+/* ---- A2/A4/A6/A9/A10/A13/A14: dense contractions on fp32 MFMA -----------------------------------
+ * C[M,N] = act( (A[+A2])[M,K] . W[N,K]^T * scale[N] + shift[N] + R[M,N] )
+ * nn.Linear: W = weight, shift = bias, scale = NULL.  a_rows (optional) gathers rows of A (and A2).
+ * K, lda, ldw multiples of 4. */
+int gom_gemm_f32(const float* A, const float* A2, const int* a_rows, int lda, const float* W, int ldw,
+                 const float* scale, const float* shift, const float* R, int ldr, int relu, float* C, int ldc, int M,
+                 int N, int K, void* stream);
+
+/* Implicit-GEMM convolution, NHWC activations, OHWI weights [Cout, KH, KW, Cin], square kernel 1/3/7,
+ * Cin a power of two >= 4.  Epilogue as above: FrozenBatchNorm as (scale, shift) (Detectron2
+ * FrozenBatchNorm2d), conv bias as shift, bottleneck shortcut as R, ReLU.  Y [B, OH, OW, Cout]. */
+int gom_conv2d_nhwc_f32(const float* X, const float* Wt, const float* scale, const float* shift, const float* R,
+                        int relu, float* Y, int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride,
+                        int pad, void* stream);
+
+/* ---- normalisation ---------------------------------------------------------------------------------*/
+/* out = LayerNorm(x + residual) * gamma + beta over rows of dim 256 or 1024 (residual may be NULL). */
+int gom_layernorm_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* out,
+                      long rows, int dim, float eps, void* stream);
+/* GroupNorm(32, 256) over [B, HW, 256]; writes out[b*out_batch_stride + r*256 + c] (lets the caller scatter a
+ * level straight into the flattened multi-level token buffer).  stats_ws: B*64 doubles of scratch. */
+int gom_groupnorm32_nhwc_f32(const float* x, const float* gamma, const float* beta, double* stats_ws, float* out,
+                             long out_batch_stride, int B, int HW, int channels, float eps, void* stream);
+
+/* ---- attention core: O = softmax(Q K^T / sqrt(head_dim)) V per (batch, head) -------------------------
+ * batch = batch_outer x batch_inner.  Element (bo, bi, i, h, d) of q lives at
+ * q[bo*S[0] + bi*S[1] + i*S[2] + h*head_dim + d]; strides [host] S[12] = q(bo,bi,seq) k(..) v(..) o(..).
+ * head_dim 32 (DeepSolo decoder, deformable_transformer.py:388-402) or 128 (matcher, transformer.py:208,287). */
+int gom_mha_core_f32(const float* q, const float* k, const float* v, float* o, int batch_outer, int batch_inner,
+                     int heads, int head_dim, int Lq, int Lk, const long* strides, void* stream);
+
+/* ---- glue (A1, A2 stem pool, A3, A5, A8, A9) ----------------------------------------------------------*/
+/* mean3/std3 are [host] arrays.  images [B,3,H,W] -> out [B,H,W,4] (4th channel 0). */
+int gom_preprocess_nchw_to_nhwc4(const float* images, const float* mean3, const float* std3, float* out, int B, int H,
+                                 int W, void* stream);
+int gom_maxpool3x3s2_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, void* stream);
+/* out [H*W, 256] = PositionalEncoding2D(normalize=True) + level_embed, for an unpadded H x W level. */
+int gom_pos_encoding_2d_f32(const float* dim_t128, const float* level_embed256, float* out, int H, int W,
+                            void* stream);
+int gom_point_pos_embed_f32(const float* pts, const float* dim_t128, float* out, long num_points, void* stream);
+/* out[q,c] = sigmoid(delta[q*ld_delta + c] + inverse_sigmoid(ref[q, c%2])), C in {2,4}. */
+int gom_ref_sigmoid_f32(const float* delta, int ld_delta, const float* ref, float* out, long num_points, int C,
+                        void* stream);
+int gom_proposal_valid(const int64_t* spatial_shapes, const int64_t* level_start_index, int num_levels,
+                       unsigned char* valid, long S, void* stream);
+int gom_encoder_reference_points(const int64_t* spatial_shapes, const int64_t* level_start_index, int num_levels,
+                                 float* ref, long S, void* stream);
+int gom_bezier_reference_points(const float* coord_raw, const int* topk_idx, const int64_t* spatial_shapes,
+                                const int64_t* level_start_index, int num_levels, const float* bernstein, float* refs,
+                                int B, long S, int num_queries, int num_points, void* stream);
+int gom_add_f32(const float* a, const float* b, float* out, long n, void* stream);
+int gom_broadcast_rows_f32(const float* src, float* out, long n, int B, void* stream);
+
+/* top-k token indices per batch element (deformable_transformer.py:188-190); idx_out [B,k] int32, sorted by
+ * logit descending.  valid/invalid_logit (optional): tokens with valid[s]==0 take *invalid_logit. */
+long gom_topk_workspace_bytes(int B, long S, int k);
+int gom_topk_tokens(const float* logits, int ld, const unsigned char* valid, const float* invalid_logit, int B, long S,
+                    int k, void* workspace, int* idx_out, void* stream);
+
+/* ---- A11/A12: detection() + NMS + foreground filter ---------------------------------------------------*/
+int gom_argmax_rows_f32(const float* x, int ld, int V, long rows, int* out, void* stream);
+/* Per frame b: count[b] kept instances, in NMS (descending score) order, written to the first count[b] slots of
+ * the nq-padded outputs: keep_idx (row into [B*nq]), scores, boxes [.,4] px, ctrl_out [.,P,2] px,
+ * bd_out [.,P,4] px, recs_out [.,P] int64. */
+int gom_detect_post(const float* cls_logits, int ld_cls, const float* rescoring_logits, int ld_rescoring,
+                    const float* ctrl_points, const float* bd_points, const int* recs, int B, int num_queries,
+                    int num_points, float img_h, float img_w, float det_thresh, float nms_thresh, float asso_thresh,
+                    int* count, int* keep_idx, float* scores, float* boxes, float* ctrl_out, float* bd_out,
+                    long long* recs_out, void* stream);
+
+/* ---- A14/A15: tracker ---------------------------------------------------------------------------------*/
+int gom_gather_rows_f32(const float* src, const int* rows, float* out, int n, int dim, void* stream);
+/* per-frame softmax with an appended zero logit (lstmatcher.py:373-381); frame_offsets [num_frames+1] int32. */
+int gom_asso_activate_f32(const float* logits, int ld, const int* frame_offsets, int num_frames, int n_k, float* out,
+                          int ld_out, void* stream);
+/* traj[n_k, M] (gom_lstmatcher.py:429-445 / 510-547).  meta int32: nonk[Np] | col_of[Np] | last_idx[M] | k_inds[n_k];
+ * boxes [N,4] in pixels of the network input (img_w x img_h). */
+int gom_track_score_f32(const float* act, int ld, const int* meta, const float* decay, const float* boxes, float img_w,
+                        float img_h, int n_k, int Np, int M, int with_iou, float max_center_dist, float* traj,
+                        void* stream);
+/* [host] rectangular assignment, SciPy-compatible tie-breaking (gom_lstmatcher.py:447,549).  Returns the number
+ * of assigned pairs (min(nr,nc)) or a negative error. */
+int gom_linear_sum_assignment(const double* cost, long nr, long nc, long* row_ind, long* col_ind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOMATCHING_HIP_H_ */

@@ -1,0 +1,56 @@
+"""CPU: the library's host LSA against the installed SciPy (which is what the reference calls at
+gom_lstmatcher.py:447,549) on random, tied, rectangular, degenerate and tracker-like matrices."""
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment
+
+from gomatching_amd import ops
+
+
+def _same(cost):
+    r0, c0 = linear_sum_assignment(cost)
+    r1, c1 = ops.linear_sum_assignment(cost)
+    return np.array_equal(r0, r1) and np.array_equal(c0, c1)
+
+
+def test_known_answers():
+    # the 3x3 known-answer cases of py-motmetrics' test_lap.py (vendored in the reference, tools/*/motmetrics/tests)
+    costs = np.array([[6, 9, 1], [10, 3, 2], [8, 7, 4.0]])
+    r, c = ops.linear_sum_assignment(costs)
+    assert r.tolist() == [0, 1, 2] and c.tolist() == [2, 1, 0]
+    costs = np.array([[5, 9, 1e9], [10, 1e9, 2], [8, 7, 4.0]])
+    r, c = ops.linear_sum_assignment(costs)
+    assert costs[r, c].sum() == 5 + 2 + 7
+    r, c = ops.linear_sum_assignment(np.ones((4, 4)))          # constant matrix -> identity (scipy #11602)
+    assert c.tolist() == [0, 1, 2, 3]
+
+
+def test_empty_and_degenerate():
+    for shape in [(0, 0), (0, 5), (5, 0)]:
+        r, c = ops.linear_sum_assignment(np.zeros(shape))
+        assert len(r) == 0 and len(c) == 0
+    assert _same(np.zeros((1, 1)))
+    assert _same(np.zeros((3, 7)))
+    assert _same(np.zeros((7, 3)))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_against_scipy(seed):
+    rng = np.random.default_rng(seed)
+    n_ok = 0
+    for it in range(1500):
+        nr, nc = int(rng.integers(1, 14)), int(rng.integers(1, 14))
+        kind = it % 5
+        if kind == 0:
+            cost = rng.standard_normal((nr, nc))
+        elif kind == 1:
+            cost = rng.integers(0, 3, size=(nr, nc)).astype(np.float64)          # heavy ties
+        elif kind == 2:
+            cost = -np.maximum(rng.random((nr, nc)) - 0.6, 0).astype(np.float32).astype(np.float64)  # many zeros
+        elif kind == 3:
+            cost = -(rng.random((nr, nc)) < 0.2).astype(np.float64)
+        else:                                                                     # tracker-like: near one-hot scores
+            cost = -rng.random((nr, nc)).astype(np.float32).astype(np.float64) * (rng.random((nr, nc)) < 0.3)
+        assert _same(cost), (seed, it, cost)
+        n_ok += 1
+    assert n_ok == 1500

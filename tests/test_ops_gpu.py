@@ -1,0 +1,381 @@
+"""GPU parity of every HIP kernel behind the C ABI against the CPU oracle / a plain fp32 torch-CPU
+statement of the same op, on seeded inputs.  Tolerances are fp32-accumulation-order level."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden, t
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from gomatching_amd import ops
+    return ops
+
+
+def _close(a, b, atol, rtol=0.0, msg=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), "%s max|d|=%.3e (tol %.1e) at %s" % (
+        msg, float(err.max()), atol, np.unravel_index(int(err.argmax()), tuple(err.shape)))
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 1, 256), (25, 38, 256), (300, 384, 256), (513, 129, 1024), (100, 1024, 6400),
+                                   (4097, 256, 256), (7, 8, 256), (130, 64, 64), (1000, 2, 256)])
+def test_gemm_shapes(M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    out = ops.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV))
+    _close(out, F.linear(A, W, b), 2e-5, 1e-5, "gemm %s" % ((M, N, K),))
+
+
+def test_gemm_epilogue_and_gather():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 333, 256, 512
+    A, A2 = torch.randn(M, K, generator=g), torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, sc = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
+    R = torch.randn(M, N, generator=g)
+    out = ops.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), scale=sc.to(DEV), A2=A2.to(DEV), R=R.to(DEV), relu=True)
+    ref = F.relu(F.linear(A + A2, W) * sc + b + R)
+    _close(out, ref, 3e-5, 1e-5, "epilogue")
+    rows = torch.randint(0, M, (77,), generator=g, dtype=torch.int64)
+    out = ops.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), rows=rows.to(torch.int32).to(DEV))
+    _close(out, F.linear(A[rows], W, b), 3e-5, 1e-5, "row gather")
+    # strided views: column slices of a wider buffer for A, row slice of W, strided output
+    big = torch.randn(M, 3 * K, generator=g).to(DEV)
+    Wd = W.to(DEV)
+    outbuf = torch.zeros(M, 2 * N, device=DEV)
+    ops.gemm(big[:, K:2 * K], Wd[64:192], out=outbuf[:, N:N + 128])
+    _close(outbuf[:, N:N + 128], F.linear(big[:, K:2 * K].cpu(), W[64:192]), 3e-5, 1e-5, "strided")
+    assert float(outbuf[:, :N].abs().max()) == 0.0
+
+
+def test_gemm_rejects_bad_args():
+    ops = _ops()
+    from gomatching_amd.lib import GomError
+    A = torch.randn(8, 6, device=DEV)           # K not a multiple of 4
+    W = torch.randn(4, 6, device=DEV)
+    with pytest.raises(GomError):
+        ops.gemm(A, W)
+
+
+# ------------------------------------------------------------------------------------------ conv
+def _conv_ref(x_nchw, w_oihw, stride, pad):
+    return F.conv2d(x_nchw, w_oihw, None, stride=stride, padding=pad)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,H,W", [
+    (64, 64, 1, 1, 0, 13, 17), (256, 512, 1, 2, 0, 14, 18), (64, 64, 3, 1, 1, 13, 17), (128, 128, 3, 2, 1, 15, 19),
+    (4, 64, 7, 2, 3, 37, 45), (512, 256, 3, 2, 1, 6, 9), (16, 32, 3, 1, 1, 9, 9)])
+def test_conv_nhwc(Cin, Cout, k, stride, pad, H, W):
+    ops = _ops()
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref = _conv_ref(x, w, stride, pad) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    R = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref + R)
+    y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV),
+                        scale=sc.to(DEV), shift=sh.to(DEV), R=R.permute(0, 2, 3, 1).contiguous().to(DEV), relu=True,
+                        stride=stride, pad=pad)
+    _close(y.permute(0, 3, 1, 2), ref, 3e-5, 1e-5, "conv")
+
+
+def test_stem_preprocess_pool():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(2, 3, 30, 42, generator=g) * 255
+    mean, std = [123.675, 116.280, 103.530], [58.395, 57.120, 57.375]
+    x = ops.preprocess(img.to(DEV), mean, std)
+    ref = (img - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    _close(x[..., :3].permute(0, 3, 1, 2), ref, 1e-6, 1e-6, "preprocess")
+    assert float(x[..., 3].abs().max()) == 0.0
+    f = torch.randn(2, 64, 15, 21, generator=g)
+    y = ops.maxpool3x3s2(f.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert torch.equal(y.permute(0, 3, 1, 2).cpu(), F.max_pool2d(f, 3, 2, 1))
+
+
+# ------------------------------------------------------------------------------------------ norms
+def test_layernorm_groupnorm():
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    for D in (256, 1024):
+        x, r = torch.randn(777, D, generator=g) * 3 + 1, torch.randn(777, D, generator=g)
+        ga, be = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+        out = ops.layernorm(x.to(DEV), ga.to(DEV), be.to(DEV), residual=r.to(DEV))
+        _close(out, F.layer_norm(x + r, (D,), ga, be, 1e-5), 2e-5, 1e-5, "layernorm %d" % D)
+    B, H, W = 2, 9, 14
+    x = torch.randn(B, 256, H, W, generator=g) * 2 + 0.5
+    ga, be = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    ref = F.group_norm(x, 32, ga, be, 1e-5)
+    S = H * W + 11
+    buf = torch.zeros(B, S, 256, device=DEV)
+    ops.groupnorm32_into(x.permute(0, 2, 3, 1).reshape(B, H * W, 256).contiguous().to(DEV), ga.to(DEV), be.to(DEV),
+                         buf[0, 5:], S * 256)
+    _close(buf[:, 5:5 + H * W].reshape(B, H, W, 256).permute(0, 3, 1, 2), ref, 2e-5, 1e-5, "groupnorm")
+    assert float(buf[:, :5].abs().max()) == 0.0 and float(buf[:, 5 + H * W:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------ MSDA
+@pytest.mark.parametrize("case", ["enc", "dec", "oob"])
+def test_msda_golden(case):
+    """The reference's own output for the native op (fixture made by oracle/gen_golden.py)."""
+    ops = _ops()
+    g = golden("msda.npz")
+    out = ops.ms_deform_attn_forward(t(g[case + "_value"]).to(DEV), t(g[case + "_shapes"]).to(DEV),
+                                     t(g[case + "_lsi"]).to(DEV), t(g[case + "_loc"]).to(DEV),
+                                     t(g[case + "_w"]).to(DEV), 64)
+    _close(out, t(g[case + "_out"]), 2e-5, 0, "msda " + case)
+
+
+def test_msda_larger_vs_oracle_and_prepare():
+    from oracle import gom_oracle as O
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    shapes = [(23, 31), (12, 16), (6, 8), (3, 4)]
+    S = sum(h * w for h, w in shapes)
+    B, Lq = 2, 301
+    ss = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(B, S, 8, 32, generator=g)
+    raw = torch.randn(B * Lq, 384, generator=g)
+    raw[:, :256] *= 3.0
+    ref = torch.rand(B * Lq, 1, 2, generator=g) * 1.2 - 0.1
+    loc, w = ops.msda_prepare(raw.to(DEV), ref.to(DEV), ss.to(DEV))
+    off = raw[:, :256].view(B * Lq, 8, 4, 4, 2)
+    norm = torch.stack([ss[:, 1], ss[:, 0]], -1)
+    loc_ref = ref[:, None, :, None, :] + off / norm[None, None, :, None, :]
+    w_ref = torch.softmax(raw[:, 256:].view(B * Lq, 8, 16), -1).view(B * Lq, 8, 4, 4)
+    _close(loc, loc_ref, 1e-6, 1e-6, "prepare loc")
+    _close(w, w_ref, 1e-6, 1e-5, "prepare w")
+    out = ops.ms_deform_attn_forward(value.to(DEV), ss.to(DEV), lsi.to(DEV), loc.view(B, Lq, 8, 4, 4, 2),
+                                     w.view(B, Lq, 8, 4, 4))
+    exp = O.ms_deform_attn_forward(value, ss, lsi, loc_ref.view(B, Lq, 8, 4, 4, 2), w_ref.view(B, Lq, 8, 4, 4))
+    _close(out, exp, 3e-5, 0, "msda vs oracle")
+
+
+# ------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("hd,Lq,Lk,outer,inner", [(32, 25, 25, 6, 1), (32, 12, 12, 2, 25), (32, 100, 100, 1, 3),
+                                                  (128, 37, 90, 1, 1), (128, 5, 700, 1, 1), (32, 300, 300, 1, 2)])
+def test_mha_core(hd, Lq, Lk, outer, inner):
+    ops = _ops()
+    g = torch.Generator().manual_seed(hd + Lq + Lk)
+    heads = 8
+    E = heads * hd
+    nb = outer * inner
+    q = torch.randn(nb, Lq, E, generator=g)
+    k = torch.randn(nb, Lk, E, generator=g)
+    v = torch.randn(nb, Lk, E, generator=g)
+    qh = q.view(nb, Lq, heads, hd).transpose(1, 2) * (1.0 / math.sqrt(hd))
+    kh = k.view(nb, Lk, heads, hd).transpose(1, 2)
+    vh = v.view(nb, Lk, heads, hd).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).transpose(1, 2).reshape(nb, Lq, E)
+    out = torch.empty(nb, Lq, E, device=DEV)
+    st = [inner * Lq * E, Lq * E, E, inner * Lk * E, Lk * E, E, inner * Lk * E, Lk * E, E, inner * Lq * E, Lq * E, E]
+    ops.mha_core(q.to(DEV), k.to(DEV), v.to(DEV), out, outer, inner, heads, hd, Lq, Lk, st)
+    _close(out, ref, 2e-5, 1e-5, "mha_core")
+
+
+def test_mha_core_swapped_view():
+    """The decoder's inter-instance attention: sequences over nq, batched over (b, point) without a transpose."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    B, nq, P, E, heads, hd = 2, 12, 25, 256, 8, 32
+    qkv = torch.randn(B, nq, P, 3 * E, generator=g)
+    x = qkv.permute(0, 2, 1, 3).reshape(B * P, nq, 3 * E)
+    qh = x[..., :E].reshape(B * P, nq, heads, hd).transpose(1, 2) / math.sqrt(hd)
+    kh = x[..., E:2 * E].reshape(B * P, nq, heads, hd).transpose(1, 2)
+    vh = x[..., 2 * E:].reshape(B * P, nq, heads, hd).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).transpose(1, 2).reshape(B, P, nq, E).permute(0, 2, 1, 3)
+    d = qkv.to(DEV)
+    out = torch.empty(B, nq, P, E, device=DEV)
+    ld = 3 * E
+    st = [nq * P * ld, ld, P * ld] * 3 + [nq * P * E, E, P * E]
+    flat = d.view(-1)
+    ops.mha_core(flat, flat[E:], flat[2 * E:], out, B, P, heads, hd, nq, nq, st)
+    _close(out, ref, 2e-5, 1e-5, "inter view")
+
+
+# ------------------------------------------------------------------------------------------ glue
+def test_positional_tables():
+    from oracle import gom_oracle as O
+    ops = _ops()
+    dim_t = torch.arange(128, dtype=torch.float32)
+    dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / 128)
+    H, W = 11, 17
+    lvl = torch.randn(256)
+    out = torch.empty(H * W, 256, device=DEV)
+    ops.pos_encoding_into(dim_t.to(DEV), lvl.to(DEV), out, H, W)
+    ref = O.pos_encoding_2d(torch.zeros(1, H, W, dtype=torch.bool))[0].flatten(1).t() + lvl
+    _close(out, ref, 2e-6, 0, "pos2d")
+    pts = torch.rand(333, 2)
+    pe = ops.point_pos_embed(pts.to(DEV), dim_t.to(DEV))
+    _close(pe, O.gen_point_pos_embed(pts, 256, 10000), 3e-6, 0, "point pos")
+    delta = torch.randn(333, 4)
+    ref2 = (delta[:, :2] + O.inverse_sigmoid(pts)).sigmoid()
+    _close(ops.ref_sigmoid(delta.to(DEV), pts.to(DEV), 2), ref2, 1e-6, 0, "ref sigmoid 2")
+    ref4 = (delta + O.inverse_sigmoid(pts).repeat(1, 2)).sigmoid()
+    _close(ops.ref_sigmoid(delta.to(DEV), pts.to(DEV), 4), ref4, 1e-6, 0, "ref sigmoid 4")
+    edge = torch.tensor([[0.0, 1.0], [1e-7, 1 - 1e-7], [0.5, 0.25]])
+    _close(ops.ref_sigmoid(torch.zeros(3, 2, device=DEV), edge.to(DEV), 2), O.inverse_sigmoid(edge).sigmoid(), 1e-6, 0)
+
+
+def test_topk_and_bezier():
+    from oracle import gom_oracle as O
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    shapes = [(60, 90), (30, 45), (15, 23), (8, 12)]
+    ss = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    S = int(ss.prod(1).sum())
+    B, k = 3, 100
+    logits = torch.randn(B * S, 1, generator=g)
+    valid = ops.proposal_valid(ss.to(DEV), lsi.to(DEV), S)
+    # oracle validity mask
+    props = []
+    for (H, W) in shapes:
+        gy, gx = torch.meshgrid(torch.linspace(0, H - 1, H), torch.linspace(0, W - 1, W), indexing="ij")
+        props.append(torch.stack([(gx + 0.5) / W, (gy + 0.5) / H], -1).view(-1, 2))
+    props = torch.cat(props, 0)
+    vref = ((props > 0.01) & (props < 0.99)).all(-1)
+    assert torch.equal(valid.cpu().bool(), vref)
+    c0 = torch.tensor([0.37])
+    idx = ops.topk_tokens(logits.to(DEV), B, S, k, valid=valid, invalid_logit=c0.to(DEV))
+    masked = torch.where(vref[None], logits.view(B, S), c0)
+    ref_idx = torch.topk(masked, k, dim=1)[1]
+    got = idx.cpu().long()
+    assert torch.equal(torch.gather(masked, 1, got), torch.gather(masked, 1, ref_idx))
+    # without ties among the winners the index sets are identical
+    for b in range(B):
+        vals = torch.gather(masked, 1, ref_idx)[b]
+        if len(torch.unique(vals)) == k:
+            assert torch.equal(got[b], ref_idx[b])
+    # small S (single chunk) and k == S
+    l2 = torch.randn(2 * 37, 3, generator=g)
+    i2 = ops.topk_tokens(l2.to(DEV), 2, 37, 37)
+    assert torch.equal(i2.cpu().long(), torch.topk(l2[:, 0].view(2, 37), 37, dim=1)[1])
+    # bezier reference points
+    coord_raw = torch.randn(B, S, 8, generator=g)
+    bern = O.bernstein_matrix(25)
+    refs = ops.bezier_reference_points(coord_raw.to(DEV), idx, ss.to(DEV), lsi.to(DEV), bern.to(DEV), B, S, k, 25)
+    lp = torch.log(props / (1 - props)).masked_fill(~vref[:, None], float("inf")).repeat(1, 4)
+    unact = coord_raw + lp[None]
+    sel = torch.gather(unact, 1, got.unsqueeze(-1).repeat(1, 1, 8)).sigmoid()
+    exp = torch.matmul(bern, sel.view(B, k, 4, 2))
+    _close(refs, exp, 2e-6, 0, "bezier refs")
+    enc_ref = ops.encoder_reference_points(ss.to(DEV), lsi.to(DEV), S)
+    _close(enc_ref, O.encoder_reference_points(shapes, torch.ones(1, 4, 2))[0, :, 0], 1e-7, 0, "enc ref")
+
+
+# ------------------------------------------------------------------------------------------ detection
+@pytest.mark.parametrize("with_re,nms_thr", [(True, 0.5), (False, 0.3)])
+def test_detect_post_vs_oracle(with_re, nms_thr):
+    from oracle import gom_oracle as O
+    from helpers import mini_cfg
+    ops = _ops()
+    g = torch.Generator().manual_seed(41 + int(with_re))
+    B, nq, P, V = 3, 60, 25, 38
+    cfg = mini_cfg("icdar15", nq=nq)
+    cfg.VIDEO_TEST.NMS_THRESH = nms_thr
+    cfg.MODEL.ROI_HEADS.WITH_RESR = with_re
+    thr = cfg.MODEL.TRANSFORMER.INFERENCE_TH_TEST
+    centers = torch.rand(B, nq, 1, 2, generator=g) * 0.8 + 0.1
+    centers[:, ::3] = centers[:, 1::3][:, :centers[:, ::3].shape[1]]          # force overlapping boxes
+    ctrl = (centers + (torch.rand(B, nq, P, 2, generator=g) - 0.5) * 0.1).clamp(0, 1)
+    bd = torch.cat([ctrl - 0.02, ctrl + 0.02], -1).clamp(0, 1) + torch.rand(B, nq, P, 4, generator=g) * 0.01
+    out = {
+        "pred_logits": torch.randn(B, nq, P, 1, generator=g) * 2 - 0.5,
+        "pred_text_logits": torch.randn(B, nq, P, V, generator=g),
+        "pred_ctrl_points": ctrl, "pred_bd_points": bd,
+        "query_features": torch.randn(B, nq, P, 256, generator=g),
+    }
+    out["pred_logits"][0] = -20.0                                  # an empty frame
+    re = torch.randn(B, nq, P, 1, generator=g) * 2 - 1.0 if with_re else None
+    if re is not None:
+        re[0] = -20.0
+    hw = (96, 128)
+    det = O.detection(cfg, out, re, [hw] * B)
+    props = O.proposals_with_nms(cfg, det)
+    recs = ops.argmax_rows(out["pred_text_logits"].reshape(-1, V).to(DEV))
+    assert torch.equal(recs.cpu().long(), out["pred_text_logits"].reshape(-1, V).argmax(-1))
+    r = ops.detect_post(out["pred_logits"].reshape(-1, 1).to(DEV),
+                        re.reshape(-1, 1).to(DEV) if re is not None else None,
+                        ctrl.to(DEV), bd.to(DEV), recs, B, nq, P, hw[0], hw[1], thr, nms_thr, thr)
+    cnt = r["count"].cpu().tolist()
+    assert cnt[0] == 0
+    for b in range(B):
+        p = props[b].select(props[b]["objectness_logits"] > thr)
+        n = len(p)
+        assert cnt[b] == n, (b, cnt[b], n)
+        if n == 0:
+            continue
+        _close(r["scores"][b, :n], p["scores"], 1e-6, 0, "scores")
+        _close(r["boxes"][b, :n], p["proposal_boxes"], 1e-4, 0, "boxes")
+        _close(r["ctrl"][b, :n], p["ctrl_points"], 1e-4, 0, "ctrl")
+        _close(r["bd"][b, :n], p["bd"], 1e-4, 0, "bd")
+        assert torch.equal(r["recs"][b, :n].cpu(), p["recs"])
+        # keep_idx points at the right query rows
+        qf = out["query_features"].reshape(B * nq, P, 256)[r["keep_idx"][b, :n].cpu().long()]
+        assert torch.equal(qf, p["query_features"])
+
+
+# ------------------------------------------------------------------------------------------ tracker pieces
+def test_asso_activate_and_track_score():
+    ops = _ops()
+    g = torch.Generator().manual_seed(51)
+    n_t = [4, 0, 7, 5]
+    N, n_k = sum(n_t), 5
+    logits = torch.randn(n_k, N, generator=g) * 3
+    offs = torch.tensor([0, 4, 4, 11, 16], dtype=torch.int32)
+    act = ops.asso_activate(logits.to(DEV), offs.to(DEV), 4)
+    ref = torch.cat([torch.cat([a, a.new_zeros((n_k, 1))], 1).softmax(1)[:, :-1] for a in logits.split(n_t, 1)], 1)
+    _close(act, ref, 1e-6, 1e-5, "activate")
+    # track score: frames 0..2 are history (k = 3)
+    boxes = torch.rand(N, 2, generator=g) * 80
+    boxes = torch.cat([boxes, boxes + torch.rand(N, 2, generator=g) * 30 + 5], 1)
+    ids = torch.tensor([3, 5, 9, 2, 5, 3, 9, 11, 2, 7, 14])
+    nonk = list(range(0, 11))
+    k_inds = list(range(11, 16))
+    uniq = torch.unique(ids)
+    M, Np = len(uniq), len(ids)
+    col_of = torch.searchsorted(uniq, ids)
+    id_inds = (uniq[None, :] == ids[:, None]).float()
+    last = (id_inds * torch.arange(Np)[:, None]).max(dim=0)[1]
+    dts = torch.tensor([2.0] * 4 + [0.0] * 7)
+    decay = 0.9 ** dts
+    meta = torch.tensor(nonk + col_of.tolist() + last.tolist() + k_inds, dtype=torch.int32)
+    img_w, img_h = 128.0, 96.0
+    traj = ops.track_score(act, meta.to(DEV), decay.to(DEV), boxes.to(DEV), img_w, img_h, n_k, Np, M, True, 1.0)
+    from oracle import gom_oracle as O
+    nb = boxes.clone()
+    nb[:, [0, 2]] /= img_w
+    nb[:, [1, 3]] /= img_h
+    kb, ob = nb[k_inds], nb[nonk]
+    tr = torch.mm(ref[:, nonk] * decay[None], id_inds)
+    tr = torch.max(tr, O.pairwise_iou(kb, ob[last]))
+    k_ct = (kb[:, :2] + kb[:, 2:]) / 2
+    k_s = ((kb[:, 2:] - kb[:, :2]) ** 2).sum(1)
+    n_ct = (ob[:, :2] + ob[:, 2:]) / 2
+    dist = ((k_ct[:, None] - n_ct[None]) ** 2).sum(2) / (k_s[:, None] + 1e-8)
+    va = torch.mm((dist < 1.0).float(), id_inds).clamp_(max=1.0).bool()
+    tr[~va] = 0
+    _close(traj, tr, 2e-6, 1e-5, "track score")
+    rows = torch.tensor([5, 0, 3, 3], dtype=torch.int32)
+    src = torch.randn(9, 1024, generator=g)
+    assert torch.equal(ops.gather_rows(src.to(DEV), rows.to(DEV)).cpu(), src[rows.long()])
