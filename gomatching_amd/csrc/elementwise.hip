@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void bezier_refs_kernel(const float* __restric
                                                           const int64_t* __restrict__ shapes,
                                                           const int64_t* __restrict__ lsi, int L,
                                                           const float* __restrict__ bern, float* __restrict__ refs,
-                                                          int B, long S, int nq, int P) {
+                                                          int B, long S, int nq, int P, int compact) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*nq*P
     if (i >= (long)B * nq * P) return;
     const int p = (int)(i % P);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void bezier_refs_kernel(const float* __restric
     const bool ok = gx > 0.01f && gx < 0.99f && gy > 0.01f && gy < 0.99f;
     const float px = ok ? logf(gx / (1.f - gx)) : INFINITY;
     const float py = ok ? logf(gy / (1.f - gy)) : INFINITY;
-    const float* cr = coord_raw + ((size_t)b * S + s) * 8;
+    const float* cr = coord_raw + (compact ? (size_t)bq : ((size_t)b * S + s)) * 8;
     float ox = 0.f, oy = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -178,6 +178,14 @@ __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
     *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(src + (i % n4) * 4);
+}
+
+// detector_postprocess (gom_lstmatcher.py:100-109): x[2i] *= sx, x[2i+1] *= sy in place
+__global__ __launch_bounds__(256) void scale_xy_kernel(float* __restrict__ x, long n_pairs, float sx, float sy) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pairs) return;
+    x[2 * i] *= sx;
+    x[2 * i + 1] *= sy;
 }
 
 }  // namespace
@@ -236,11 +244,12 @@ extern "C" int gom_proposal_valid(const int64_t* spatial_shapes, const int64_t* 
 extern "C" int gom_bezier_reference_points(const float* coord_raw, const int* topk_idx, const int64_t* spatial_shapes,
                                            const int64_t* level_start_index, int num_levels, const float* bernstein,
                                            float* refs, int B, long S, int num_queries, int num_points,
-                                           void* stream) {
+                                           int compact, void* stream) {
     GOM_CHECK_ARG(coord_raw && topk_idx && spatial_shapes && level_start_index && bernstein && refs);
     GOM_CHECK_ARG(B > 0 && S > 0 && num_queries > 0 && num_points > 0);
     hipLaunchKernelGGL(bezier_refs_kernel, GOM_GRID((long)B * num_queries * num_points), coord_raw, topk_idx,
-                       spatial_shapes, level_start_index, num_levels, bernstein, refs, B, S, num_queries, num_points);
+                       spatial_shapes, level_start_index, num_levels, bernstein, refs, B, S, num_queries, num_points,
+                       compact);
     return gom_launch_status();
 }
 
@@ -261,5 +270,12 @@ extern "C" int gom_add_f32(const float* a, const float* b, float* out, long n, v
 extern "C" int gom_broadcast_rows_f32(const float* src, float* out, long n, int B, void* stream) {
     GOM_CHECK_ARG(src && out && n > 0 && (n % 4) == 0 && B > 0);
     hipLaunchKernelGGL(bcast_rows_kernel, GOM_GRID(n / 4 * B), src, out, n / 4, n / 4 * B);
+    return gom_launch_status();
+}
+
+extern "C" int gom_scale_xy_f32(float* x, long n_pairs, float sx, float sy, void* stream) {
+    GOM_CHECK_ARG(n_pairs >= 0 && (x || n_pairs == 0));
+    if (n_pairs == 0) return GOM_OK;
+    hipLaunchKernelGGL(scale_xy_kernel, GOM_GRID(n_pairs), x, n_pairs, sx, sy);
     return gom_launch_status();
 }

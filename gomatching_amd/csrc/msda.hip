@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float* __restrict__
                                                        const int64_t* __restrict__ lsi,
                                                        const float* __restrict__ loc,
                                                        const float* __restrict__ attw, float* __restrict__ out,
-                                                       int B, int S, int Lq) {
+                                                       int B, int Lq, long v_bs, int v_rs) {
     const long q_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per (b, q)
     if (q_global >= (long)B * Lq) return;
     const int lane = threadIdx.x & 63;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float* __restrict__
     const int c4 = (lane & 7) * 4;      // first of this lane's 4 channels
     const int b = (int)(q_global / Lq);
 
-    const float* vb = value + (size_t)b * S * (HEADS * CH) + m * CH + c4;
+    const float* vb = value + (size_t)b * v_bs + m * CH + c4;
     const float* lp = loc + ((size_t)q_global * HEADS + m) * (LEVELS * POINTS * 2);
     const float* wp = attw + ((size_t)q_global * HEADS + m) * (LEVELS * POINTS);
 
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int l = 0; l < LEVELS; ++l) {
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-        const float* vl = vb + (size_t)lsi[l] * (HEADS * CH);
+        const float* vl = vb + (size_t)lsi[l] * v_rs;
 #pragma unroll
         for (int p = 0; p < POINTS; ++p) {
             const float lx = lp[(l * POINTS + p) * 2], ly = lp[(l * POINTS + p) * 2 + 1];
@@ -51,12 +51,12 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float* __restrict__
                 const float hh = 1.f - lh, hw = 1.f - lw;
                 const bool y0 = h_low >= 0, y1 = h_low + 1 <= H - 1;
                 const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
-                const float* base = vl + ((size_t)h_low * W + w_low) * (HEADS * CH);
+                const float* base = vl + ((long)h_low * W + w_low) * (long)v_rs;
                 f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
                 if (y0 && x0) v1 = *reinterpret_cast<const f32x4*>(base);
-                if (y0 && x1) v2 = *reinterpret_cast<const f32x4*>(base + HEADS * CH);
-                if (y1 && x0) v3 = *reinterpret_cast<const f32x4*>(base + (size_t)W * (HEADS * CH));
-                if (y1 && x1) v4 = *reinterpret_cast<const f32x4*>(base + (size_t)(W + 1) * (HEADS * CH));
+                if (y0 && x1) v2 = *reinterpret_cast<const f32x4*>(base + v_rs);
+                if (y1 && x0) v3 = *reinterpret_cast<const f32x4*>(base + (long)W * v_rs);
+                if (y1 && x1) v4 = *reinterpret_cast<const f32x4*>(base + (long)(W + 1) * v_rs);
                 const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
                 const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
                 acc += val * w;
@@ -118,8 +118,24 @@ extern "C" int gom_ms_deform_attn_forward(const float* value, const int64_t* spa
     GOM_CHECK_ARG(batch > 0 && spatial_size > 0 && num_query > 0);
     const long nq = (long)batch * num_query;
     hipLaunchKernelGGL((msda_fwd_kernel<4>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
-                       spatial_shapes, level_start_index, sampling_loc, attn_weight, output, batch, spatial_size,
-                       num_query);
+                       spatial_shapes, level_start_index, sampling_loc, attn_weight, output, batch, num_query,
+                       (long)spatial_size * (HEADS * CH), HEADS * CH);
+    return gom_launch_status();
+}
+
+// Same op reading the value map in place from a wider row-major buffer (e.g. one 256-column slice of
+// the fused [B*S, 6*256] decoder value projection): row stride / batch stride in floats.
+extern "C" int gom_ms_deform_attn_forward_strided(const float* value, long value_batch_stride, int value_row_stride,
+                                                  const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                                  const float* sampling_loc, const float* attn_weight, float* output,
+                                                  int batch, int num_query, void* stream) {
+    GOM_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && output);
+    GOM_CHECK_ARG(batch > 0 && num_query > 0 && value_row_stride >= HEADS * CH && (value_row_stride % 4) == 0 &&
+                  (value_batch_stride % 4) == 0);
+    const long nq = (long)batch * num_query;
+    hipLaunchKernelGGL((msda_fwd_kernel<4>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
+                       spatial_shapes, level_start_index, sampling_loc, attn_weight, output, batch, num_query,
+                       value_batch_stride, value_row_stride);
     return gom_launch_status();
 }
 

@@ -59,13 +59,17 @@ __global__ __launch_bounds__(1024) void topk_chunk_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long long* __restrict__ cand, int ncand, int k,
-                                                          int* __restrict__ idx_out) {
+                                                          long S, int* __restrict__ idx_out,
+                                                          int* __restrict__ rows_out) {
     extern __shared__ unsigned long long mkeys[];
     const int b = blockIdx.x;
     for (int t = threadIdx.x; t < MERGE_MAX; t += blockDim.x) mkeys[t] = t < ncand ? cand[(size_t)b * ncand + t] : 0ull;
     bitonic_sort_desc<MERGE_MAX>(mkeys);
-    for (int t = threadIdx.x; t < k; t += blockDim.x)
-        idx_out[(size_t)b * k + t] = (int)(0xFFFFFFFFu - (unsigned)(mkeys[t] & 0xFFFFFFFFull));
+    for (int t = threadIdx.x; t < k; t += blockDim.x) {
+        const int s = (int)(0xFFFFFFFFu - (unsigned)(mkeys[t] & 0xFFFFFFFFull));
+        idx_out[(size_t)b * k + t] = s;
+        if (rows_out) rows_out[(size_t)b * k + t] = (int)(b * S + s);   // row into the [B*S, .] token buffers
+    }
 }
 
 }  // namespace
@@ -75,10 +79,10 @@ extern "C" long gom_topk_workspace_bytes(int B, long S, int k) {
 }
 
 extern "C" int gom_topk_tokens(const float* logits, int ld, const unsigned char* valid, const float* invalid_logit,
-                               int B, long S, int k, void* workspace, int* idx_out, void* stream) {
+                               int B, long S, int k, void* workspace, int* idx_out, int* rows_out, void* stream) {
     GOM_CHECK_ARG(logits && workspace && idx_out && B > 0 && S > 0 && k > 0 && ld >= 1);
     const int chunks = cdiv(S, CHUNK);
-    GOM_CHECK_ARG(k <= CHUNK && k <= S && (long)chunks * k <= MERGE_MAX);
+    GOM_CHECK_ARG(k <= CHUNK && k <= S && (long)chunks * k <= MERGE_MAX && (long)B * S < (1L << 31));
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* cand = (unsigned long long*)workspace;
     hipLaunchKernelGGL(topk_chunk_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(1024), 0, s, logits, ld, valid,
@@ -91,6 +95,6 @@ extern "C" int gom_topk_tokens(const float* logits, int ld, const unsigned char*
         if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(1024), lds, s, cand, chunks * k, k, idx_out);
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(1024), lds, s, cand, chunks * k, k, S, idx_out, rows_out);
     return gom_launch_status();
 }

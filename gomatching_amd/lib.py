@@ -23,6 +23,7 @@ SIGNATURES = {
     "gom_abi_version": (I, []),
     "gom_built_for_arch": (ctypes.c_char_p, []),
     "gom_ms_deform_attn_forward": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "gom_ms_deform_attn_forward_strided": (I, [P, L, I, P, P, P, P, P, I, I, P]),
     "gom_msda_prepare": (I, [P, I, P, I, P, P, P, L, P]),
     "gom_gemm_f32": (I, [P, P, P, I, P, I, P, P, P, I, I, P, I, I, I, I, P]),
     "gom_conv2d_nhwc_f32": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P]),
@@ -36,11 +37,12 @@ SIGNATURES = {
     "gom_ref_sigmoid_f32": (I, [P, I, P, P, L, I, P]),
     "gom_proposal_valid": (I, [P, P, I, P, L, P]),
     "gom_encoder_reference_points": (I, [P, P, I, P, L, P]),
-    "gom_bezier_reference_points": (I, [P, P, P, P, I, P, P, I, L, I, I, P]),
+    "gom_bezier_reference_points": (I, [P, P, P, P, I, P, P, I, L, I, I, I, P]),
+    "gom_scale_xy_f32": (I, [P, L, F, F, P]),
     "gom_add_f32": (I, [P, P, P, L, P]),
     "gom_broadcast_rows_f32": (I, [P, P, L, I, P]),
     "gom_topk_workspace_bytes": (L, [I, L, I]),
-    "gom_topk_tokens": (I, [P, I, P, P, I, L, I, P, P, P]),
+    "gom_topk_tokens": (I, [P, I, P, P, I, L, I, P, P, P, P]),
     "gom_argmax_rows_f32": (I, [P, I, I, L, P, P]),
     "gom_detect_post": (I, [P, I, P, I, P, P, P, I, I, I, F, F, F, F, F, P, P, P, P, P, P, P, P]),
     "gom_gather_rows_f32": (I, [P, P, P, I, I, P]),

@@ -1,0 +1,72 @@
+"""ResNet-50 / FrozenBN backbone driver: every convolution is one launch of the
+implicit-GEMM MFMA kernel with FrozenBatchNorm, ReLU and the bottleneck shortcut fused into its epilogue.
+
+Follows Detectron2 v0.6 `build_resnet_backbone` for DEPTH 50, STRIDE_IN_1X1 False, FrozenBN (the backbone
+the reference builds at gom_lstmatcher.py:46 from configs/*.yaml:6-11): stem conv7x7/2 + BN + ReLU +
+maxpool3x3/2, bottlenecks [3,4,6,3] with the stride on the 3x3, 1x1 projection shortcuts, outputs
+res3/res4/res5.  Activations are channels-last so a 1x1 convolution is a plain GEMM over pixels.
+"""
+import torch
+
+from .. import ops
+
+_STAGES = (("res2", 3, 1), ("res3", 4, 2), ("res4", 6, 2), ("res5", 3, 2))
+
+
+def _fold_bn(sd, name, device, eps=1e-5):
+    # same arithmetic as FrozenBatchNorm2d.forward: scale = w * rsqrt(var + eps); shift = b - mean * scale
+    scale = sd[name + ".norm.weight"] * (sd[name + ".norm.running_var"] + eps).rsqrt()
+    shift = sd[name + ".norm.bias"] - sd[name + ".norm.running_mean"] * scale
+    return scale.float().contiguous().to(device), shift.float().contiguous().to(device)
+
+
+def _ohwi(w, device, pad_cin_to=None):
+    w = w.float().permute(0, 2, 3, 1)
+    if pad_cin_to is not None and w.shape[-1] < pad_cin_to:
+        w = torch.cat([w, w.new_zeros(w.shape[:-1] + (pad_cin_to - w.shape[-1],))], -1)
+    return w.contiguous().to(device)
+
+
+class ResNet50:
+    out_features = ("res3", "res4", "res5")
+    strides = {"res3": 8, "res4": 16, "res5": 32}
+    channels = {"res3": 512, "res4": 1024, "res5": 2048}
+
+    def __init__(self, sd, device, prefix="backbone.0.backbone."):
+        self.device = device
+        self.convs = {}
+
+        def add(name, pad_cin_to=None):
+            w = _ohwi(sd[prefix + name + ".weight"], device, pad_cin_to)
+            sc, sh = _fold_bn(sd, prefix + name, device)
+            self.convs[name] = (w, sc, sh)
+
+        add("stem.conv1", pad_cin_to=4)
+        self.blocks = []
+        for stage, nblk, first_stride in _STAGES:
+            for i in range(nblk):
+                p = "%s.%d." % (stage, i)
+                has_sc = (prefix + p + "shortcut.weight") in sd
+                if has_sc:
+                    add(p + "shortcut")
+                for c in ("conv1", "conv2", "conv3"):
+                    add(p + c)
+                self.blocks.append((stage, p, first_stride if i == 0 else 1, has_sc, i == nblk - 1))
+
+    def _conv(self, x, name, stride=1, pad=0, relu=False, R=None):
+        w, sc, sh = self.convs[name]
+        return ops.conv2d_nhwc(x, w, scale=sc, shift=sh, R=R, relu=relu, stride=stride, pad=pad)
+
+    def forward(self, x_nhwc4):
+        """x: [B,H,W,4] normalised RGB + zero channel.  Returns {'res3','res4','res5'} NHWC."""
+        x = self._conv(x_nhwc4, "stem.conv1", stride=2, pad=3, relu=True)
+        x = ops.maxpool3x3s2(x)
+        outs = {}
+        for stage, p, s, has_sc, last in self.blocks:
+            sc = self._conv(x, p + "shortcut", stride=s) if has_sc else x
+            y = self._conv(x, p + "conv1", relu=True)
+            y = self._conv(y, p + "conv2", stride=s, pad=1, relu=True)
+            x = self._conv(y, p + "conv3", relu=True, R=sc)           # relu(conv3 + shortcut)
+            if last:
+                outs[stage] = x
+        return {k: outs[k] for k in self.out_features}

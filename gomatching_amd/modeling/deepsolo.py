@@ -1,0 +1,286 @@
+"""DeepSolo-without-backbone on MI355X, batched over the frames of a step.
+
+Host-side mirror of `DETECTION_TRANSFORMER_WOBACKBONE.forward`
+(/root/reference/third_party/adet/modeling/model/detection_transformer_wobackbone.py:159-270) and
+`DeformableTransformer.forward` (third_party/adet/layers/deformable_transformer.py:150-215), driving the
+HIP kernels through `gomatching_amd.ops`.  Results are identical in meaning; the schedule is not the
+reference's:
+  * tokens are channels-last from the backbone on, so flatten/transpose/cat are free: GroupNorm writes
+    each level straight into the flattened [B,S,256] buffer;
+  * sampling_offsets and attention_weights share one GEMM (N = 384) fed by (src + pos) added in the
+    operand loader; residual adds ride in GEMM epilogues, LayerNorm fuses the add it needs;
+  * the six decoder cross-attention value projections (same memory, six weights,
+    ms_deform_attn.py:133) are ONE GEMM with N = 1536 right after the encoder;
+  * the Bezier-coordinate MLP runs on the nq selected tokens only (the reference runs it on all S
+    tokens and gathers afterwards, deformable_transformer.py:185-196) -- same values, ~S/nq fewer FLOPs;
+  * instead of zero-filling invalid-proposal rows before enc_output (:136-137), their class logit
+    (a constant: the head applied to a zero row) is substituted inside the top-k kernel;
+  * position tables (sine encodings + level embed, encoder reference grid, proposal validity) are
+    computed on the GPU once per input resolution and cached.
+Padding masks: the reference feeds one unpadded image per call (gom_lstmatcher.py:369-371), so masks are
+all-False and valid ratios are 1; that is the only case built (frames of one step share a size).
+"""
+import math
+
+import torch
+
+from .. import ops
+
+_f32 = torch.float32
+
+
+def _dev(t, device):
+    return t.detach().float().contiguous().to(device)
+
+
+class DeepSolo:
+    def __init__(self, cfg, sd, device, prefix="detection_transformer."):
+        T = cfg.MODEL.TRANSFORMER
+        self.cfg, self.device = cfg, device
+        self.d, self.nq, self.P = T.HIDDEN_DIM, T.NUM_QUERIES, T.NUM_POINTS
+        self.heads, self.L = T.NHEADS, T.NUM_FEATURE_LEVELS
+        self.n_enc, self.n_dec = T.ENC_LAYERS, T.DEC_LAYERS
+        self.voc = T.VOC_SIZE
+        assert self.d == 256 and self.heads == 8 and self.L == 4 and T.ENC_N_POINTS == 4 and T.DEC_N_POINTS == 4, \
+            "kernels are specialised for d_model 256 / 8 heads / 4 levels / 4 points (every shipped config)"
+        assert T.BOUNDARY_HEAD
+        g = lambda k: _dev(sd[prefix + k], device)
+        self.proj = []
+        for l in range(3):
+            self.proj.append((g("input_proj.%d.0.weight" % l).reshape(self.d, -1).contiguous(),
+                              g("input_proj.%d.0.bias" % l), g("input_proj.%d.1.weight" % l),
+                              g("input_proj.%d.1.bias" % l)))
+        self.proj3 = (_dev(sd[prefix + "input_proj.3.0.weight"].permute(0, 2, 3, 1), device),
+                      g("input_proj.3.0.bias"), g("input_proj.3.1.weight"), g("input_proj.3.1.bias"))
+        self.point_embed = g("point_embed.weight")                           # [nq*P, 256]
+        t = "transformer."
+        self.level_embed = g(t + "level_embed")
+        self.enc_output = (g(t + "enc_output.weight"), g(t + "enc_output.bias"))
+        self.enc_output_norm = (g(t + "enc_output_norm.weight"), g(t + "enc_output_norm.bias"))
+
+        def lin(name):
+            return g(name + ".weight"), g(name + ".bias")
+
+        def msda(name):
+            w = torch.cat([sd[prefix + name + ".sampling_offsets.weight"],
+                           sd[prefix + name + ".attention_weights.weight"]], 0)
+            b = torch.cat([sd[prefix + name + ".sampling_offsets.bias"],
+                           sd[prefix + name + ".attention_weights.bias"]], 0)
+            return {"raw": (_dev(w, device), _dev(b, device)), "value": lin(name + ".value_proj"),
+                    "out": lin(name + ".output_proj")}
+
+        self.enc = []
+        for i in range(self.n_enc):
+            p = t + "encoder.layers.%d." % i
+            self.enc.append({"attn": msda(p + "self_attn"), "norm1": lin(p + "norm1"), "lin1": lin(p + "linear1"),
+                             "lin2": lin(p + "linear2"), "norm2": lin(p + "norm2")})
+        self.dec = []
+        for i in range(self.n_dec):
+            p = t + "decoder.layers.%d." % i
+            self.dec.append({
+                "intra_in": (g(p + "attn_intra.in_proj_weight"), g(p + "attn_intra.in_proj_bias")),
+                "intra_out": lin(p + "attn_intra.out_proj"), "norm_intra": lin(p + "norm_intra"),
+                "inter_in": (g(p + "attn_inter.in_proj_weight"), g(p + "attn_inter.in_proj_bias")),
+                "inter_out": lin(p + "attn_inter.out_proj"), "norm_inter": lin(p + "norm_inter"),
+                "cross": msda(p + "attn_cross"), "norm_cross": lin(p + "norm_cross"),
+                "lin1": lin(p + "linear1"), "lin2": lin(p + "linear2"), "norm3": lin(p + "norm3")})
+        # all six cross-attention value projections as one [6*256, 256] weight
+        self.dec_value_w = torch.cat([L["cross"]["value"][0] for L in self.dec], 0).contiguous()
+        self.dec_value_b = torch.cat([L["cross"]["value"][1] for L in self.dec], 0).contiguous()
+        self.ref_point_head = [lin(t + "decoder.ref_point_head.layers.%d" % i) for i in range(2)]
+        self.bezier_coord = [lin("bezier_proposal_coord.layers.%d" % i) for i in range(3)]
+        self.bezier_class = lin("bezier_proposal_class")
+        self.ctrl_coord = [lin("ctrl_point_coord.0.layers.%d" % i) for i in range(3)]
+        self.ctrl_class = lin("ctrl_point_class.0")
+        self.ctrl_text = lin("ctrl_point_text.0")
+        self.boundary = [lin("boundary_offset.0.layers.%d" % i) for i in range(3)]
+
+        dim_t = torch.arange(128, dtype=_f32)
+        dim_t = T.TEMPERATURE ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / 128)
+        self.dim_t = dim_t.to(device)
+        from scipy.special import comb                      # the reference's table (deformable_transformer.py:83-86)
+        ts = torch.linspace(0, 1, self.P)
+        self.bernstein = torch.tensor([[tt ** k * (1 - tt) ** (3 - k) * comb(3, k) for k in range(4)]
+                                       for tt in ts]).to(device)
+        self._geom = {}
+        self._invalid_logit = None
+
+    # --------------------------------------------------------------------------------- tables
+    @staticmethod
+    def level_shapes(h, w):
+        """Spatial sizes of res3/res4/res5 and the extra stride-64 level for an h x w network input."""
+        def c(x, k, s, p):
+            return (x + 2 * p - k) // s + 1
+        h2, w2 = c(c(h, 7, 2, 3), 3, 2, 1), c(c(w, 7, 2, 3), 3, 2, 1)
+        shapes = []
+        for _ in range(3):
+            h2, w2 = c(h2, 3, 2, 1), c(w2, 3, 2, 1)
+            shapes.append((h2, w2))
+        shapes.append((c(h2, 3, 2, 1), c(w2, 3, 2, 1)))
+        return shapes
+
+    def geometry(self, shapes, B):
+        key = (tuple(shapes), B)
+        if key in self._geom:
+            return self._geom[key]
+        dev = self.device
+        ss = torch.as_tensor(shapes, dtype=torch.long)
+        lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+        S = int(ss.prod(1).sum())
+        ss_d, lsi_d = ss.to(dev), lsi.to(dev)
+        lvl_pos = torch.empty((S, 256), dtype=_f32, device=dev)
+        for l, (H, W) in enumerate(shapes):
+            ops.pos_encoding_into(self.dim_t, self.level_embed[l], lvl_pos[int(lsi[l]):], H, W)
+        geo = {
+            "S": S, "shapes": ss_d, "lsi": lsi_d, "lsi_host": [int(v) for v in lsi],
+            "lvl_pos": ops.broadcast_rows(lvl_pos, B).view(B * S, 256),
+            "enc_ref": ops.broadcast_rows(ops.encoder_reference_points(ss_d, lsi_d, S), B).view(B * S, 1, 2),
+            "valid": ops.proposal_valid(ss_d, lsi_d, S),
+        }
+        self._geom[key] = geo
+        return geo
+
+    def invalid_logit(self):
+        """Class logit of a zeroed memory row (what every invalid-proposal token gets in the reference)."""
+        if self._invalid_logit is None:
+            z = torch.zeros((1, 256), dtype=_f32, device=self.device)
+            om = ops.layernorm(ops.gemm(z, self.enc_output[0], bias=self.enc_output[1]), *self.enc_output_norm)
+            self._invalid_logit = ops.gemm(om, self.bezier_class[0], bias=self.bezier_class[1]).view(1)
+        return self._invalid_logit
+
+    # --------------------------------------------------------------------------------- pieces
+    def _msda(self, W, query, query_pos, ref, value, geo, B, Lq):
+        """MSDeformAttn minus value_proj/output_proj (ms_deform_attn.py:136-151)."""
+        raw = ops.gemm(query, W["raw"][0], bias=W["raw"][1], A2=query_pos)
+        loc, w = ops.msda_prepare(raw, ref, geo["shapes"])
+        S = geo["S"]
+        return ops.ms_deform_attn_forward(value.view(B, S, 8, 32), geo["shapes"], geo["lsi"],
+                                          loc.view(B, Lq, 8, 4, 4, 2), w.view(B, Lq, 8, 4, 4)).view(B * Lq, 256)
+
+    def input_tokens(self, feats, B):
+        """A4 + A5: input_proj (conv + GroupNorm) of the 3 backbone levels + the stride-2 extra level,
+        written level by level into the flattened token buffer."""
+        shapes = [(f.shape[1], f.shape[2]) for f in feats]
+        x3 = ops.conv2d_nhwc(feats[-1], self.proj3[0], shift=self.proj3[1], stride=2, pad=1)
+        shapes.append((x3.shape[1], x3.shape[2]))
+        geo = self.geometry(shapes, B)
+        S = geo["S"]
+        src = torch.empty((B, S, 256), dtype=_f32, device=self.device)
+        for l, f in enumerate(feats):
+            H, W = shapes[l]
+            y = ops.gemm(f.view(B * H * W, f.shape[3]), self.proj[l][0], bias=self.proj[l][1])
+            ops.groupnorm32_into(y.view(B, H * W, 256), self.proj[l][2], self.proj[l][3],
+                                 src[0, geo["lsi_host"][l]:], S * 256)
+        ops.groupnorm32_into(x3.view(B, -1, 256), self.proj3[2], self.proj3[3], src[0, geo["lsi_host"][3]:], S * 256)
+        return src.view(B * S, 256), geo
+
+    def encoder(self, src, geo, B):
+        S = geo["S"]
+        for L in self.enc:
+            value = ops.gemm(src, L["attn"]["value"][0], bias=L["attn"]["value"][1])
+            samp = self._msda(L["attn"], src, geo["lvl_pos"], geo["enc_ref"], value, geo, B, S)
+            x = ops.gemm(samp, L["attn"]["out"][0], bias=L["attn"]["out"][1], R=src)
+            src = ops.layernorm(x, *L["norm1"])
+            h = ops.gemm(src, L["lin1"][0], bias=L["lin1"][1], relu=True)
+            x = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=src)
+            src = ops.layernorm(x, *L["norm2"])
+        return src
+
+    def proposals(self, memory, geo, B):
+        """A8: class logits for every token, top-k, Bezier proposals of the winners -> 25 reference points."""
+        S = geo["S"]
+        om = ops.layernorm(ops.gemm(memory, self.enc_output[0], bias=self.enc_output[1]), *self.enc_output_norm)
+        enc_class = ops.gemm(om, self.bezier_class[0], bias=self.bezier_class[1])              # [B*S, 1]
+        topk, rows = ops.topk_tokens(enc_class, B, S, self.nq, valid=geo["valid"],
+                                     invalid_logit=self.invalid_logit(), with_rows=True)
+        rows = rows.view(-1)                       # coordinate MLP on the nq winning rows per frame only
+        h = ops.gemm(om, self.bezier_coord[0][0], bias=self.bezier_coord[0][1], rows=rows, relu=True)
+        h = ops.gemm(h, self.bezier_coord[1][0], bias=self.bezier_coord[1][1], relu=True)
+        coord_sel = ops.gemm(h, self.bezier_coord[2][0], bias=self.bezier_coord[2][1])          # [B*nq, 8]
+        refs = ops.bezier_reference_points(coord_sel, topk, geo["shapes"], geo["lsi"], self.bernstein, B, S, self.nq,
+                                           self.P, compact=True)
+        return refs, topk, enc_class
+
+    def decoder(self, memory, refs, geo, B):
+        """A9: six composite decoder layers with iterative reference refinement."""
+        nq, P, S = self.nq, self.P, geo["S"]
+        Q = B * nq * P
+        tgt = ops.broadcast_rows(self.point_embed, B).view(Q, 256)
+        values = ops.gemm(memory, self.dec_value_w, bias=self.dec_value_b)                    # [B*S, 1536]
+        refs = refs.view(Q, 2)
+        inter_refs = []
+        E = 256
+        for lid, L in enumerate(self.dec):
+            qpos = ops.point_pos_embed(refs, self.dim_t)
+            qpos = ops.gemm(qpos, self.ref_point_head[0][0], bias=self.ref_point_head[0][1], relu=True)
+            qpos = ops.gemm(qpos, self.ref_point_head[1][0], bias=self.ref_point_head[1][1])
+            # intra-instance attention over the 25 points of each query (deformable_transformer.py:386-394)
+            w, b = L["intra_in"]
+            qk = ops.gemm(tgt, w[:2 * E], bias=b[:2 * E], A2=qpos)                             # [Q, 512]
+            v = ops.gemm(tgt, w[2 * E:], bias=b[2 * E:])
+            attn = torch.empty((Q, E), dtype=_f32, device=self.device)
+            qkf = qk.view(-1)
+            ops.mha_core(qkf, qkf[E:], v, attn, B * nq, 1, 8, 32, P, P,
+                         [P * 2 * E, 0, 2 * E, P * 2 * E, 0, 2 * E, P * E, 0, E, P * E, 0, E])
+            x = ops.gemm(attn, L["intra_out"][0], bias=L["intra_out"][1], R=tgt)
+            tgt = ops.layernorm(x, *L["norm_intra"])
+            # inter-instance attention over the nq queries, batched over (frame, point) (:396-404)
+            w, b = L["inter_in"]
+            qkv = ops.gemm(tgt, w, bias=b)                                                     # [Q, 768]
+            f = qkv.view(-1)
+            ld = 3 * E
+            ops.mha_core(f, f[E:], f[2 * E:], attn, B, P, 8, 32, nq, nq,
+                         [nq * P * ld, ld, P * ld] * 3 + [nq * P * E, E, P * E])
+            x = ops.gemm(attn, L["inter_out"][0], bias=L["inter_out"][1], R=tgt)
+            tgt = ops.layernorm(x, *L["norm_inter"])
+            # deformable cross attention into the encoder memory (:406-422)
+            value = values[:, lid * E:(lid + 1) * E]
+            samp = self._msda_strided(L["cross"], tgt, qpos, refs.view(Q, 1, 2), value, values.stride(0), geo, B,
+                                      nq * P)
+            x = ops.gemm(samp, L["cross"]["out"][0], bias=L["cross"]["out"][1], R=tgt)
+            tgt = ops.layernorm(x, *L["norm_cross"])
+            h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True)
+            x = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt)
+            tgt = ops.layernorm(x, *L["norm3"])
+            # reference refinement (:484-488)
+            d = self._mlp3(tgt, self.ctrl_coord)
+            refs = ops.ref_sigmoid(d, refs, 2)
+            inter_refs.append(refs)
+        return tgt, inter_refs
+
+    def _msda_strided(self, W, query, query_pos, ref, value_view, ld_value, geo, B, Lq):
+        """Cross-attention sampling straight out of the fused [B*S, 1536] value buffer (no compaction copy)."""
+        raw = ops.gemm(query, W["raw"][0], bias=W["raw"][1], A2=query_pos)
+        loc, w = ops.msda_prepare(raw, ref, geo["shapes"])
+        return ops.ms_deform_attn_forward_strided(value_view, geo["S"] * ld_value, geo["shapes"], geo["lsi"], loc, w,
+                                                  B, Lq)
+
+    def _mlp3(self, x, layers):
+        h = ops.gemm(x, layers[0][0], bias=layers[0][1], relu=True)
+        h = ops.gemm(h, layers[1][0], bias=layers[1][1], relu=True)
+        return ops.gemm(h, layers[2][0], bias=layers[2][1])
+
+    def heads(self, hs, inter_refs):
+        """A10: last-layer heads with inter_references[last-1] (detection_transformer_wobackbone.py:209-253)."""
+        ref = inter_refs[self.n_dec - 2]
+        cls = ops.gemm(hs, self.ctrl_class[0], bias=self.ctrl_class[1])                       # [Q,1]
+        text = ops.gemm(hs, self.ctrl_text[0], bias=self.ctrl_text[1])                        # [Q,voc+1]
+        ctrl = ops.ref_sigmoid(self._mlp3(hs, self.ctrl_coord), ref, 2)
+        bd = ops.ref_sigmoid(self._mlp3(hs, self.boundary), ref, 4)
+        return {"pred_logits": cls, "pred_text_logits": text, "pred_ctrl_points": ctrl, "pred_bd_points": bd,
+                "query_features": hs}
+
+    # --------------------------------------------------------------------------------- whole forward
+    def forward(self, feats, taps=None):
+        """feats: [res3, res4, res5] NHWC tensors of one batch of same-size frames.  Returns the reference's
+        output dict with tensors flattened over (B, nq, P): pred_logits [B*nq*P,1], pred_text_logits [.,voc+1],
+        pred_ctrl_points [.,2], pred_bd_points [.,4], query_features [.,256]."""
+        B = feats[0].shape[0]
+        src, geo = self.input_tokens(feats, B)
+        memory = self.encoder(src, geo, B)
+        refs, topk, enc_class = self.proposals(memory, geo, B)
+        hs, inter_refs = self.decoder(memory, refs, geo, B)
+        out = self.heads(hs, inter_refs)
+        if taps is not None:
+            taps.update(src=src, memory=memory, topk=topk, enc_class=enc_class, init_ref=refs, geo=geo)
+        return out

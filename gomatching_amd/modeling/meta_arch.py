@@ -1,0 +1,363 @@
+"""`GoMatching` meta-architecture on MI355X: the reference's inference interface
+(/root/reference/gomatching/modeling/meta_arch/gom_lstmatcher.py:113-651) over the HIP kernels.
+
+Same public surface as the reference class -- `inference`, `batch_inference`, `run_short_term_match`,
+`run_long_term_match`, `_remove_short_track`, `batch_postprocess`, `min_track_len`, `roi_heads`,
+`detection_transformer` -- so `GoMBatchPredictor.__call__` (text_track_visualizer.py:295-335) and
+eval.py drive it unchanged.  What differs is the schedule:
+  * detection + embedding of a whole step of frames runs as ONE batch on the GPU (the reference loops
+    frames one at a time, :369-371); frames are independent there (frozen BN, per-sample GN/LN);
+  * thresholding, boxes, NMS and the foreground filter stay on the device with nq-padded outputs
+    (`gom_detect_post`), so there is one host sync per step, not several per frame;
+  * the tracker keeps the reference's strictly sequential control flow and host-side integer id
+    bookkeeping + assignment; its float arithmetic runs in HIP kernels.
+Training (`forward` returning losses) is out of scope and raises.
+"""
+import time
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..structures import Boxes, Instances
+from ..weights import normalize_state_dict
+from .backbone import ResNet50
+from .deepsolo import DeepSolo
+from .roi_heads import build_roi_heads
+
+_f32 = torch.float32
+
+
+class GoMatching:
+    def __init__(self, cfg, state_dict, device=None, frames_per_step=8):
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else cfg.MODEL.DEVICE)
+        if self.device.type != "cuda":
+            raise RuntimeError("gomatching_amd runs on an MI355X only (MODEL.DEVICE=%s); there is no CPU path" %
+                               cfg.MODEL.DEVICE)
+        if cfg.MODEL.BACKBONE.NAME != "build_resnet_backbone":
+            raise NotImplementedError("only the R-50 backbone of the shipped configs is built (SURVEY.md §8-f3)")
+        V = cfg.VIDEO_TEST
+        self.test_len = cfg.INPUT.VIDEO.TEST_LEN
+        self.overlap_thresh = V.OVERLAP_THRESH
+        self.min_track_len = V.MIN_TRACK_LEN
+        self.max_center_dist = V.MAX_CENTER_DIST
+        self.decay_time = V.DECAY_TIME
+        self.asso_thresh = cfg.MODEL.ASSO_HEAD.ASSO_THRESH
+        self.with_iou = V.WITH_IOU
+        self.not_mult_thresh = V.NOT_MULT_THRESH
+        self.nms_thresh = V.NMS_THRESH
+        self.with_rescore = cfg.MODEL.ROI_HEADS.WITH_RESR
+        self.test_score_threshold = cfg.MODEL.TRANSFORMER.INFERENCE_TH_TEST
+        self.min_size_test = None          # only set for the ViTAE backbone in the reference (:144-146)
+        self.max_size_test = None
+        self.pixel_mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
+        self.pixel_std = [float(v) for v in cfg.MODEL.PIXEL_STD]
+        self.frames_per_step = frames_per_step
+        self.training = False
+
+        sd = normalize_state_dict(state_dict)
+        self.backbone = ResNet50(sd, self.device)
+        self.detection_transformer = DeepSolo(cfg, sd, self.device)
+        self.roi_heads = build_roi_heads(cfg, sd, self.device)
+        self._pool = None
+        self._pool_used = 0
+
+    @classmethod
+    def from_config(cls, cfg, state_dict, **kw):
+        return cls(cfg, state_dict, **kw)
+
+    def eval(self):
+        return self
+
+    def __call__(self, batched_inputs):
+        return self.forward(batched_inputs)
+
+    def forward(self, batched_inputs):
+        raise NotImplementedError("training forward (losses) is outside the MI355X inference path (SURVEY.md §8-f4)")
+
+    # ------------------------------------------------------------------------------------ detection
+    def preprocess_image(self, batched_inputs):
+        """gom_lstmatcher.py:164-170 for same-size frames: normalise + channels-last (no padding needed)."""
+        imgs = [x["image"] for x in batched_inputs]
+        hw = tuple(imgs[0].shape[-2:])
+        for im in imgs:
+            if tuple(im.shape[-2:]) != hw:
+                raise ValueError("frames of one step must share a size (got %s and %s)" % (hw, tuple(im.shape[-2:])))
+        x = torch.stack([im.to(self.device, non_blocking=True).to(_f32) for im in imgs]).contiguous()
+        return ops.preprocess(x, self.pixel_mean, self.pixel_std), hw
+
+    def _ensure_pool(self, extra_rows):
+        need = self._pool_used + extra_rows
+        if self._pool is None or need > self._pool.shape[0]:
+            cap = max(need, 2 * (self._pool.shape[0] if self._pool is not None else 0), 1024)
+            new = torch.empty((cap, self.roi_heads.feature_dim), dtype=_f32, device=self.device)
+            if self._pool is not None and self._pool_used:
+                new[:self._pool_used].copy_(self._pool[:self._pool_used])
+            self._pool = new
+
+    def inference(self, batched_inputs, time_cost):
+        """Detection + re-id embedding for a step of frames (gom_lstmatcher.py:268-351), batched."""
+        assert not self.training
+        sync = torch.cuda.synchronize if time_cost.get("_sync") else (lambda: None)
+        t0 = time.time()
+        x, hw = self.preprocess_image(batched_inputs)
+        sync(); time_cost["pre_process"] += time.time() - t0
+        t0 = time.time()
+        feats = self.backbone.forward(x)
+        sync(); time_cost["backbone"] += time.time() - t0
+        t0 = time.time()
+        out = self.detection_transformer.forward([feats["res3"], feats["res4"], feats["res5"]])
+        sync(); time_cost["detector"] += time.time() - t0
+        re = None
+        if self.with_rescore:
+            t0 = time.time()
+            re = self.roi_heads.rescoring_head(out["query_features"])
+            sync(); time_cost["rescore"] += time.time() - t0
+        return self._detect_and_embed(out, re, len(batched_inputs), hw, time_cost)
+
+    def _detect_and_embed(self, out, re, B, hw, time_cost):
+        T = self.cfg.MODEL.TRANSFORMER
+        nq, P = T.NUM_QUERIES, T.NUM_POINTS
+        recs = ops.argmax_rows(out["pred_text_logits"])
+        det = ops.detect_post(out["pred_logits"], re, out["pred_ctrl_points"], out["pred_bd_points"], recs, B, nq, P,
+                              hw[0], hw[1], self.test_score_threshold, self.nms_thresh,
+                              self.roi_heads.asso_thresh_test)
+        t0 = time.time()
+        counts = det["count"].cpu().numpy()                   # the one host sync of the step
+        keep = det["keep_idx"].cpu().numpy()
+        scores_h = det["scores"].cpu().numpy()
+        boxes_h = det["boxes"].cpu().numpy()
+        n_total = int(counts.sum())
+        rows = np.concatenate([keep[b, :counts[b]] for b in range(B)]) if n_total else np.zeros((0,), np.int32)
+        self._ensure_pool(n_total)
+        row0 = self._pool_used
+        if n_total:
+            rows_d = torch.from_numpy(rows.astype(np.int32)).to(self.device)
+            qf = out["query_features"].view(B * nq, P * T.HIDDEN_DIM)
+            x = ops.gemm(qf, self.roi_heads.fcs[0][0], bias=self.roi_heads.fcs[0][1], rows=rows_d, relu=True)
+            for i, (w, b) in enumerate(self.roi_heads.fcs[1:]):
+                last = i == len(self.roi_heads.fcs) - 2
+                x = ops.gemm(x, w, bias=b, relu=True, out=self._pool[row0:row0 + n_total] if last else None)
+            if len(self.roi_heads.fcs) == 1:
+                self._pool[row0:row0 + n_total].copy_(x)
+        self._pool_used += n_total
+        time_cost["tracker"] += time.time() - t0
+        results, off = [], row0
+        for b in range(B):
+            n = int(counts[b])
+            r = Instances(hw)
+            r.reid_features = self._pool[off:off + n]
+            r.pred_boxes = Boxes(det["boxes"][b, :n])
+            r.scores = det["scores"][b, :n]
+            r.pred_classes = torch.zeros((n,), dtype=torch.int64, device=self.device)
+            r.ctrl_points = det["ctrl"][b, :n]
+            r.recs = det["recs"][b, :n]
+            r.bd = det["bd"][b, :n]
+            r._gom = {"boxes": boxes_h[b, :n].copy(), "scores": scores_h[b, :n].copy(), "row0": off, "ids": None}
+            results.append(r)
+            off += n
+        return results
+
+    # ------------------------------------------------------------------------------------ tracking
+    @staticmethod
+    def _host(inst):
+        """Host-side mirror (boxes, ids, pool rows) of an Instances; rebuilt for foreign Instances."""
+        g = getattr(inst, "_gom", None)
+        if g is None:
+            g = {"boxes": inst.pred_boxes.tensor.detach().cpu().numpy(), "row0": None, "ids": None}
+            inst._gom = g
+        if g["ids"] is None and inst.has("track_ids"):
+            g["ids"] = inst.track_ids.detach().cpu().numpy().astype(np.int64)
+        return g
+
+    def _set_ids(self, inst, ids):
+        ids = np.asarray(ids, dtype=np.int64)
+        self._host(inst)["ids"] = ids
+        inst._fields["track_ids"] = torch.from_numpy(ids.copy()).to(self.device)
+
+    def _reid_rows(self, inst, sel):
+        """Pool rows of the selected detections of one frame (re-homes foreign features into the pool)."""
+        g = self._host(inst)
+        if g["row0"] is None or not self._in_pool(inst):
+            n = len(inst)
+            self._ensure_pool(n)
+            g["row0"] = self._pool_used
+            if n:
+                self._pool[g["row0"]:g["row0"] + n].copy_(inst.reid_features)
+            inst._fields["reid_features"] = self._pool[g["row0"]:g["row0"] + n]
+            self._pool_used += n
+        return g["row0"] + np.nonzero(sel)[0]
+
+    def _in_pool(self, inst):
+        if self._pool is None or not inst.has("reid_features"):
+            return False
+        f = inst.reid_features
+        if f.numel() == 0:
+            return True
+        lo = self._pool.data_ptr()
+        return lo <= f.data_ptr() < lo + self._pool.numel() * 4
+
+    def _match(self, window, sels, k, short_term, hw):
+        """Shared arithmetic of run_short_term_match / run_long_term_match: returns (traj [n_k,M] numpy,
+        unique ids [M], ids of the non-k detections)."""
+        n_t = [int(s.sum()) for s in sels]
+        N, T = sum(n_t), len(n_t)
+        n_k = n_t[k]
+        ids = np.concatenate([self._host(w)["ids"][s] for t, (w, s) in enumerate(zip(window, sels)) if t != k]) \
+            if T > 1 else np.zeros((0,), np.int64)
+        Np = N - n_k
+        uniq = np.unique(ids)
+        M = len(uniq)
+        if n_k == 0 or M == 0:
+            return np.zeros((n_k, M), np.float32), uniq
+        rows = np.concatenate([self._reid_rows(w, s) for w, s in zip(window, sels)]).astype(np.int32)
+        boxes = np.concatenate([self._host(w)["boxes"][s] for w, s in zip(window, sels)]).astype(np.float32)
+        lo = sum(n_t[:k])
+        k_inds = np.arange(lo, lo + n_k)
+        nonk = np.concatenate([np.arange(0, lo), np.arange(lo + n_k, N)])
+        col_of = np.searchsorted(uniq, ids)
+        # "last box of a track": arg-max over onehot*arange, first index on ties (gom_lstmatcher.py:436-438)
+        last = np.zeros((M,), np.int64)
+        for j in range(Np):
+            last[col_of[j]] = j if j > 0 else last[col_of[j]]
+        meta = np.concatenate([nonk, col_of, last, k_inds]).astype(np.int32)
+        decay = None
+        if (not short_term) and self.decay_time > 0:
+            dts = np.concatenate([np.full((n,), T - t - 2, np.float32) for t, n in enumerate(n_t) if t != k])
+            decay = torch.from_numpy(np.power(np.float32(self.decay_time), dts).astype(np.float32)).to(self.device)
+        src = ops.gather_rows(self._pool, torch.from_numpy(rows).to(self.device))
+        asso = self.roi_heads._forward_transformer(src, n_t, k, short_term=short_term)
+        act = self.roi_heads._activate_asso(asso, n_t)
+        traj = ops.track_score(act, torch.from_numpy(meta).to(self.device), decay,
+                               torch.from_numpy(boxes).to(self.device), hw[1], hw[0], n_k, Np, M, self.with_iou,
+                               self.max_center_dist if not short_term else 0.0)
+        return traj.cpu().numpy(), uniq
+
+    def _assign(self, traj, uniq, ids_nonk, n_k):
+        """LSA on -traj + thresholding (gom_lstmatcher.py:447-453 / 549-555)."""
+        track_ids = np.full((n_k,), -1, np.int64)
+        if traj.size:
+            mi, mj = ops.linear_sum_assignment(-traj.astype(np.float64))
+            for i, j in zip(mi, mj):
+                thresh = self.overlap_thresh if self.not_mult_thresh else \
+                    self.overlap_thresh * float((ids_nonk == uniq[j]).sum())
+                if traj[i, j] > np.float32(thresh):
+                    track_ids[i] = uniq[j]
+        return track_ids
+
+    def run_short_term_match(self, instances, id_count=None):
+        """gom_lstmatcher.py:405-465."""
+        prev, cur = instances
+        sels = [np.ones((len(prev),), bool), np.ones((len(cur),), bool)]
+        traj, uniq = self._match(instances, sels, 1, True, cur.image_size)
+        track_ids = self._assign(traj, uniq, self._host(prev)["ids"], len(cur))
+        if id_count:
+            for i in range(len(cur)):
+                if track_ids[i] < 0:
+                    id_count = id_count + 1
+                    track_ids[i] = id_count
+        self._set_ids(cur, track_ids)
+        if id_count:
+            return instances, id_count
+        return instances, np.unique(track_ids)
+
+    def run_long_term_match(self, full_instances, k, id_count, cur_id):
+        """gom_lstmatcher.py:467-564."""
+        cur = set(int(c) for c in np.asarray(cur_id).reshape(-1))
+        sels = []
+        for idx, p in enumerate(full_instances):
+            ids = self._host(p)["ids"]
+            if idx != len(full_instances) - 1:
+                sels.append(np.array([int(t) not in cur for t in ids], dtype=bool))
+            else:
+                sels.append(ids == -1)
+        traj, uniq = self._match(full_instances, sels, k, False, full_instances[k].image_size)
+        ids_nonk = np.concatenate([self._host(p)["ids"][s] for t, (p, s) in enumerate(zip(full_instances, sels))
+                                   if t != k]) if len(full_instances) > 1 else np.zeros((0,), np.int64)
+        n_k = int(sels[k].sum())
+        track_ids = self._assign(traj, uniq, ids_nonk, n_k)
+        for i in range(n_k):
+            if track_ids[i] < 0:
+                id_count = id_count + 1
+                track_ids[i] = id_count
+        full = self._host(full_instances[k])["ids"].copy()
+        full[sels[k]] = track_ids
+        self._set_ids(full_instances[k], full)
+        return full_instances, id_count
+
+    def batch_inference(self, batched_inputs, batch_id, id_count, instances, time_cost):
+        """gom_lstmatcher.py:366-403: detection runs per step of `frames_per_step` frames, the id recurrence
+        stays strictly per frame."""
+        video_len = len(batched_inputs)
+        start_frame_id = batch_id * 100
+        # keep the carried-over window's embeddings addressable, drop everything older
+        carried = [x for x in instances[-self.test_len:] if x.has("reid_features")]
+        saved = [x.reid_features.clone() for x in carried]      # may alias the pool that is about to be reused
+        self._pool_used = 0
+        for x, f in zip(carried, saved):
+            self._host(x)["row0"] = None
+            x._fields["reid_features"] = f
+            self._reid_rows(x, np.ones((len(x),), bool))
+        self._ensure_pool(video_len * self.cfg.MODEL.TRANSFORMER.NUM_QUERIES)   # no re-allocation mid-batch
+        dets = []
+        for s0 in range(0, video_len, self.frames_per_step):
+            dets.extend(self.inference(batched_inputs[s0:s0 + self.frames_per_step], time_cost))
+        for frame_id in range(video_len):
+            instances.append(dets[frame_id])
+            real_frame_id = start_frame_id + frame_id
+            if real_frame_id == 0:
+                n0 = len(instances[0])
+                self._set_ids(instances[0], np.arange(1, n0 + 1))
+                id_count = n0 + 1
+            elif real_frame_id == 1:
+                t0 = time.time()
+                instances[0:2], id_count = self.run_short_term_match(instances[0:2], id_count=id_count)
+                time_cost["short_match"] += time.time() - t0
+            else:
+                t0 = time.time()
+                instances[real_frame_id - 1: real_frame_id + 1], cur_id = self.run_short_term_match(
+                    instances[real_frame_id - 1: real_frame_id + 1])
+                time_cost["short_match"] += time.time() - t0
+                if -1 in cur_id:
+                    win_st = max(0, real_frame_id + 1 - self.test_len)
+                    win_ed = real_frame_id + 1
+                    t0 = time.time()
+                    instances[win_st:win_ed], id_count = self.run_long_term_match(
+                        instances[win_st:win_ed], k=min(self.test_len - 1, real_frame_id), id_count=id_count,
+                        cur_id=cur_id)
+                    time_cost["long_match"] += time.time() - t0
+            ids = self._host(instances[-1])["ids"]
+            assert len(ids) == len(np.unique(ids))
+            if real_frame_id - self.test_len >= 0:
+                instances[real_frame_id - self.test_len].remove("reid_features")
+        return instances, id_count
+
+    def _remove_short_track(self, instances):
+        """gom_lstmatcher.py:566-577."""
+        ids = np.concatenate([self._host(x)["ids"] for x in instances]) if instances else np.zeros((0,), np.int64)
+        uniq, counts = np.unique(ids, return_counts=True)
+        short = set(int(u) for u, c in zip(uniq, counts) if c < self.min_track_len)
+        for k in range(len(instances)):
+            hid = self._host(instances[k])["ids"]
+            keep = np.array([int(t) not in short for t in hid], dtype=bool)
+            g = instances[k]._gom
+            idx = torch.from_numpy(np.nonzero(keep)[0]).to(self.device)
+            new = instances[k][idx]
+            new._gom = {"boxes": g["boxes"][keep], "ids": hid[keep], "row0": None}
+            instances[k] = new
+        return instances
+
+    def batch_postprocess(self, instances, image_sizes):
+        """gom_lstmatcher.py:353-364 + detector_postprocess :78-111 (non-ViTAE branch): scale ctrl_points and
+        bd to the original frame size; pred_boxes stay in network-input pixels."""
+        processed = []
+        for r, image_size in zip(instances, image_sizes):
+            height, width = image_size[0], image_size[1]
+            sx, sy = width / r.image_size[1], height / r.image_size[0]
+            if r.has("ctrl_points"):
+                r._fields["ctrl_points"] = ops.scale_xy_(r.ctrl_points.contiguous(), sx, sy)
+            if r.has("pred_boxes") and not isinstance(r.bd, list):
+                r._fields["bd"] = ops.scale_xy_(r.bd.contiguous(), sx, sy)
+            processed.append({"instances": r})
+        return processed

@@ -1,0 +1,157 @@
+"""LST-Matcher association heads on MI355X.
+
+Mirrors of the reference's ROI_HEADS classes, same names and inference-side methods:
+  * `LSTMatcher`       /root/reference/gomatching/modeling/roi_heads/lstmatcher.py:59-557
+  * `SHA_FFN_CRSATTN`  /root/reference/gomatching/modeling/roi_heads/shared_ffn_crsattn.py:62-535
+Only the shipped-config shape is built (NUM_WEIGHT_LAYERS 0 -> bare dot-product predictor, NO_POS_EMB,
+NORM False, NO_DECODER_SELF_ATT): other shapes raise at construction.  Training methods
+(`loss_res`, `_get_asso_gt`, `detr_asso_loss`) are out of scope.
+"""
+import torch
+
+from .. import ops
+
+_f32 = torch.float32
+
+
+def _dev(t, device):
+    return t.detach().float().contiguous().to(device)
+
+
+class _MatcherTransformer:
+    """roi_heads/transformer.py:19-96 with norm=False: post-norm layers whose norms are Identity."""
+
+    def __init__(self, sd, name, device, d, heads, n_enc, n_dec, only_dec_crs_attn):
+        self.d, self.heads, self.only_crs = d, heads, only_dec_crs_attn
+        g = lambda k: _dev(sd[name + "." + k], device)
+        self.enc = []
+        for i in range(n_enc):
+            p = "encoder.layers.%d." % i
+            self.enc.append({"in": (g(p + "self_attn.in_proj_weight"), g(p + "self_attn.in_proj_bias")),
+                             "out": (g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias")),
+                             "lin1": (g(p + "linear1.weight"), g(p + "linear1.bias")),
+                             "lin2": (g(p + "linear2.weight"), g(p + "linear2.bias"))})
+        self.dec = []
+        for i in range(n_dec):
+            p = "decoder.layers.%d." % i
+            L = {"in": (g(p + "multihead_attn.in_proj_weight"), g(p + "multihead_attn.in_proj_bias")),
+                 "out": (g(p + "multihead_attn.out_proj.weight"), g(p + "multihead_attn.out_proj.bias"))}
+            if not only_dec_crs_attn:
+                L["lin1"] = (g(p + "linear1.weight"), g(p + "linear1.bias"))
+                L["lin2"] = (g(p + "linear2.weight"), g(p + "linear2.bias"))
+            self.dec.append(L)
+
+    def _attend(self, q, k, v, ld_q, ld_kv, Lq, Lk):
+        out = torch.empty((Lq, self.d), dtype=_f32, device=q.device)
+        hd = self.d // self.heads
+        ops.mha_core(q, k, v, out, 1, 1, self.heads, hd, Lq, Lk,
+                     [0, 0, ld_q, 0, 0, ld_kv, 0, 0, ld_kv, 0, 0, self.d])
+        return out
+
+    def forward(self, src, lo, hi):
+        """src [N,F] (frames concatenated), query rows [lo,hi) -> (feats [M,F], memory [N,F])."""
+        N, E = src.shape
+        memory = src
+        for L in self.enc:                                   # forward_post, norms = Identity (transformer.py:180-195)
+            qkv = ops.gemm(memory, L["in"][0], bias=L["in"][1])                       # [N, 3E]
+            f = qkv.view(-1)
+            a = self._attend(f, f[E:], f[2 * E:], 3 * E, 3 * E, N, N)
+            memory = ops.gemm(a, L["out"][0], bias=L["out"][1], R=memory)
+            h = ops.gemm(memory, L["lin1"][0], bias=L["lin1"][1], relu=True)
+            memory = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=memory)
+        tgt = src[lo:hi]                                     # tgt = src[query_inds] (transformer.py:80-84)
+        M = hi - lo
+        for L in self.dec:                                   # no decoder self-attention (transformer.py:270-294)
+            w, b = L["in"]
+            q = ops.gemm(tgt, w[:E], bias=b[:E])
+            kv = ops.gemm(memory, w[E:], bias=b[E:])                                  # [N, 2E]
+            f = kv.view(-1)
+            a = self._attend(q, f, f[E:], E, 2 * E, M, N)
+            tgt = ops.gemm(a, L["out"][0], bias=L["out"][1], R=tgt)
+            if not self.only_crs:
+                h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True)
+                tgt = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt)
+        return tgt, memory
+
+
+class _MatcherBase:
+    def __init__(self, cfg, sd, device, prefix="roi_heads."):
+        A = cfg.MODEL.ASSO_HEAD
+        if A.NUM_WEIGHT_LAYERS != 0 or not A.NO_POS_EMB or A.NORM or not A.NO_DECODER_SELF_ATT or A.NO_ENCODER_SELF_ATT:
+            raise NotImplementedError("association head shape outside the shipped configs (see module docstring)")
+        self.cfg, self.device, self.prefix = cfg, device, prefix
+        self.feature_dim = A.FC_DIM
+        self.num_fc = A.NUM_FC
+        self.with_rescore = cfg.MODEL.ROI_HEADS.WITH_RESR
+        self.asso_thresh_train = A.ASSO_THRESH
+        self.fcs = [(_dev(sd[prefix + "asso_head.fc%d.weight" % (k + 1)], device),
+                     _dev(sd[prefix + "asso_head.fc%d.bias" % (k + 1)], device)) for k in range(self.num_fc)]
+        if self.with_rescore:
+            self._rescoring = (_dev(sd[prefix + "rescoring_head.weight"], device),
+                               _dev(sd[prefix + "rescoring_head.bias"], device))
+
+    def rescoring_head(self, query_features):
+        """nn.Linear(256, 1) on every point query (lstmatcher.py:185-186; call gom_lstmatcher.py:286-289)."""
+        x = query_features.reshape(-1, query_features.shape[-1])
+        return ops.gemm(x, self._rescoring[0], bias=self._rescoring[1])
+
+    def asso_head(self, query_features, rows):
+        """FCHead4Query (association_head.py:100-122) on the gathered rows of [B*nq, 25*256]."""
+        x = ops.gemm(query_features, self.fcs[0][0], bias=self.fcs[0][1], rows=rows, relu=True)
+        for w, b in self.fcs[1:]:
+            x = ops.gemm(x, w, bias=b, relu=True)
+        return x
+
+    def _matcher(self, short_term):
+        raise NotImplementedError
+
+    def _forward_transformer(self, reid_features, n_t, query_frame, short_term=False):
+        """lstmatcher.py:333-370 (eval; no positional/temporal embedding): returns asso logits [n_k, N]."""
+        lo, hi = sum(n_t[:query_frame]), sum(n_t[:query_frame + 1])
+        feats, memory = self._matcher(short_term).forward(reid_features, lo, hi)
+        return ops.gemm(feats, memory)                        # ATTWeightHead with 0 layers: q . k^T
+
+    def _activate_asso(self, asso_logits, n_t):
+        """lstmatcher.py:373-381 on the concatenated [n_k, N] logits."""
+        offs = [0]
+        for n in n_t:
+            offs.append(offs[-1] + n)
+        offs = torch.tensor(offs, dtype=torch.int32).to(self.device)
+        return ops.asso_activate(asso_logits, offs, len(n_t))
+
+
+class LSTMatcher(_MatcherBase):
+    def __init__(self, cfg, sd, device, prefix="roi_heads."):
+        super().__init__(cfg, sd, device, prefix)
+        A = cfg.MODEL.ASSO_HEAD
+        t = A.ASSO_THRESH_TEST
+        self.asso_thresh_test = t if t > 0 else A.ASSO_THRESH
+        mk = lambda n: _MatcherTransformer(sd, prefix + n, device, A.FC_DIM, A.NUM_HEADS, A.NUM_ENCODER_LAYERS,
+                                           A.NUM_DECODER_LAYERS, False)
+        self.long_term_matcher = mk("long_term_matcher")
+        self.short_term_matcher = mk("short_term_matcher")
+
+    def _matcher(self, short_term):
+        return self.short_term_matcher if short_term else self.long_term_matcher
+
+
+class SHA_FFN_CRSATTN(_MatcherBase):
+    def __init__(self, cfg, sd, device, prefix="roi_heads."):
+        super().__init__(cfg, sd, device, prefix)
+        A = cfg.MODEL.ASSO_HEAD
+        t = cfg.MODEL.TRANSFORMER.INFERENCE_TH_TEST                     # shared_ffn_crsattn.py:160
+        self.asso_thresh_test = t if t > 0 else A.ASSO_THRESH
+        self.shared_matcher = _MatcherTransformer(sd, prefix + "shared_matcher", device, A.FC_DIM, A.NUM_HEADS, 0,
+                                                  A.NUM_DECODER_LAYERS, True)
+
+    def _matcher(self, short_term):
+        return self.shared_matcher
+
+
+def build_roi_heads(cfg, sd, device):
+    name = cfg.MODEL.ROI_HEADS.NAME
+    if name == "LSTMatcher":
+        return LSTMatcher(cfg, sd, device)
+    if name == "SHA_FFN_CRSATTN":
+        return SHA_FFN_CRSATTN(cfg, sd, device)
+    raise ValueError("unknown MODEL.ROI_HEADS.NAME %r" % name)

@@ -124,6 +124,16 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+def ms_deform_attn_forward_strided(value2d, batch_stride, shapes, lsi, loc, w, B, Lq):
+    """value2d: [B*S, 256] column slice (stride(1)==1) of a wider buffer; reads it in place."""
+    assert value2d.stride(1) == 1
+    out = torch.empty((B * Lq, 256), dtype=_f32, device=value2d.device)
+    check(_L().gom_ms_deform_attn_forward_strided(_p(value2d), batch_stride, value2d.stride(0), _p(shapes), _p(lsi),
+                                                  _p(loc), _p(w), _p(out), B, Lq, _stream()),
+          "gom_ms_deform_attn_forward_strided")
+    return out
+
+
 def msda_prepare(raw, ref, spatial_shapes, ref_levels=1):
     """raw [Q, >=384] (offsets | logits), ref [Q, ref_levels, 2] -> loc [Q,8,4,4,2], w [Q,8,4,4]."""
     _chk_f32(ref)
@@ -199,12 +209,21 @@ def encoder_reference_points(shapes, lsi, S):
     return out
 
 
-def bezier_reference_points(coord_raw, topk_idx, shapes, lsi, bern, B, S, nq, P):
+def bezier_reference_points(coord_raw, topk_idx, shapes, lsi, bern, B, S, nq, P, compact=False):
+    """coord_raw: [B,S,8] (compact=False) or the selected tokens' rows [B*nq,8] (compact=True)."""
     _chk_f32(coord_raw, bern)
     out = torch.empty((B, nq, P, 2), dtype=_f32, device=coord_raw.device)
     check(_L().gom_bezier_reference_points(_p(coord_raw), _p(topk_idx), _p(shapes), _p(lsi), shapes.shape[0],
-                                           _p(bern), _p(out), B, S, nq, P, _stream()), "gom_bezier_reference_points")
+                                           _p(bern), _p(out), B, S, nq, P, 1 if compact else 0, _stream()),
+          "gom_bezier_reference_points")
     return out
+
+
+def scale_xy_(x, sx, sy):
+    """In-place scaling of interleaved (x, y) pairs of a contiguous tensor."""
+    _chk_f32(x)
+    check(_L().gom_scale_xy_f32(_p(x), x.numel() // 2, float(sx), float(sy), _stream()), "gom_scale_xy_f32")
+    return x
 
 
 def add(a, b):
@@ -221,14 +240,15 @@ def broadcast_rows(src, B):
     return out
 
 
-def topk_tokens(logits, B, S, k, valid=None, invalid_logit=None):
+def topk_tokens(logits, B, S, k, valid=None, invalid_logit=None, with_rows=False):
     """logits: [B*S, ld] (column 0 used) -> int32 [B,k] sorted by value desc."""
     nbytes = _L().gom_topk_workspace_bytes(B, S, k)
     ws = torch.empty((max(nbytes, 8),), dtype=torch.uint8, device=logits.device)
     idx = torch.empty((B, k), dtype=torch.int32, device=logits.device)
+    rows = torch.empty((B, k), dtype=torch.int32, device=logits.device) if with_rows else None
     check(_L().gom_topk_tokens(_p(logits), logits.stride(0), _p(valid), _p(invalid_logit), B, S, k, _p(ws), _p(idx),
-                               _stream()), "gom_topk_tokens")
-    return idx
+                               _p(rows), _stream()), "gom_topk_tokens")
+    return (idx, rows) if with_rows else idx
 
 
 def argmax_rows(x):

@@ -50,6 +50,12 @@ int gom_ms_deform_attn_forward(const float* value, const int64_t* spatial_shapes
                                int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                                int num_point, void* stream);
 
+/* Same op, value read in place from a wider row-major buffer (row / batch strides in floats). */
+int gom_ms_deform_attn_forward_strided(const float* value, long value_batch_stride, int value_row_stride,
+                                       const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                       const float* sampling_loc, const float* attn_weight, float* output, int batch,
+                                       int num_query, void* stream);
+
 /* Sampling-location + softmax arithmetic of MSDeformAttn.forward (ms_deform_attn.py:136-145).
  * raw [Q, ld_raw]: columns [0,256) = sampling_offsets output, [256,384) = attention_weights logits;
  * ref [Q, ref_levels, 2] (ref_levels 1 = same point on every level, the unpadded case). */
@@ -103,17 +109,20 @@ int gom_proposal_valid(const int64_t* spatial_shapes, const int64_t* level_start
                        unsigned char* valid, long S, void* stream);
 int gom_encoder_reference_points(const int64_t* spatial_shapes, const int64_t* level_start_index, int num_levels,
                                  float* ref, long S, void* stream);
+/* coord_raw: [B,S,8] indexed by token (compact = 0) or [B*num_queries,8] rows of the selected tokens (compact = 1). */
 int gom_bezier_reference_points(const float* coord_raw, const int* topk_idx, const int64_t* spatial_shapes,
                                 const int64_t* level_start_index, int num_levels, const float* bernstein, float* refs,
-                                int B, long S, int num_queries, int num_points, void* stream);
+                                int B, long S, int num_queries, int num_points, int compact, void* stream);
+/* A18: in-place (x, y) pair scaling, detector_postprocess gom_lstmatcher.py:100-109. */
+int gom_scale_xy_f32(float* x, long n_pairs, float sx, float sy, void* stream);
 int gom_add_f32(const float* a, const float* b, float* out, long n, void* stream);
 int gom_broadcast_rows_f32(const float* src, float* out, long n, int B, void* stream);
 
 /* top-k token indices per batch element (deformable_transformer.py:188-190); idx_out [B,k] int32, sorted by
- * logit descending.  valid/invalid_logit (optional): tokens with valid[s]==0 take *invalid_logit. */
+ * logit descending; rows_out (optional) [B,k] = b*S + idx.  valid/invalid_logit (optional): tokens with valid[s]==0 take *invalid_logit. */
 long gom_topk_workspace_bytes(int B, long S, int k);
 int gom_topk_tokens(const float* logits, int ld, const unsigned char* valid, const float* invalid_logit, int B, long S,
-                    int k, void* workspace, int* idx_out, void* stream);
+                    int k, void* workspace, int* idx_out, int* rows_out, void* stream);
 
 /* ---- A11/A12: detection() + NMS + foreground filter ---------------------------------------------------*/
 int gom_argmax_rows_f32(const float* x, int ld, int V, long rows, int* out, void* stream);

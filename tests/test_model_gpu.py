@@ -1,0 +1,171 @@
+"""GPU parity of the assembled path (backbone, DeepSolo, matcher heads, tracker, whole clip) against the
+reference-generated fixtures and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import mini_cfg, golden, e2e_state_dict, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(a, b, atol, msg=""):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (msg, a.shape, b.shape)
+    err = (a - b).abs()
+    assert bool((err <= atol).all()), "%s max|d|=%.3e (tol %.1e)" % (msg, float(err.max()) if err.numel() else 0, atol)
+
+
+def _time_cost():
+    return {k: 0.0 for k in ("pre_process", "backbone", "detector", "rescore", "tracker", "short_match",
+                             "long_match", "post_process", "total_time")}
+
+
+def test_backbone_vs_oracle():
+    from gomatching_amd.weights import synth_state_dict
+    from gomatching_amd.modeling import ResNet50
+    from gomatching_amd import ops
+    from oracle import gom_oracle as O
+    cfg = mini_cfg()
+    sd = synth_state_dict(cfg, seed=7)
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(2, 3, 96, 128, generator=g) * 255
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(cfg.MODEL.PIXEL_STD).view(1, 3, 1, 1)
+    with torch.no_grad():
+        ref = O.resnet50((img - mean) / std, sd)
+    net = ResNet50(sd, DEV)
+    out = net.forward(ops.preprocess(img.to(DEV), cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD))
+    for k in ("res3", "res4", "res5"):
+        scale = float(ref[k].abs().max())
+        _close(out[k].permute(0, 3, 1, 2), ref[k], 2e-5 * max(scale, 1.0), k)
+
+
+@pytest.mark.parametrize("builtin,tag,voc", [("icdar15", "ic15", None), ("bovtext", "voc96", 96)])
+def test_deepsolo_mini_golden(builtin, tag, voc):
+    """DeepSolo-without-backbone against the reference's own outputs (mini geometry, B=2)."""
+    from gomatching_amd.weights import synth_state_dict
+    from gomatching_amd.modeling import DeepSolo
+    g = golden("deepsolo_%s.npz" % tag)
+    cfg = mini_cfg(builtin, voc=voc)
+    sd = synth_state_dict(cfg, seed=7)
+    net = DeepSolo(cfg, sd, DEV)
+    feats = [t(g["feat%d" % i]).permute(0, 2, 3, 1).contiguous().to(DEV) for i in range(3)]
+    taps = {}
+    out = net.forward(feats, taps=taps)
+    B, nq, P = 2, cfg.MODEL.TRANSFORMER.NUM_QUERIES, 25
+    _close(taps["memory"].view(B, -1, 256), g["tap_memory"], 1e-4, "memory")
+    assert torch.equal(taps["topk"].cpu().long(), t(g["tap_topk"])), "top-k proposals differ"
+    _close(taps["init_ref"].view(B, nq, P, 2), g["tap_init_ref"], 1e-5, "init_ref")
+    for k, shape in (("pred_logits", (B, nq, P, 1)), ("pred_text_logits", (B, nq, P, -1)),
+                     ("pred_ctrl_points", (B, nq, P, 2)), ("pred_bd_points", (B, nq, P, 4)),
+                     ("query_features", (B, nq, P, 256))):
+        _close(out[k].view(*shape), g[k], 2e-4, k)
+
+
+@pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
+def test_matcher_heads_golden(builtin, tag):
+    from gomatching_amd.weights import synth_state_dict
+    from gomatching_amd.modeling import build_roi_heads
+    g = golden("matcher_%s.npz" % tag)
+    cfg = mini_cfg(builtin)
+    sd = synth_state_dict(cfg, seed=7)
+    rh = build_roi_heads(cfg, sd, DEV)
+    for n in (1, 7, 20):
+        x = t(g["fc_in_%d" % n]).reshape(n, -1).to(DEV)
+        rows = torch.arange(n, dtype=torch.int32, device=DEV)
+        _close(rh.asso_head(x, rows), g["fc_out_%d" % n], 1e-4, "fchead")
+    for ci in range(5):
+        n_t = [int(v) for v in g["asso%d_nt" % ci]]
+        k, short = int(g["asso%d_k" % ci][0]), bool(g["asso%d_k" % ci][1])
+        if n_t[k] == 0:
+            continue
+        reid = t(g["asso%d_reid" % ci]).to(DEV)
+        logits = rh._forward_transformer(reid, n_t, k, short_term=short)
+        _close(logits, g["asso%d_logits" % ci], 2e-3, "asso logits")
+        _close(rh._activate_asso(logits, n_t), g["asso%d_out" % ci], 1e-4, "asso act")
+
+
+@pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
+def test_tracker_trace_golden(builtin, tag):
+    """The reference's 16-frame id trace (empty frame, births, drop-outs, long-term re-association)."""
+    from gomatching_amd.weights import synth_state_dict
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.structures import Instances, Boxes
+    g = golden("tracker_%s.npz" % tag)
+    cfg = mini_cfg(builtin, device=DEV)
+    sd = synth_state_dict(cfg, seed=7)
+    model = GoMatching(cfg, sd, device=DEV)
+    size = tuple(int(v) for v in g["image_size"])
+    frames = int(g["num_frames"][0])
+    dets = []
+    for f in range(frames):
+        inst = Instances(size)
+        inst.reid_features = t(g["reid_%d" % f]).to(DEV)
+        inst.pred_boxes = Boxes(t(g["boxes_%d" % f]).to(DEV))
+        dets.append(inst)
+    it = iter(dets)
+    model.inference = lambda batched_inputs, time_cost: [next(it) for _ in batched_inputs]
+    insts, id_count = model.batch_inference([{} for _ in range(frames)], 0, 0, [], _time_cost())
+    assert int(id_count) == int(g["id_count"][0])
+    for f in range(frames):
+        assert insts[f].track_ids.cpu().tolist() == g["ids_%d" % f].tolist(), f
+    kept = model._remove_short_track(insts)
+    for f in range(frames):
+        assert kept[f].track_ids.cpu().tolist() == g["kept_ids_%d" % f].tolist(), f
+
+
+@pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
+@pytest.mark.parametrize("step", [8, 3])
+def test_end_to_end_clip_golden(builtin, tag, step):
+    """Whole path on the 8-frame mini clip against the reference's outputs: identical ids and characters,
+    points within 1e-3 px."""
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.synth import make_clip
+    g = golden("e2e_%s.npz" % tag)
+    cfg = mini_cfg(builtin, device=DEV)
+    sd = e2e_state_dict(cfg, g)
+    hw = tuple(int(v) for v in g["hw"])
+    frames = int(g["num_frames"][0])
+    clip = make_clip(frames, hw[0], hw[1], clip_id=1)
+    inputs = [{"image": torch.as_tensor(f.astype("float32").transpose(2, 0, 1)), "height": hw[0], "width": hw[1]}
+              for f in clip]
+    model = GoMatching(cfg, sd, device=DEV, frames_per_step=step)
+    insts, id_count = model.batch_inference(inputs, 0, 0, [], _time_cost())
+    for f in range(frames):
+        assert insts[f].track_ids.cpu().tolist() == g["pre_ids_%d" % f].tolist(), ("pre ids", f)
+        _close(insts[f].scores, g["pre_scores_%d" % f], 1e-4, "pre scores")
+        _close(insts[f].pred_boxes.tensor, g["pre_boxes_%d" % f], 1e-3, "pre boxes")
+    assert int(id_count) == int(g["id_count"][0])
+    insts = model._remove_short_track(insts)
+    res = model.batch_postprocess(insts, [hw] * len(insts))
+    for f in range(frames):
+        r = res[f]["instances"]
+        assert r.track_ids.cpu().tolist() == g["track_ids_%d" % f].tolist()
+        assert r.recs.cpu().tolist() == g["recs_%d" % f].tolist()
+        _close(r.scores, g["scores_%d" % f], 1e-4, "scores")
+        _close(r.bd, g["bd_%d" % f], 1e-3, "bd")
+        _close(r.ctrl_points, g["ctrl_points_%d" % f], 1e-3, "ctrl")
+        _close(r.pred_boxes.tensor, g["pred_boxes_%d" % f], 1e-3, "boxes")
+
+
+def test_batch_invariance_and_determinism():
+    """Size-independent properties at a larger geometry: a frame's detections do not depend on what shares its
+    step, and the path is run-to-run deterministic."""
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.synth import make_clip
+    from gomatching_amd.weights import synth_state_dict
+    cfg = mini_cfg("icdar15", nq=100, device=DEV)
+    sd = synth_state_dict(cfg, seed=3, cls_bias={"detection_transformer.ctrl_point_class.0.bias": 0.0})
+    clip = make_clip(3, 320, 480, clip_id=5)
+    inputs = [{"image": torch.as_tensor(f.astype("float32").transpose(2, 0, 1))} for f in clip]
+    model = GoMatching(cfg, sd, device=DEV)
+    a = model.inference(inputs, _time_cost())
+    b = model.inference(inputs[1:2], _time_cost())
+    c = model.inference(inputs, _time_cost())
+    assert len(a[1]) == len(b[0]) and len(a[1]) > 0
+    assert torch.equal(a[1].scores, b[0].scores) and torch.equal(a[1].bd, b[0].bd)
+    assert torch.equal(a[1].reid_features, b[0].reid_features)
+    for x, y in zip(a, c):
+        assert torch.equal(x.scores, y.scores) and torch.equal(x.recs, y.recs) and torch.equal(x.bd, y.bd)
