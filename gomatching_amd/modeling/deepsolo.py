@@ -38,10 +38,10 @@ class DeepSolo:
         T = cfg.MODEL.TRANSFORMER
         self.cfg, self.device = cfg, device
         self.d, self.nq, self.P = T.HIDDEN_DIM, T.NUM_QUERIES, T.NUM_POINTS
-        self.heads, self.L = T.NHEADS, T.NUM_FEATURE_LEVELS
+        self.nheads, self.L = T.NHEADS, T.NUM_FEATURE_LEVELS
         self.n_enc, self.n_dec = T.ENC_LAYERS, T.DEC_LAYERS
         self.voc = T.VOC_SIZE
-        assert self.d == 256 and self.heads == 8 and self.L == 4 and T.ENC_N_POINTS == 4 and T.DEC_N_POINTS == 4, \
+        assert self.d == 256 and self.nheads == 8 and self.L == 4 and T.ENC_N_POINTS == 4 and T.DEC_N_POINTS == 4, \
             "kernels are specialised for d_model 256 / 8 heads / 4 levels / 4 points (every shipped config)"
         assert T.BOUNDARY_HEAD
         g = lambda k: _dev(sd[prefix + k], device)
