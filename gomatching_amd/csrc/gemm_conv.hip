@@ -271,6 +271,10 @@ extern "C" int gom_conv2d_nhwc_f32(const float* X, const float* Wt, const float*
     a.H = H; a.Wd = Wd; a.cin_log2 = lg; a.OH = OH; a.OW = OW; a.stride = stride; a.pad = pad;
     GOM_CHECK_ARG((long)a.M * Cout < (1L << 31));
     hipStream_t s = (hipStream_t)stream;
+    if (KH == 1 && stride == 1 && pad == 0) {                // pointwise conv on channels-last = plain GEMM over pixels
+        a.H = a.Wd = a.OH = a.OW = 0;
+        return dispatch_tile<0, 0>(a, s);
+    }
     if (KH == 1) return dispatch_tile<1, 1>(a, s);
     if (KH == 3) return dispatch_tile<3, 3>(a, s);
     return dispatch_tile<7, 7>(a, s);

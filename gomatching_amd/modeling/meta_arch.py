@@ -289,9 +289,12 @@ class GoMatching:
     def batch_inference(self, batched_inputs, batch_id, id_count, instances, time_cost):
         """gom_lstmatcher.py:366-403: detection runs per step of `frames_per_step` frames, the id recurrence
         stays strictly per frame."""
-        video_len = len(batched_inputs)
-        start_frame_id = batch_id * 100
-        # keep the carried-over window's embeddings addressable, drop everything older
+        self.begin_batch(instances, len(batched_inputs))
+        dets = self.detect_steps(batched_inputs, time_cost)
+        return self.track_frames(dets, batch_id, id_count, instances, time_cost)
+
+    def begin_batch(self, instances, num_new_frames):
+        """Keep the carried-over window's embeddings addressable, drop everything older, size the pool."""
         carried = [x for x in instances[-self.test_len:] if x.has("reid_features")]
         saved = [x.reid_features.clone() for x in carried]      # may alias the pool that is about to be reused
         self._pool_used = 0
@@ -299,11 +302,18 @@ class GoMatching:
             self._host(x)["row0"] = None
             x._fields["reid_features"] = f
             self._reid_rows(x, np.ones((len(x),), bool))
-        self._ensure_pool(video_len * self.cfg.MODEL.TRANSFORMER.NUM_QUERIES)   # no re-allocation mid-batch
+        self._ensure_pool(num_new_frames * self.cfg.MODEL.TRANSFORMER.NUM_QUERIES)   # no re-allocation mid-batch
+
+    def detect_steps(self, batched_inputs, time_cost):
         dets = []
-        for s0 in range(0, video_len, self.frames_per_step):
+        for s0 in range(0, len(batched_inputs), self.frames_per_step):
             dets.extend(self.inference(batched_inputs[s0:s0 + self.frames_per_step], time_cost))
-        for frame_id in range(video_len):
+        return dets
+
+    def track_frames(self, dets, batch_id, id_count, instances, time_cost):
+        """The per-frame id recurrence of gom_lstmatcher.py:369-403 over already detected frames."""
+        start_frame_id = batch_id * 100
+        for frame_id in range(len(dets)):
             instances.append(dets[frame_id])
             real_frame_id = start_frame_id + frame_id
             if real_frame_id == 0:

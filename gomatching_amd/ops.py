@@ -18,6 +18,16 @@ def _L():
     return _lib_mod.load()
 
 
+# Optional launch profiler for bench.py's roofline leg: a list that receives (start_event, end_event, flops) for
+# every launch of the dominant kernel (the 128x128-tile plain GEMM).  None = no events recorded.
+_gemm_profile = None
+
+
+def set_gemm_profile(collector):
+    global _gemm_profile
+    _gemm_profile = collector
+
+
 def _p(t):
     if t is None:
         return None
@@ -64,8 +74,15 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
         ldr = R.stride(0) if R.shape[0] > 1 else N
     if rows is not None:
         assert rows.dtype == torch.int32 and rows.is_contiguous()
+    prof = _gemm_profile if (_gemm_profile is not None and N > 64 and M > 0) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_L().gom_gemm_f32(_p(A), _p(A2), _p(rows), lda, _p(W), ldw, _p(scale), _p(bias), _p(R), ldr,
                             1 if relu else 0, _p(out), ldc, M, N, K, _stream()), "gom_gemm_f32")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K))
     return out
 
 

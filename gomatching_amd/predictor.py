@@ -1,0 +1,125 @@
+"""Harness-side counterpart of `GoMBatchPredictor.__call__`
+(/root/reference/gomatching/text_track_visualizer.py:295-335): colour-order flip, shortest-edge resize,
+float32 CHW conversion, the timing window, short-track removal and rescaling on the last batch; plus the
+CTC-style transcription decode (`_ctc_decode_recognition`, :167-182) and boundary->polygon conversion
+(`pre_vis_process`, :76-91) that eval.py applies to the returned Instances.
+
+The resize follows Detectron2 `ResizeShortestEdge` semantics (mirrored in the reference at
+gom_lstmatcher.py:82-96): scale the short side to MIN_SIZE_TEST, cap the long side at MAX_SIZE_TEST,
+round with int(x + 0.5), PIL bilinear on uint8.  It runs on the host, outside the timing window, exactly
+as in the reference.
+"""
+import pickle
+import time
+
+import numpy as np
+import torch
+
+CTLABELS_37 = list("abcdefghijklmnopqrstuvwxyz0123456789")
+CTLABELS_96 = [chr(c) for c in range(32, 127)]
+
+
+def resized_shape(h, w, min_size, max_size):
+    scale = min_size * 1.0 / min(h, w)
+    if h < w:
+        newh, neww = min_size, scale * w
+    else:
+        newh, neww = scale * h, min_size
+    if max(newh, neww) > max_size:
+        s = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * s, neww * s
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+def resize_shortest_edge(img, min_size, max_size):
+    """img: HxWx3 uint8 -> resized uint8 (PIL bilinear, as Detectron2's ResizeTransform.apply_image)."""
+    from PIL import Image
+    h, w = img.shape[:2]
+    nh, nw = resized_shape(h, w, min_size, max_size)
+    if (nh, nw) == (h, w):
+        return img
+    return np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+
+
+def new_time_cost(sync=False):
+    tc = {k: 0.0 for k in ("pre_process", "backbone", "detector", "rescore", "tracker", "short_match",
+                           "long_match", "post_process", "total_time")}
+    if sync:
+        tc["_sync"] = True
+    return tc
+
+
+class GoMBatchPredictor:
+    def __init__(self, cfg, model):
+        self.cfg = cfg
+        self.model = model
+        self.input_format = cfg.INPUT.FORMAT
+        self.min_size, self.max_size = cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST
+
+    def prepare(self, original_frames):
+        """Host-side, untimed part of __call__ (:315-324): returns (inputs, (height, width))."""
+        if self.input_format == "RGB":
+            original_frames = [x[:, :, ::-1] for x in original_frames]
+        height, width = original_frames[0].shape[:2]
+        frames = [resize_shortest_edge(np.ascontiguousarray(x), self.min_size, self.max_size)
+                  for x in original_frames]
+        frames = [torch.as_tensor(x.astype("float32").transpose(2, 0, 1)) for x in frames]
+        inputs = [{"image": x, "height": height, "width": width, "video_id": 0} for x in frames]
+        return inputs, (height, width)
+
+    @torch.no_grad()
+    def __call__(self, original_frames, instances, batch_id, id_count, last_batch, time_cost, return_time=False):
+        inputs, (height, width) = self.prepare(original_frames)
+        return self.run_prepared(inputs, (height, width), instances, batch_id, id_count, last_batch, time_cost,
+                                 return_time)
+
+    @torch.no_grad()
+    def run_prepared(self, inputs, hw, instances, batch_id, id_count, last_batch, time_cost, return_time=False):
+        """The timed window of the reference (:325-334)."""
+        start_time = time.time()
+        instances, id_count = self.model.batch_inference(inputs, batch_id, id_count, instances, time_cost)
+        if last_batch:
+            start = time.time()
+            if self.model.min_track_len > 0:
+                instances = self.model._remove_short_track(instances)
+            instances = self.model.batch_postprocess(instances, [hw for _ in range(len(instances))])
+            time_cost["post_process"] += time.time() - start
+        if return_time:
+            return instances, id_count, time.time() - start_time
+        return instances, id_count
+
+
+class TextDecoder:
+    """Character tables + `_ctc_decode_recognition` of the reference visualizer (:40-55,167-182)."""
+
+    def __init__(self, voc_size, custom_dict=""):
+        self.voc_size = voc_size
+        if voc_size == 96:
+            self.labels = CTLABELS_96
+        elif voc_size == 37:
+            self.labels = CTLABELS_37
+        else:
+            with open(custom_dict, "rb") as fp:
+                self.labels = pickle.load(fp)
+        assert int(voc_size - 1) == len(self.labels), \
+            "voc_size is not matched dictionary size, got {} and {}.".format(int(voc_size - 1), len(self.labels))
+
+    def decode(self, rec):
+        last_char = "###"
+        s = ""
+        for c in rec:
+            c = int(c)
+            if c < self.voc_size - 1:
+                if last_char != c:
+                    s += self.labels[c] if self.voc_size in (37, 96) else str(chr(self.labels[c]))
+                    last_char = c
+            else:
+                last_char = "###"
+        return s
+
+
+def boundary_to_polygon(bd):
+    """`pre_vis_process` polygon construction (:82-85): bd [25,4] (top xy | bottom xy) -> [50,2] closed outline."""
+    bd = np.asarray(bd)
+    top, bottom = np.hsplit(bd, 2)
+    return np.vstack([top, bottom[::-1]])
