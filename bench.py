@@ -58,11 +58,12 @@ def calibrate(model, inputs, frac=0.3):
     return shift, re_shift
 
 
-def cpu_baseline(cfg, sd, shift, re_shift, frame_chw):
-    """The CPU oracle ("port") timed on the host cores, on a bounded sample: ONE 1000x1778 frame through the
-    whole path (detector + embedding + first-frame id init)."""
+def cpu_baseline(cfg, sd, shift, re_shift, frame_chw, gpu_frame0):
+    """The CPU oracle ("port") timed on the host cores, on a bounded sample: ONE 1000x1778 frame through
+    detection + embedding + id initialisation (short-track removal is skipped: it would delete every track of a
+    1-frame sample).  The same run doubles as a full-size parity check of frame 0 against the HIP path."""
     from oracle import gom_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)                    # torch's CPU kernels stop scaling (and thrash) beyond this
     torch.set_num_threads(cores)
     sd = dict(sd)
     k = "detection_transformer.ctrl_point_class.0.bias"
@@ -70,11 +71,23 @@ def cpu_baseline(cfg, sd, shift, re_shift, frame_chw):
     if re_shift is not None:
         sd["roi_heads.rescoring_head.bias"] = sd["roi_heads.rescoring_head.bias"] + re_shift
     t0 = time.time()
-    res, _ = O.run_clip(sd, cfg, [frame_chw])
+    with torch.no_grad():
+        dets = O.detect_frames(sd, cfg, [frame_chw])
+        O.track_clip(sd, cfg, dets)
     dt = time.time() - t0
+    ref = dets[0]
+    n = len(ref)
+    parity = {"detections_cpu": n, "detections_gpu": len(gpu_frame0)}
+    if n == len(gpu_frame0) and n > 0:
+        parity["max_abs_score"] = float((gpu_frame0.scores.cpu() - ref["scores"]).abs().max())
+        parity["max_abs_bd_px"] = float((gpu_frame0.bd.cpu() - ref["bd"]).abs().max())
+        parity["max_abs_ctrl_px"] = float((gpu_frame0.ctrl_points.cpu() - ref["ctrl_points"]).abs().max())
+        parity["recs_identical"] = bool(torch.equal(gpu_frame0.recs.cpu(), ref["recs"]))
+        parity["max_abs_reid"] = float((gpu_frame0.reid_features.cpu() - ref["reid_features"]).abs().max())
     return {"value": 1.0 / dt, "unit": "frames/sec", "cores": cores, "kind": "port",
-            "sample": "1 frame 1280x720->1000x1778 through oracle/gom_oracle.py run_clip (%.1f s, %d detections)" % (
-                dt, len(res[0]["instances"]))}
+            "sample": "1 frame 1280x720->1000x1778 through oracle/gom_oracle.py detect_frames+track_clip "
+                      "(%.1f s of CPU work on %d threads)" % (dt, cores),
+            "full_size_parity_frame0": parity}
 
 
 def main():
@@ -174,7 +187,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_cfg = setup_cfg(builtin="icdar15")
         cpu_cfg.MODEL.DEVICE = "cpu"
-        line["cpu_baseline"] = cpu_baseline(cpu_cfg, sd, shift, re_shift, inputs[0]["image"].cpu())
+        gpu0 = model.inference(inputs[:1], new_time_cost())[0]
+        line["cpu_baseline"] = cpu_baseline(cpu_cfg, sd, shift, re_shift, inputs[0]["image"].cpu(), gpu0)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

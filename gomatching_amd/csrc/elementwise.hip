@@ -180,6 +180,12 @@ __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict
     *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(src + (i % n4) * 4);
 }
 
+__global__ __launch_bounds__(256) void bcast_rows_scalar_kernel(const float* __restrict__ src, float* __restrict__ out,
+                                                                long n, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = src[i % n];
+}
+
 // detector_postprocess (gom_lstmatcher.py:100-109): x[2i] *= sx, x[2i+1] *= sy in place
 __global__ __launch_bounds__(256) void scale_xy_kernel(float* __restrict__ x, long n_pairs, float sx, float sy) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -268,8 +274,11 @@ extern "C" int gom_add_f32(const float* a, const float* b, float* out, long n, v
 }
 
 extern "C" int gom_broadcast_rows_f32(const float* src, float* out, long n, int B, void* stream) {
-    GOM_CHECK_ARG(src && out && n > 0 && (n % 4) == 0 && B > 0);
-    hipLaunchKernelGGL(bcast_rows_kernel, GOM_GRID(n / 4 * B), src, out, n / 4, n / 4 * B);
+    GOM_CHECK_ARG(src && out && n > 0 && B > 0);
+    if (n % 4)
+        hipLaunchKernelGGL(bcast_rows_scalar_kernel, GOM_GRID(n * B), src, out, n, n * B);
+    else
+        hipLaunchKernelGGL(bcast_rows_kernel, GOM_GRID(n / 4 * B), src, out, n / 4, n / 4 * B);
     return gom_launch_status();
 }
 

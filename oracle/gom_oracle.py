@@ -152,8 +152,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     B, S, M, D = value.shape
     _, Lq, _, L, P, _ = sampling_loc.shape
     out = value.new_zeros((B, Lq, M, D))
-    bidx = torch.arange(B).view(B, 1, 1, 1)
-    midx = torch.arange(M).view(1, 1, M, 1)
+    vflat = value.reshape(B * S * M, D)
+    bm = (torch.arange(B).view(B, 1, 1, 1) * S) * M + torch.arange(M).view(1, 1, M, 1)   # row of (b, s=0, m)
     for l in range(L):
         H, W = int(spatial_shapes[l, 0]), int(spatial_shapes[l, 1])
         start = int(level_start_index[l])
@@ -171,7 +171,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
             yy, xx = h_low + dy, w_low + dx
             ok = inside & (yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1)
             idx = start + yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)
-            v = value[bidx, idx, midx]                          # B,Lq,M,P,D
+            v = vflat.index_select(0, (idx * M + bm).reshape(-1)).view(B, Lq, M, P, D)
             acc = acc + v * (wt * ok.to(value.dtype))[..., None]
         out = out + (acc * attn_weight[:, :, :, l, :, None]).sum(3)
     return out.reshape(B, Lq, M * D)
