@@ -37,7 +37,7 @@ class ResNet50:
         self.convs = {}
 
         def add(name, pad_cin_to=None):
-            w = _ohwi(sd[prefix + name + ".weight"], device, pad_cin_to)
+            w = ops.prep_conv_weight(_ohwi(sd[prefix + name + ".weight"], device, pad_cin_to))
             sc, sh = _fold_bn(sd, prefix + name, device)
             self.convs[name] = (w, sc, sh)
 

@@ -47,18 +47,21 @@ class DeepSolo:
         g = lambda k: _dev(sd[prefix + k], device)
         self.proj = []
         for l in range(3):
-            self.proj.append((g("input_proj.%d.0.weight" % l).reshape(self.d, -1).contiguous(),
+            self.proj.append((ops.prep_weight(g("input_proj.%d.0.weight" % l).reshape(self.d, -1).contiguous()),
                               g("input_proj.%d.0.bias" % l), g("input_proj.%d.1.weight" % l),
                               g("input_proj.%d.1.bias" % l)))
-        self.proj3 = (_dev(sd[prefix + "input_proj.3.0.weight"].permute(0, 2, 3, 1), device),
+        self.proj3 = (ops.prep_conv_weight(_dev(sd[prefix + "input_proj.3.0.weight"].permute(0, 2, 3, 1), device)),
                       g("input_proj.3.0.bias"), g("input_proj.3.1.weight"), g("input_proj.3.1.bias"))
         self.point_embed = g("point_embed.weight")                           # [nq*P, 256]
         t = "transformer."
         self.level_embed = g(t + "level_embed")
-        self.enc_output = (g(t + "enc_output.weight"), g(t + "enc_output.bias"))
+        self.enc_output = (ops.prep_weight(g(t + "enc_output.weight")), g(t + "enc_output.bias"))
         self.enc_output_norm = (g(t + "enc_output_norm.weight"), g(t + "enc_output_norm.bias"))
 
-        def lin(name):
+        def lin(name):                                       # nn.Linear: weight goes through the GEMM weight policy
+            return ops.prep_weight(g(name + ".weight")), g(name + ".bias")
+
+        def norm(name):                                      # LayerNorm gain / bias stay plain fp32 vectors
             return g(name + ".weight"), g(name + ".bias")
 
         def msda(name):
@@ -66,27 +69,28 @@ class DeepSolo:
                            sd[prefix + name + ".attention_weights.weight"]], 0)
             b = torch.cat([sd[prefix + name + ".sampling_offsets.bias"],
                            sd[prefix + name + ".attention_weights.bias"]], 0)
-            return {"raw": (_dev(w, device), _dev(b, device)), "value": lin(name + ".value_proj"),
+            return {"raw": (ops.prep_weight(_dev(w, device)), _dev(b, device)), "value": lin(name + ".value_proj"),
                     "out": lin(name + ".output_proj")}
 
         self.enc = []
         for i in range(self.n_enc):
             p = t + "encoder.layers.%d." % i
-            self.enc.append({"attn": msda(p + "self_attn"), "norm1": lin(p + "norm1"), "lin1": lin(p + "linear1"),
-                             "lin2": lin(p + "linear2"), "norm2": lin(p + "norm2")})
+            self.enc.append({"attn": msda(p + "self_attn"), "norm1": norm(p + "norm1"), "lin1": lin(p + "linear1"),
+                             "lin2": lin(p + "linear2"), "norm2": norm(p + "norm2")})
         self.dec = []
         for i in range(self.n_dec):
             p = t + "decoder.layers.%d." % i
             self.dec.append({
-                "intra_in": (g(p + "attn_intra.in_proj_weight"), g(p + "attn_intra.in_proj_bias")),
-                "intra_out": lin(p + "attn_intra.out_proj"), "norm_intra": lin(p + "norm_intra"),
-                "inter_in": (g(p + "attn_inter.in_proj_weight"), g(p + "attn_inter.in_proj_bias")),
-                "inter_out": lin(p + "attn_inter.out_proj"), "norm_inter": lin(p + "norm_inter"),
-                "cross": msda(p + "attn_cross"), "norm_cross": lin(p + "norm_cross"),
-                "lin1": lin(p + "linear1"), "lin2": lin(p + "linear2"), "norm3": lin(p + "norm3")})
+                "intra_in": (ops.prep_weight(g(p + "attn_intra.in_proj_weight")), g(p + "attn_intra.in_proj_bias")),
+                "intra_out": lin(p + "attn_intra.out_proj"), "norm_intra": norm(p + "norm_intra"),
+                "inter_in": (ops.prep_weight(g(p + "attn_inter.in_proj_weight")), g(p + "attn_inter.in_proj_bias")),
+                "inter_out": lin(p + "attn_inter.out_proj"), "norm_inter": norm(p + "norm_inter"),
+                "cross": msda(p + "attn_cross"), "norm_cross": norm(p + "norm_cross"),
+                "lin1": lin(p + "linear1"), "lin2": lin(p + "linear2"), "norm3": norm(p + "norm3")})
         # all six cross-attention value projections as one [6*256, 256] weight
-        self.dec_value_w = torch.cat([L["cross"]["value"][0] for L in self.dec], 0).contiguous()
-        self.dec_value_b = torch.cat([L["cross"]["value"][1] for L in self.dec], 0).contiguous()
+        vp = [t + "decoder.layers.%d.attn_cross.value_proj" % i for i in range(self.n_dec)]
+        self.dec_value_w = ops.prep_weight(torch.cat([g(n + ".weight") for n in vp], 0).contiguous())
+        self.dec_value_b = torch.cat([g(n + ".bias") for n in vp], 0).contiguous()
         self.ref_point_head = [lin(t + "decoder.ref_point_head.layers.%d" % i) for i in range(2)]
         self.bezier_coord = [lin("bezier_proposal_coord.layers.%d" % i) for i in range(3)]
         self.bezier_class = lin("bezier_proposal_class")

@@ -52,9 +52,83 @@ def empty(shape, like=None, dtype=_f32, device=None):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+# "bf16x6": weights of the big contractions are pre-split into three bf16 planes and multiplied on the bf16
+# matrix cores with fp32-level accuracy (csrc/gemm_bf16x6.hip); "fp32": exact-fp32 MFMA everywhere.
+GEMM_MODE = "bf16x6"
+
+
+class SplitWeight:
+    """[3, N, Kpad] bf16 planes of an fp32 weight [N, K] (row slices keep the plane stride)."""
+
+    def __init__(self, planes, N, K, conv_shape=None):
+        self.planes, self.N, self.K, self.conv_shape = planes, N, K, conv_shape
+
+    @property
+    def shape(self):
+        return (self.N, self.K)
+
+    def __getitem__(self, sl):
+        assert isinstance(sl, slice) and sl.step in (None, 1)
+        a, b, _ = sl.indices(self.N)
+        return SplitWeight(self.planes[:, a:b], b - a, self.K)
+
+
+def split_weight(w, conv_shape=None):
+    """w: fp32 [N, K] (contiguous) on the GPU -> SplitWeight."""
+    _chk_f32(w)
+    N, K = w.shape
+    Kpad = (K + 31) // 32 * 32
+    planes = torch.empty((3, N, Kpad), dtype=torch.bfloat16, device=w.device)
+    check(_L().gom_split_bf16x3(_p(w), K, N, K, _p(planes), Kpad, _stream()), "gom_split_bf16x3")
+    return SplitWeight(planes, N, K, conv_shape)
+
+
+def prep_weight(w, min_n=33):
+    """Weight preparation policy for the detector's nn.Linear weights."""
+    if GEMM_MODE == "bf16x6" and w.shape[0] >= min_n:
+        return split_weight(w.contiguous())
+    return w
+
+
+def prep_conv_weight(w_ohwi):
+    if GEMM_MODE == "bf16x6" and w_ohwi.shape[0] >= 33:
+        Cout = w_ohwi.shape[0]
+        return split_weight(w_ohwi.reshape(Cout, -1).contiguous(), conv_shape=tuple(w_ohwi.shape))
+    return w_ohwi
+
+
+def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M):
+    K, N = A.shape[1], W.N
+    assert W.K == K
+    lda = A.stride(0) if A.shape[0] > 1 else K
+    if out is None:
+        out = torch.empty((M, N), dtype=_f32, device=A.device)
+    ldc = out.stride(0) if out.shape[0] > 1 else N
+    ldr = (R.stride(0) if R.shape[0] > 1 else N) if R is not None else 0
+    pl = W.planes
+    prof = _gemm_profile if (_gemm_profile is not None and M > 0) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().gom_gemm_f32_bf16x6(_p(A), _p(A2), _p(rows), lda, _p(pl), pl.stride(0), pl.stride(1), _p(scale),
+                                   _p(bias), _p(R), ldr, 1 if relu else 0, _p(out), ldc, M, N, K, _stream()),
+          "gom_gemm_f32_bf16x6")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K))
+    return out
+
+
 def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, out=None, M=None):
     """C = act((A[+A2])[M,K] @ W[N,K]^T * scale + bias + R).  A may be a 2-D row-strided view
     (stride(1) == 1); W likewise (row slices of a weight matrix)."""
+    if isinstance(W, SplitWeight):
+        assert A.dim() == 2 and A.stride(1) == 1
+        if M is None:
+            M = A.shape[0] if rows is None else rows.numel()
+        if A2 is not None:
+            assert A2.shape == A.shape and A2.stride() == A.stride()
+        return _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M)
     assert A.dim() == 2 and W.dim() == 2 and A.stride(1) == 1 and W.stride(1) == 1
     K = A.shape[1]
     assert W.shape[1] == K
@@ -74,7 +148,7 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
         ldr = R.stride(0) if R.shape[0] > 1 else N
     if rows is not None:
         assert rows.dtype == torch.int32 and rows.is_contiguous()
-    prof = _gemm_profile if (_gemm_profile is not None and N > 64 and M > 0) else None
+    prof = _gemm_profile if (_gemm_profile is not None and N > 64 and M > 0 and GEMM_MODE == "fp32") else None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -87,16 +161,23 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
 
 
 def conv2d_nhwc(x, w_ohwi, scale=None, shift=None, R=None, relu=False, stride=1, pad=0):
-    """x [B,H,W,Cin] -> [B,OH,OW,Cout]; w [Cout,KH,KW,Cin]."""
-    _chk_f32(x, w_ohwi, scale, shift, R)
+    """x [B,H,W,Cin] -> [B,OH,OW,Cout]; w [Cout,KH,KW,Cin] fp32, or a SplitWeight made by prep_conv_weight."""
+    split = isinstance(w_ohwi, SplitWeight)
+    _chk_f32(x, None if split else w_ohwi, scale, shift, R)
     B, H, Wd, Cin = x.shape
-    Cout, KH, KW, Cin2 = w_ohwi.shape
+    Cout, KH, KW, Cin2 = w_ohwi.conv_shape if split else w_ohwi.shape
     assert Cin == Cin2
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (Wd + 2 * pad - KW) // stride + 1
     y = torch.empty((B, OH, OW, Cout), dtype=_f32, device=x.device)
     if R is not None:
         assert R.shape == y.shape
+    if split:
+        pl = w_ohwi.planes
+        check(_L().gom_conv2d_nhwc_f32_bf16x6(_p(x), _p(pl), pl.stride(0), pl.stride(1), _p(scale), _p(shift), _p(R),
+                                              1 if relu else 0, _p(y), B, H, Wd, Cin, Cout, KH, KW, stride, pad,
+                                              _stream()), "gom_conv2d_nhwc_f32_bf16x6")
+        return y
     check(_L().gom_conv2d_nhwc_f32(_p(x), _p(w_ohwi), _p(scale), _p(shift), _p(R), 1 if relu else 0, _p(y), B, H, Wd,
                                    Cin, Cout, KH, KW, stride, pad, _stream()), "gom_conv2d_nhwc_f32")
     return y

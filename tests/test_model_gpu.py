@@ -10,6 +10,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(params=["bf16x6", "fp32"])
+def gemm_mode(request):
+    """Both contraction back-ends: split-bf16 (default) and exact-fp32 MFMA, held to the same tolerances."""
+    from gomatching_amd import ops
+    old = ops.GEMM_MODE
+    ops.GEMM_MODE = request.param
+    yield request.param
+    ops.GEMM_MODE = old
+
+
 def _close(a, b, atol, msg=""):
     a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
     assert a.shape == b.shape, (msg, a.shape, b.shape)
@@ -22,7 +32,7 @@ def _time_cost():
                              "long_match", "post_process", "total_time")}
 
 
-def test_backbone_vs_oracle():
+def test_backbone_vs_oracle(gemm_mode):
     from gomatching_amd.weights import synth_state_dict
     from gomatching_amd.modeling import ResNet50
     from gomatching_amd import ops
@@ -43,7 +53,7 @@ def test_backbone_vs_oracle():
 
 
 @pytest.mark.parametrize("builtin,tag,voc", [("icdar15", "ic15", None), ("bovtext", "voc96", 96)])
-def test_deepsolo_mini_golden(builtin, tag, voc):
+def test_deepsolo_mini_golden(builtin, tag, voc, gemm_mode):
     """DeepSolo-without-backbone against the reference's own outputs (mini geometry, B=2)."""
     from gomatching_amd.weights import synth_state_dict
     from gomatching_amd.modeling import DeepSolo
@@ -118,7 +128,7 @@ def test_tracker_trace_golden(builtin, tag):
 
 @pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
 @pytest.mark.parametrize("step", [8, 3])
-def test_end_to_end_clip_golden(builtin, tag, step):
+def test_end_to_end_clip_golden(builtin, tag, step, gemm_mode):
     """Whole path on the 8-frame mini clip against the reference's outputs: identical ids and characters,
     points within 1e-3 px."""
     from gomatching_amd.modeling import GoMatching

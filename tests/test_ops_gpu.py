@@ -41,6 +41,48 @@ def test_gemm_shapes(M, N, K):
     _close(out, F.linear(A, W, b), 2e-5, 1e-5, "gemm %s" % ((M, N, K),))
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 64, 256), (25, 38, 256), (300, 384, 256), (513, 129, 1024), (100, 1024, 6400),
+                                   (4097, 256, 256), (130, 64, 64), (777, 1536, 256), (64, 100, 36)])
+def test_gemm_bf16x6_shapes(M, N, K):
+    """Split-bf16 path: same tolerance as the exact-fp32 MFMA kernel (reference in float64)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g) * 3
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    sw = ops.split_weight(W.to(DEV))
+    out = ops.gemm(A.to(DEV), sw, bias=b.to(DEV))
+    ref = (A.double() @ W.double().t() + b.double()).float()
+    _close(out, ref, 2e-5, 1e-5, "gemm bf16x6 %s" % ((M, N, K),))
+    if N > 40:                                       # row slices of the planes (in_proj q/k/v style)
+        out2 = ops.gemm(A.to(DEV), sw[8:40], bias=b[8:40].to(DEV))
+        _close(out2, ref[:, 8:40], 2e-5, 1e-5, "sliced planes")
+
+
+def test_gemm_bf16x6_epilogue_gather_and_extremes():
+    ops = _ops()
+    g = torch.Generator().manual_seed(13)
+    M, N, K = 333, 256, 512
+    A, A2 = torch.randn(M, K, generator=g), torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, sc = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
+    R = torch.randn(M, N, generator=g)
+    sw = ops.split_weight(W.to(DEV))
+    out = ops.gemm(A.to(DEV), sw, bias=b.to(DEV), scale=sc.to(DEV), A2=A2.to(DEV), R=R.to(DEV), relu=True)
+    ref = F.relu(((A + A2).double() @ W.double().t()).float() * sc + b + R)
+    _close(out, ref, 3e-5, 1e-5, "epilogue")
+    rows = torch.randint(0, M, (77,), generator=g, dtype=torch.int64)
+    out = ops.gemm(A.to(DEV), sw, bias=b.to(DEV), rows=rows.to(torch.int32).to(DEV))
+    _close(out, (A[rows].double() @ W.double().t()).float() + b, 3e-5, 1e-5, "row gather")
+    # wide dynamic range: tiny and huge magnitudes in one dot product keep fp32-level RELATIVE accuracy
+    A3 = torch.randn(64, K, generator=g) * torch.logspace(-6, 6, K)
+    W3 = torch.randn(128, K, generator=g) * torch.logspace(3, -3, K)
+    out = ops.gemm(A3.to(DEV), ops.split_weight(W3.to(DEV)))
+    ref = A3.double() @ W3.double().t()
+    scale = (A3.double().abs() @ W3.double().abs().t())
+    assert float(((out.cpu().double() - ref).abs() / scale).max()) < 2e-6
+
+
 def test_gemm_epilogue_and_gather():
     ops = _ops()
     g = torch.Generator().manual_seed(3)
@@ -91,10 +133,13 @@ def test_conv_nhwc(Cin, Cout, k, stride, pad, H, W):
     ref = _conv_ref(x, w, stride, pad) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
     R = torch.randn(ref.shape, generator=g)
     ref = F.relu(ref + R)
-    y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV),
-                        scale=sc.to(DEV), shift=sh.to(DEV), R=R.permute(0, 2, 3, 1).contiguous().to(DEV), relu=True,
-                        stride=stride, pad=pad)
+    xd, wd = x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    Rd = R.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = ops.conv2d_nhwc(xd, wd, scale=sc.to(DEV), shift=sh.to(DEV), R=Rd, relu=True, stride=stride, pad=pad)
     _close(y.permute(0, 3, 1, 2), ref, 3e-5, 1e-5, "conv")
+    sw = ops.split_weight(wd.reshape(Cout, -1), conv_shape=tuple(wd.shape))
+    y6 = ops.conv2d_nhwc(xd, sw, scale=sc.to(DEV), shift=sh.to(DEV), R=Rd, relu=True, stride=stride, pad=pad)
+    _close(y6.permute(0, 3, 1, 2), ref, 3e-5, 1e-5, "conv bf16x6")
 
 
 def test_stem_preprocess_pool():
