@@ -40,6 +40,9 @@ struct GemmArgs {
     int relu;
     // convolution geometry (KH > 0)
     int H, Wd, cin_log2, OH, OW, stride, pad;
+    // split-K (skinny problems): blockIdx.y owns k-tiles [y*kt_per_split, ...) and stores raw partial sums
+    int kt_per_split;
+    float* partial;                                          // [splits][M][N] or nullptr
 };
 
 template <int BM, int BN, int WM, int WN, int KH, int KW>
@@ -161,14 +164,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = p.partial ? blockIdx.y * p.kt_per_split : 0;
+    const int nk = p.partial ? min(nk_all, kt0 + p.kt_per_split) : nk_all;
     const int fr = lane & 31, fh = lane >> 5;
 
-    load_tile(0);
-    store_tile(0);
+    load_tile(kt0);
+    store_tile(kt0 & 1);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1);                  // global loads fly under the MFMAs
         const float* a_base = As + (buf * BM + wr * WM + fr) * LDS_STRIDE + fh * 4;
@@ -194,6 +199,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
+    if (p.partial) {                                         // split-K: raw partial sums, epilogue in the reducer
+        float* dst = p.partial + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wc * WN + j * 32 + fr;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (n < p.N && m < p.M) dst[(size_t)m * p.N + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     // ---- epilogue: y = acc*scale + shift (+ residual) (ReLU) ---------------------------------
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -216,6 +236,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
             }
         }
     }
+}
+
+// sums the split-K partials in split order (deterministic) and applies the epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, int splits) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)p.M * p.N) return;
+    const int m = (int)(i / p.N), n = (int)(i % p.N);
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += p.partial[(size_t)s * p.M * p.N + i];
+    const float sh = p.shift ? p.shift[n] : 0.f;
+    if (p.scale) v = v * p.scale[n] + sh; else v = v + sh;
+    if (p.R) v += p.R[(size_t)m * p.ldr + n];
+    if (p.relu) v = fmaxf(v, 0.f);
+    p.C[(size_t)m * p.ldc + n] = v;
 }
 
 template <int BM, int BN, int WM, int WN, int KH, int KW>
@@ -250,6 +284,42 @@ extern "C" int gom_gemm_f32(const float* A, const float* A2, const int* a_rows, 
     a.A = A; a.A2 = A2; a.W = W; a.C = C; a.scale = scale; a.shift = shift; a.R = R; a.a_rows = a_rows;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.relu = relu;
     return dispatch_tile<0, 0>(a, (hipStream_t)stream);
+}
+
+static int splitk_splits(int K) {                           // ~8 k-tiles of 16 per workgroup, at most 32 slices
+    const int nk = cdiv(K, BK);
+    int s = nk / 8;
+    return s < 1 ? 1 : (s > 32 ? 32 : s);
+}
+
+extern "C" long gom_gemm_splitk_workspace_bytes(int M, int N, int K) {
+    return (long)sizeof(float) * splitk_splits(K) * M * N;
+}
+
+// Skinny problems (M <= 128: tracker / re-id head, weight-read bound): K is split over blockIdx.y so that
+// N/64 x 8 workgroups stream the weights in parallel instead of N/128 workgroups looping the whole K.
+extern "C" int gom_gemm_f32_splitk(const float* A, const int* a_rows, int lda, const float* W, int ldw,
+                                   const float* scale, const float* shift, const float* R, int ldr, int relu,
+                                   float* C, int ldc, int M, int N, int K, void* workspace, long workspace_bytes,
+                                   void* stream) {
+    GOM_CHECK_ARG(A && W && C && workspace);
+    GOM_CHECK_ARG(M > 0 && M <= 256 && N > 0 && K > 0 && (K % 4) == 0);
+    GOM_CHECK_ARG((lda % 4) == 0 && (ldw % 4) == 0 && lda >= K && ldw >= K && ldc >= N && (!R || ldr >= N));
+    GOM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
+    GOM_CHECK_ARG(workspace_bytes >= gom_gemm_splitk_workspace_bytes(M, N, K));
+    const int nk = cdiv(K, BK);
+    const int splits = splitk_splits(K);
+    GemmArgs a{};
+    a.A = A; a.W = W; a.C = C; a.scale = scale; a.shift = shift; a.R = R; a.a_rows = a_rows;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.relu = relu;
+    a.kt_per_split = cdiv(nk, splits);
+    a.partial = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(cdiv(M, 256) * cdiv(N, 64)), (unsigned)splits);
+    const size_t lds = 2 * (256 + 64) * LDS_STRIDE * sizeof(float);
+    hipLaunchKernelGGL((gemm_f32_kernel<256, 64, 64, 64, 0, 0>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv((long)M * N, 256)), dim3(256), 0, s, a, splits);
+    return gom_launch_status();
 }
 
 extern "C" int gom_conv2d_nhwc_f32(const float* X, const float* Wt, const float* scale, const float* shift,

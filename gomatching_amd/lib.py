@@ -26,6 +26,8 @@ SIGNATURES = {
     "gom_ms_deform_attn_forward_strided": (I, [P, L, I, P, P, P, P, P, I, I, P]),
     "gom_msda_prepare": (I, [P, I, P, I, P, P, P, L, P]),
     "gom_gemm_f32": (I, [P, P, P, I, P, I, P, P, P, I, I, P, I, I, I, I, P]),
+    "gom_gemm_splitk_workspace_bytes": (L, [I, I, I]),
+    "gom_gemm_f32_splitk": (I, [P, P, I, P, I, P, P, P, I, I, P, I, I, I, I, P, L, P]),
     "gom_conv2d_nhwc_f32": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P]),
     "gom_split_bf16x3": (I, [P, I, I, I, P, I, P]),
     "gom_gemm_f32_bf16x6": (I, [P, P, P, I, P, L, I, P, P, P, I, I, P, I, I, I, I, P]),

@@ -246,11 +246,47 @@ class GoMatching:
                     track_ids[i] = uniq[j]
         return track_ids
 
-    def run_short_term_match(self, instances, id_count=None):
-        """gom_lstmatcher.py:405-465."""
+    def precompute_short_term(self, frames):
+        """Id-independent device work of every consecutive-frame short-term match of `frames`, batched
+        (roi_heads.short_term_scores); one D2H for all pairs.  Returns {index of cur frame: S numpy}."""
+        pairs, rows, boxes, which, off = [], [], [], [], 0
+        for t in range(1, len(frames)):
+            n_prev, n_cur = len(frames[t - 1]), len(frames[t])
+            if n_prev == 0 or n_cur == 0:
+                continue
+            for fr in (frames[t - 1], frames[t]):
+                rows.append(self._reid_rows(fr, np.ones((len(fr),), bool)))
+                boxes.append(self._host(fr)["boxes"])
+            pairs.append((off, n_prev, n_cur))
+            which.append(t)
+            off += n_prev + n_cur
+        if not pairs:
+            return {}
+        rows_d = torch.from_numpy(np.concatenate(rows).astype(np.int32)).to(self.device)
+        boxes_d = torch.from_numpy(np.concatenate(boxes).astype(np.float32)).to(self.device)
+        src_all = ops.gather_rows(self._pool, rows_d)
+        scores = self.roi_heads.short_term_scores(src_all, pairs, boxes_d, frames[1].image_size)
+        flat = torch.cat([s.reshape(-1) for s in scores]).cpu().numpy()      # the one sync of the short-term path
+        out, o = {}, 0
+        for t, (_, n_prev, n_cur) in zip(which, pairs):
+            out[t] = flat[o:o + n_cur * n_prev].reshape(n_cur, n_prev)
+            o += n_cur * n_prev
+        return out
+
+    def run_short_term_match(self, instances, id_count=None, S=None):
+        """gom_lstmatcher.py:405-465.  `S` (from precompute_short_term) makes this a pure host step."""
         prev, cur = instances
-        sels = [np.ones((len(prev),), bool), np.ones((len(cur),), bool)]
-        traj, uniq = self._match(instances, sels, 1, True, cur.image_size)
+        if S is not None or len(prev) == 0 or len(cur) == 0:
+            ids_prev = self._host(prev)["ids"]
+            uniq = np.unique(ids_prev)
+            if S is None:
+                traj = np.zeros((len(cur), len(uniq)), np.float32)
+            else:
+                order = np.argsort(ids_prev, kind="stable")         # column m <-> the detection carrying uniq[m]
+                traj = S[:, order]
+        else:
+            sels = [np.ones((len(prev),), bool), np.ones((len(cur),), bool)]
+            traj, uniq = self._match(instances, sels, 1, True, cur.image_size)
         track_ids = self._assign(traj, uniq, self._host(prev)["ids"], len(cur))
         if id_count:
             for i in range(len(cur)):
@@ -313,21 +349,28 @@ class GoMatching:
     def track_frames(self, dets, batch_id, id_count, instances, time_cost):
         """The per-frame id recurrence of gom_lstmatcher.py:369-403 over already detected frames."""
         start_frame_id = batch_id * 100
+        t0 = time.time()
+        base = len(instances)
+        window = ([instances[-1]] if base else []) + list(dets)
+        st = self.precompute_short_term(window)                  # keyed by index into `window`
+        shift = 1 if base else 0
+        time_cost["short_match"] += time.time() - t0
         for frame_id in range(len(dets)):
             instances.append(dets[frame_id])
             real_frame_id = start_frame_id + frame_id
+            S = st.get(frame_id + shift)
             if real_frame_id == 0:
                 n0 = len(instances[0])
                 self._set_ids(instances[0], np.arange(1, n0 + 1))
                 id_count = n0 + 1
             elif real_frame_id == 1:
                 t0 = time.time()
-                instances[0:2], id_count = self.run_short_term_match(instances[0:2], id_count=id_count)
+                instances[0:2], id_count = self.run_short_term_match(instances[0:2], id_count=id_count, S=S)
                 time_cost["short_match"] += time.time() - t0
             else:
                 t0 = time.time()
                 instances[real_frame_id - 1: real_frame_id + 1], cur_id = self.run_short_term_match(
-                    instances[real_frame_id - 1: real_frame_id + 1])
+                    instances[real_frame_id - 1: real_frame_id + 1], S=S)
                 time_cost["short_match"] += time.time() - t0
                 if -1 in cur_id:
                     win_st = max(0, real_frame_id + 1 - self.test_len)

@@ -74,6 +74,54 @@ class _MatcherTransformer:
         return tgt, memory
 
 
+    def forward_pairs(self, src_all, pairs):
+        """Batched forward over independent (previous frame, current frame) pairs -- the short-term matcher input
+        depends only on the two frames' embeddings, never on track ids, so all pairs of a batch of frames share
+        every GEMM (weights streamed once) and only the tiny attention cores run per pair.
+        src_all [sum N_p, F]: per pair the previous frame's rows then the current frame's.
+        pairs: list of (row offset, n_prev, n_cur).  Returns per-pair association logits [n_cur, N_p]."""
+        E = self.d
+        Nall = src_all.shape[0]
+        memory = src_all
+        for L in self.enc:
+            qkv = ops.gemm(memory, L["in"][0], bias=L["in"][1])
+            a = torch.empty((Nall, E), dtype=_f32, device=src_all.device)
+            for off, n_prev, n_cur in pairs:
+                n = n_prev + n_cur
+                f = qkv[off:off + n].view(-1)
+                self._attend_into(a[off:off + n], f, f[E:], f[2 * E:], 3 * E, 3 * E, n, n)
+            memory = ops.gemm(a, L["out"][0], bias=L["out"][1], R=memory)
+            h = ops.gemm(memory, L["lin1"][0], bias=L["lin1"][1], relu=True)
+            memory = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=memory)
+        cur_rows = torch.cat([torch.arange(off + n_prev, off + n_prev + n_cur, dtype=torch.int32)
+                              for off, n_prev, n_cur in pairs]).to(src_all.device)
+        tgt = ops.gather_rows(src_all, cur_rows)
+        M = tgt.shape[0]
+        cur_off = [0]
+        for _, _, n_cur in pairs:
+            cur_off.append(cur_off[-1] + n_cur)
+        for L in self.dec:
+            w, b = L["in"]
+            q = ops.gemm(tgt, w[:E], bias=b[:E])
+            kv = ops.gemm(memory, w[E:], bias=b[E:])
+            a = torch.empty((M, E), dtype=_f32, device=src_all.device)
+            for i, (off, n_prev, n_cur) in enumerate(pairs):
+                n = n_prev + n_cur
+                f = kv[off:off + n].view(-1)
+                self._attend_into(a[cur_off[i]:cur_off[i + 1]], q[cur_off[i]:cur_off[i + 1]], f, f[E:], E, 2 * E,
+                                  n_cur, n)
+            tgt = ops.gemm(a, L["out"][0], bias=L["out"][1], R=tgt)
+            if not self.only_crs:
+                h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True)
+                tgt = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt)
+        return [ops.gemm(tgt[cur_off[i]:cur_off[i + 1]], memory[off:off + n_prev + n_cur])
+                for i, (off, n_prev, n_cur) in enumerate(pairs)]
+
+    def _attend_into(self, out, q, k, v, ld_q, ld_kv, Lq, Lk):
+        hd = self.d // self.heads
+        ops.mha_core(q, k, v, out, 1, 1, self.heads, hd, Lq, Lk, [0, 0, ld_q, 0, 0, ld_kv, 0, 0, ld_kv, 0, 0, self.d])
+
+
 class _MatcherBase:
     def __init__(self, cfg, sd, device, prefix="roi_heads."):
         A = cfg.MODEL.ASSO_HEAD
@@ -110,6 +158,23 @@ class _MatcherBase:
         lo, hi = sum(n_t[:query_frame]), sum(n_t[:query_frame + 1])
         feats, memory = self._matcher(short_term).forward(reid_features, lo, hi)
         return ops.gemm(feats, memory)                        # ATTWeightHead with 0 layers: q . k^T
+
+    def short_term_scores(self, src_all, pairs, boxes_all, image_size):
+        """For every (prev, cur) pair: S[i, j] = max(activated association of cur i with prev j, IoU(i, j)).
+        Within one frame track ids are unique, so the reference's trajectory score of cur detection i for track m
+        (gom_lstmatcher.py:429-445) is exactly S[i, j_m] with j_m the previous-frame detection carrying id m: the
+        whole device side of short-term matching is id-independent and is done here for all pairs at once.
+        boxes_all [sum N_p, 4] px, same row order as src_all.  Returns a list of device tensors [n_cur, n_prev]."""
+        logits = self._matcher(True).forward_pairs(src_all, pairs)
+        out = []
+        for (off, n_prev, n_cur), lg in zip(pairs, logits):
+            act = self._activate_asso(lg, [n_prev, n_cur])
+            ident = list(range(n_prev))
+            meta = torch.tensor(ident + ident + ident + list(range(n_prev, n_prev + n_cur)), dtype=torch.int32)
+            out.append(ops.track_score(act, meta.to(self.device), None, boxes_all[off:off + n_prev + n_cur],
+                                       image_size[1], image_size[0], n_cur, n_prev, n_prev,
+                                       self.cfg.VIDEO_TEST.WITH_IOU, 0.0))
+        return out
 
     def _activate_asso(self, asso_logits, n_t):
         """lstmatcher.py:373-381 on the concatenated [n_k, N] logits."""

@@ -148,6 +148,13 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
         ldr = R.stride(0) if R.shape[0] > 1 else N
     if rows is not None:
         assert rows.dtype == torch.int32 and rows.is_contiguous()
+    if A2 is None and 0 < M <= 128 and N * K >= (1 << 18) and K >= 256:      # skinny, weight-read bound: split-K
+        nbytes = _L().gom_gemm_splitk_workspace_bytes(M, N, K)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)
+        check(_L().gom_gemm_f32_splitk(_p(A), _p(rows), lda, _p(W), ldw, _p(scale), _p(bias), _p(R), ldr,
+                                       1 if relu else 0, _p(out), ldc, M, N, K, _p(ws), nbytes, _stream()),
+              "gom_gemm_f32_splitk")
+        return out
     prof = _gemm_profile if (_gemm_profile is not None and N > 64 and M > 0 and GEMM_MODE == "fp32") else None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

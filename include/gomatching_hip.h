@@ -70,6 +70,13 @@ int gom_gemm_f32(const float* A, const float* A2, const int* a_rows, int lda, co
                  const float* scale, const float* shift, const float* R, int ldr, int relu, float* C, int ldc, int M,
                  int N, int K, void* stream);
 
+/* Same contraction for skinny problems (M <= 256; tracker / re-id head, weight-read bound): K split over
+ * workgroups, partial sums reduced in slice order (deterministic) with the epilogue.  No A2. */
+long gom_gemm_splitk_workspace_bytes(int M, int N, int K);
+int gom_gemm_f32_splitk(const float* A, const int* a_rows, int lda, const float* W, int ldw, const float* scale,
+                        const float* shift, const float* R, int ldr, int relu, float* C, int ldc, int M, int N, int K,
+                        void* workspace, long workspace_bytes, void* stream);
+
 /* Implicit-GEMM convolution, NHWC activations, OHWI weights [Cout, KH, KW, Cin], square kernel 1/3/7,
  * Cin a power of two >= 4.  Epilogue as above: FrozenBatchNorm as (scale, shift) (Detectron2
  * FrozenBatchNorm2d), conv bias as shift, bottleneck shortcut as R, ReLU.  Y [B, OH, OW, Cout]. */

@@ -106,6 +106,25 @@ def test_gemm_epilogue_and_gather():
     assert float(outbuf[:, :N].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 1024, 1024), (26, 3072, 1024), (100, 1024, 6400), (128, 2048, 1024),
+                                   (7, 600, 1024), (33, 1024, 256)])
+def test_gemm_skinny_splitk(M, N, K):
+    """Tracker / re-id head shapes take the split-K path inside ops.gemm; deterministic run to run."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Wd, bd, Rd = A.to(DEV), W.to(DEV), b.to(DEV), R.to(DEV)
+    out = ops.gemm(Ad, Wd, bias=bd, R=Rd, relu=True)
+    ref = F.relu((A.double() @ W.double().t()).float() + b + R)
+    _close(out, ref, 2e-5, 1e-5, "splitk %s" % ((M, N, K),))
+    assert torch.equal(out, ops.gemm(Ad, Wd, bias=bd, R=Rd, relu=True))
+    rows = torch.randint(0, M, (max(M // 2, 1),), generator=g)
+    out = ops.gemm(Ad, Wd, bias=bd, rows=rows.to(torch.int32).to(DEV))
+    _close(out, (A[rows].double() @ W.double().t()).float() + b, 2e-5, 1e-5, "splitk gather")
+
+
 def test_gemm_rejects_bad_args():
     ops = _ops()
     from gomatching_amd.lib import GomError

@@ -46,13 +46,15 @@ def timeit(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--mode", default="bf16x6", choices=["bf16x6", "fp32"])
     a = ap.parse_args()
+    ops.GEMM_MODE = a.mode
     dev = "cuda"
     tot_t = tot_f = 0.0
     for name, M, N, K, a2 in GEMMS:
         A = torch.randn(M, K, device=dev)
         A2 = torch.randn(M, K, device=dev) if a2 else None
-        W = torch.randn(N, K, device=dev)
+        W = ops.prep_weight(torch.randn(N, K, device=dev))
         b = torch.randn(N, device=dev)
         out = torch.empty(M, N, device=dev)
         t = timeit(lambda: ops.gemm(A, W, bias=b, A2=A2, out=out), a.iters)
@@ -62,7 +64,7 @@ def main():
         print("%-26s M=%7d N=%5d K=%5d  %8.1f us  %6.1f TF" % (name, M, N, K, t * 1e6, fl / t / 1e12))
     for name, B, H, W_, Cin, Cout, k, s, p in CONVS:
         x = torch.randn(B, H, W_, Cin, device=dev)
-        w = torch.randn(Cout, k, k, Cin, device=dev)
+        w = ops.prep_conv_weight(torch.randn(Cout, k, k, Cin, device=dev))
         sc, sh = torch.rand(Cout, device=dev), torch.randn(Cout, device=dev)
         t = timeit(lambda: ops.conv2d_nhwc(x, w, scale=sc, shift=sh, relu=True, stride=s, pad=p), a.iters)
         OH, OW = (H + 2 * p - k) // s + 1, (W_ + 2 * p - k) // s + 1
