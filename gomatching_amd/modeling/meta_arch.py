@@ -124,10 +124,12 @@ class GoMatching:
                               hw[0], hw[1], self.test_score_threshold, self.nms_thresh,
                               self.roi_heads.asso_thresh_test)
         t0 = time.time()
-        counts = det["count"].cpu().numpy()                   # the one host sync of the step
-        keep = det["keep_idx"].cpu().numpy()
-        scores_h = det["scores"].cpu().numpy()
-        boxes_h = det["boxes"].cpu().numpy()
+        small = det["small"].cpu().numpy()                    # the one host sync (and D2H copy) of the step
+        o1, o2, o3 = det["small_layout"]
+        counts = small[:o1]
+        keep = small[o1:o2].reshape(B, nq)
+        scores_h = small[o2:o3].view(np.float32).reshape(B, nq)
+        boxes_h = small[o3:].view(np.float32).reshape(B, nq, 4)
         n_total = int(counts.sum())
         rows = np.concatenate([keep[b, :counts[b]] for b in range(B)]) if n_total else np.zeros((0,), np.int32)
         self._ensure_pool(n_total)
@@ -222,15 +224,20 @@ class GoMatching:
         for j in range(Np):
             last[col_of[j]] = j if j > 0 else last[col_of[j]]
         meta = np.concatenate([nonk, col_of, last, k_inds]).astype(np.int32)
-        decay = None
+        offs = np.concatenate([[0], np.cumsum(n_t)]).astype(np.int32)
+        dec = None
         if (not short_term) and self.decay_time > 0:
             dts = np.concatenate([np.full((n,), T - t - 2, np.float32) for t, n in enumerate(n_t) if t != k])
-            decay = torch.from_numpy(np.power(np.float32(self.decay_time), dts).astype(np.float32)).to(self.device)
-        src = ops.gather_rows(self._pool, torch.from_numpy(rows).to(self.device))
+            dec = np.power(np.float32(self.decay_time), dts).astype(np.float32)
+        # one packed host->device copy per match: rows | frame offsets | meta | boxes (f32 bits) | decay (f32 bits)
+        parts = [rows, offs, meta, boxes.reshape(-1).view(np.int32)] + ([dec.view(np.int32)] if dec is not None else [])
+        buf = torch.from_numpy(np.concatenate(parts)).to(self.device)
+        o0 = len(rows); o1 = o0 + len(offs); o2 = o1 + len(meta); o3 = o2 + 4 * N
+        src = ops.gather_rows(self._pool, buf[:o0])
         asso = self.roi_heads._forward_transformer(src, n_t, k, short_term=short_term)
-        act = self.roi_heads._activate_asso(asso, n_t)
-        traj = ops.track_score(act, torch.from_numpy(meta).to(self.device), decay,
-                               torch.from_numpy(boxes).to(self.device), hw[1], hw[0], n_k, Np, M, self.with_iou,
+        act = ops.asso_activate(asso, buf[o0:o1], T)
+        traj = ops.track_score(act, buf[o1:o2], buf[o3:].view(torch.float32) if dec is not None else None,
+                               buf[o2:o3].view(torch.float32), hw[1], hw[0], n_k, Np, M, self.with_iou,
                                self.max_center_dist if not short_term else 0.0)
         return traj.cpu().numpy(), uniq
 

@@ -365,11 +365,15 @@ def argmax_rows(x):
 
 def detect_post(cls, recls, ctrl, bd, recs, B, nq, P, img_h, img_w, det_thr, nms_thr, asso_thr):
     dev = cls.device
+    # count | keep_idx | scores | boxes share one buffer so the host needs a single D2H copy per step
+    small = torch.zeros((B * (1 + 6 * nq),), dtype=torch.int32, device=dev)
+    o1, o2, o3 = B, B + B * nq, B + 2 * B * nq
     out = {
-        "count": torch.zeros((B,), dtype=torch.int32, device=dev),
-        "keep_idx": torch.zeros((B, nq), dtype=torch.int32, device=dev),
-        "scores": torch.zeros((B, nq), dtype=_f32, device=dev),
-        "boxes": torch.zeros((B, nq, 4), dtype=_f32, device=dev),
+        "small": small, "small_layout": (o1, o2, o3),
+        "count": small[:o1],
+        "keep_idx": small[o1:o2].view(B, nq),
+        "scores": small[o2:o3].view(_f32).view(B, nq),
+        "boxes": small[o3:].view(_f32).view(B, nq, 4),
         "ctrl": torch.zeros((B, nq, P * 2), dtype=_f32, device=dev),
         "bd": torch.zeros((B, nq, P, 4), dtype=_f32, device=dev),
         "recs": torch.zeros((B, nq, P), dtype=torch.int64, device=dev),
