@@ -303,7 +303,7 @@ extern "C" int gom_gemm_f32_splitk(const float* A, const int* a_rows, int lda, c
                                    float* C, int ldc, int M, int N, int K, void* workspace, long workspace_bytes,
                                    void* stream) {
     GOM_CHECK_ARG(A && W && C && workspace);
-    GOM_CHECK_ARG(M > 0 && M <= 256 && N > 0 && K > 0 && (K % 4) == 0);
+    GOM_CHECK_ARG(M > 0 && N > 0 && K > 0 && (K % 4) == 0 && (long)M * lda < (1L << 31));
     GOM_CHECK_ARG((lda % 4) == 0 && (ldw % 4) == 0 && lda >= K && ldw >= K && ldc >= N && (!R || ldr >= N));
     GOM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
     GOM_CHECK_ARG(workspace_bytes >= gom_gemm_splitk_workspace_bytes(M, N, K));

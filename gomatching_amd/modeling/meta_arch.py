@@ -137,10 +137,13 @@ class GoMatching:
         if n_total:
             rows_d = torch.from_numpy(rows.astype(np.int32)).to(self.device)
             qf = out["query_features"].view(B * nq, P * T.HIDDEN_DIM)
-            x = ops.gemm(qf, self.roi_heads.fcs[0][0], bias=self.roi_heads.fcs[0][1], rows=rows_d, relu=True)
+            # split-K always: a row's embedding then never depends on how many detections share the launch
+            x = ops.gemm(qf, self.roi_heads.fcs[0][0], bias=self.roi_heads.fcs[0][1], rows=rows_d, relu=True,
+                         splitk=True)
             for i, (w, b) in enumerate(self.roi_heads.fcs[1:]):
                 last = i == len(self.roi_heads.fcs) - 2
-                x = ops.gemm(x, w, bias=b, relu=True, out=self._pool[row0:row0 + n_total] if last else None)
+                x = ops.gemm(x, w, bias=b, relu=True, out=self._pool[row0:row0 + n_total] if last else None,
+                             splitk=True)
             if len(self.roi_heads.fcs) == 1:
                 self._pool[row0:row0 + n_total].copy_(x)
         self._pool_used += n_total

@@ -119,7 +119,7 @@ def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M):
     return out
 
 
-def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, out=None, M=None):
+def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, out=None, M=None, splitk=None):
     """C = act((A[+A2])[M,K] @ W[N,K]^T * scale + bias + R).  A may be a 2-D row-strided view
     (stride(1) == 1); W likewise (row slices of a weight matrix)."""
     if isinstance(W, SplitWeight):
@@ -148,7 +148,9 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
         ldr = R.stride(0) if R.shape[0] > 1 else N
     if rows is not None:
         assert rows.dtype == torch.int32 and rows.is_contiguous()
-    if A2 is None and 0 < M <= 128 and N * K >= (1 << 18) and K >= 256:      # skinny, weight-read bound: split-K
+    if splitk is None:
+        splitk = 0 < M <= 128 and N * K >= (1 << 18) and K >= 256      # skinny, weight-read bound
+    if splitk and A2 is None and M > 0:
         nbytes = _L().gom_gemm_splitk_workspace_bytes(M, N, K)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)
         check(_L().gom_gemm_f32_splitk(_p(A), _p(rows), lda, _p(W), ldw, _p(scale), _p(bias), _p(R), ldr,
