@@ -1,6 +1,6 @@
 // fp32-accurate GEMM / implicit-GEMM convolution on the bf16 matrix cores ("bf16x6" split emulation).
 //
-//   C[M,N] = epilogue( (A [+ A2])[M,K] . W[N,K]^T ),  fp32 in, fp32 out
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T ),  fp32 in, fp32 out
 //
 // gfx950 has no TF32-class fast path and its fp32 MFMA runs at 1/16 of the bf16 rate
 // (MI355X_MICROARCH.md "Matrix cores").  Each fp32 operand is therefore split into three bf16 planes
@@ -32,7 +32,6 @@ constexpr int ROW_BYTES = 80;                    // 32 bf16 + 16 B pad: 5 sixtee
 
 struct Args {
     const float* A;
-    const float* A2;
     const unsigned short* Wp;                    // [3][N][ldw] bf16 planes
     long w_plane_stride;                         // elements between planes
     float* C;
@@ -43,28 +42,38 @@ struct Args {
     int M, N, K;
     int lda, ldw, ldc, ldr;
     int relu;
+    int r_cols;                                  // residual applies to columns < r_cols
     int H, Wd, cin_log2, OH, OW, stride, pad;
 };
 
-__device__ __forceinline__ unsigned int f2bf_bits(float x) {      // round-to-nearest-even (hipcc: v_cvt_pk_bf16_f32)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned int f2bf_bits(float x) {      // round-to-nearest-even
     return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)x);
 }
 __device__ __forceinline__ float bf_bits2f(unsigned int b) { return __uint_as_float(b << 16); }
 
+// two floats -> packed bf16 pair (v_cvt_pk_bf16_f32) and the exact residuals
+__device__ __forceinline__ unsigned int cvt_pk(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1, unsigned int& q2) {
+    q0 = cvt_pk(x, y);
+    const float rx = x - __uint_as_float(q0 << 16), ry = y - __uint_as_float(q0 & 0xFFFF0000u);
+    q1 = cvt_pk(rx, ry);
+    const float sx = rx - __uint_as_float(q1 << 16), sy = ry - __uint_as_float(q1 & 0xFFFF0000u);
+    q2 = cvt_pk(sx, sy);
+}
 // split 4 floats into 3 planes of 4 bf16 (8 bytes each)
 __device__ __forceinline__ void split4(const f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
-    unsigned int b0[4], b1[4], b2[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        b0[i] = f2bf_bits(v[i]);
-        const float r1 = v[i] - bf_bits2f(b0[i]);
-        b1[i] = f2bf_bits(r1);
-        const float r2 = r1 - bf_bits2f(b1[i]);
-        b2[i] = f2bf_bits(r2);
-    }
-    p0[0] = b0[0] | (b0[1] << 16); p0[1] = b0[2] | (b0[3] << 16);
-    p1[0] = b1[0] | (b1[1] << 16); p1[1] = b1[2] | (b1[3] << 16);
-    p2[0] = b2[0] | (b2[1] << 16); p2[1] = b2[2] | (b2[3] << 16);
+    unsigned int a0, a1, a2, b0, b1, b2;
+    split2(v[0], v[1], a0, a1, a2);
+    split2(v[2], v[3], b0, b1, b2);
+    p0 = u32x2{a0, b0};
+    p1 = u32x2{a1, b1};
+    p2 = u32x2{a2, b2};
 }
 
 template <int BM, int BN, int KH, int KW>
@@ -94,82 +103,81 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(const Args p) {
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // ---- A descriptors: unit u = tid + i*256 -> row u>>3, k-quad u&7 -----------------------------
+    // ---- buffer descriptors: 32-bit byte offsets, out-of-range lanes read zeros (no select instructions) ----
+    constexpr unsigned RANGE = 0x80000000u, INVALID = 0xC0000000u;       // offsets stay OOB after adding < 1 GiB
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)RANGE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, (int)RANGE, 0x00020000);
+
+    // A: unit u = tid + i*256 -> row u>>3, k-quad u&7.  a_off = byte offset of (row, k = kq*4) or of the tap origin
     const int kq = tid & 7;
-    int a_off[A_UNITS], a_ih0[A_UNITS], a_iw0[A_UNITS];
-    bool a_ok[A_UNITS];
+    unsigned a_off[A_UNITS];
+    int a_ih0[A_UNITS], a_iw0[A_UNITS];
 #pragma unroll
     for (int i = 0; i < A_UNITS; ++i) {
         const int row = (tid >> 3) + i * 32;
         const int m = m0 + row;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
         if (CONV) {
             const int ow = mm % p.OW;
             const int t = mm / p.OW;
             const int oh = t % p.OH;
             const int b = t / p.OH;
-            a_ih0[i] = oh * p.stride - p.pad;
+            a_ih0[i] = ok ? oh * p.stride - p.pad : -(1 << 28);            // invalid row: every tap fails the bounds test
             a_iw0[i] = ow * p.stride - p.pad;
-            a_off[i] = ((b * p.H + a_ih0[i]) * p.Wd + a_iw0[i]) << p.cin_log2;
+            a_off[i] = (unsigned)((((b * p.H + oh * p.stride - p.pad) * p.Wd + a_iw0[i]) << p.cin_log2) * 4);
         } else {
             const int src = p.a_rows ? p.a_rows[mm] : mm;
-            a_off[i] = src * p.lda;
+            a_off[i] = ok ? (unsigned)(src * p.lda + kq * 4) * 4u : INVALID;
             a_ih0[i] = a_iw0[i] = 0;
         }
     }
-    // ---- W descriptors: unit u = tid + i*256 -> row u>>2, 16-byte chunk u&3 (8 bf16) ---------------
+    // W: unit u = tid + i*256 -> row u>>2, 16-byte chunk u&3 (8 bf16); byte offsets into plane 0
     const int wq = tid & 3;
-    long w_off[W_UNITS];
-    bool w_ok[W_UNITS];
+    unsigned w_off[W_UNITS];
 #pragma unroll
     for (int i = 0; i < W_UNITS; ++i) {
-        const int row = (tid >> 2) + i * 64;
-        const int n = n0 + row;
-        w_ok[i] = n < p.N;
-        w_off[i] = (long)(w_ok[i] ? n : 0) * p.ldw;
+        const int n = n0 + (tid >> 2) + i * 64;
+        w_off[i] = n < p.N ? (unsigned)(n * p.ldw + wq * 8) * 2u : INVALID;
     }
+    const unsigned w_plane_bytes = (unsigned)(p.w_plane_stride * 2);
 
-    f32x4 a_reg[A_UNITS];
+    f32x4 a_even[A_UNITS], a_odd[A_UNITS];                 // two k-tiles of A in flight (HBM latency > one MFMA phase)
     u32x4 w_reg[3][W_UNITS];
 
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + kq * 4;
-        const bool k_ok = k < p.K;
-        int tap_off = k;
+    auto load_A = [&](int kt, f32x4 (&a_reg)[A_UNITS]) {
+        unsigned koff = (unsigned)(kt * BK) * 4u;            // plain GEMM: columns kt*BK..
+        const bool k_ok = kt * BK + kq * 4 < p.K;            // K tail reads nothing (weights are zero there anyway)
         int kh = 0, kw = 0;
         if (CONV) {
+            const int k = kt * BK + kq * 4;
             const int c = k & ((1 << p.cin_log2) - 1);
             const int khw = k >> p.cin_log2;
             kh = khw / KW;
             kw = khw - kh * KW;
-            tap_off = ((kh * p.Wd + kw) << p.cin_log2) + c;
+            koff = (unsigned)((((kh * p.Wd + kw) << p.cin_log2) + c) * 4);
+            if (k >= p.K) kh = 1 << 28;                      // K tail: force out of range
         }
 #pragma unroll
         for (int i = 0; i < A_UNITS; ++i) {
-            bool ok = a_ok[i] && k_ok;
+            unsigned off = a_off[i] + koff;
+            if (!CONV && !k_ok) off = INVALID;
             if (CONV) {
                 const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-                ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.Wd);
+                if (!(((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.Wd))) off = INVALID;
             }
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                v = *reinterpret_cast<const f32x4*>(p.A + a_off[i] + tap_off);
-                if (p.A2) v += *reinterpret_cast<const f32x4*>(p.A2 + a_off[i] + tap_off);
-            }
-            a_reg[i] = v;
+            a_reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
         }
-        const int kw8 = kt * BK + wq * 8;                    // planes are zero-padded to ldw (multiple of 32)
+    };
+    auto load_W = [&](int kt) {
+        const unsigned koff = (unsigned)(kt * BK) * 2u;      // planes are zero-padded to ldw (multiple of 32)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-            for (int i = 0; i < W_UNITS; ++i) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (w_ok[i]) v = *reinterpret_cast<const u32x4*>(p.Wp + pl * p.w_plane_stride + w_off[i] + kw8);
-                w_reg[pl][i] = v;
-            }
+            for (int i = 0; i < W_UNITS; ++i)
+                w_reg[pl][i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(w_off[i] + koff + pl * w_plane_bytes), 0, 0);
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](const f32x4 (&a_reg)[A_UNITS]) {  // split A in registers, then A planes + W planes -> LDS
 #pragma unroll
         for (int i = 0; i < A_UNITS; ++i) {
             const int row = (tid >> 3) + i * 32;
@@ -202,62 +210,123 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(const Args p) {
     const unsigned char* a_base = As + (wr * WM + fr) * ROW_BYTES + fh * 16;
     const unsigned char* w_base = Ws + (wc * WN + fr) * ROW_BYTES + fh * 16;
 
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile(kt + 1);                  // in flight under the MFMAs below
+    auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 af[3][MT], bf[3][NT];
+            bf16x8 af[3][MT];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
                     af[pl][i] = *reinterpret_cast<const bf16x8*>(a_base + pl * A_PLANE + i * 32 * ROW_BYTES + ks * 32);
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    bf[pl][j] = *reinterpret_cast<const bf16x8*>(w_base + pl * W_PLANE + j * 32 * ROW_BYTES + ks * 32);
-            }
+            for (int j = 0; j < NT; ++j) {
+                bf16x8 b0 = *reinterpret_cast<const bf16x8*>(w_base + j * 32 * ROW_BYTES + ks * 32);
+                bf16x8 b1 = *reinterpret_cast<const bf16x8*>(w_base + W_PLANE + j * 32 * ROW_BYTES + ks * 32);
+                bf16x8 b2 = *reinterpret_cast<const bf16x8*>(w_base + 2 * W_PLANE + j * 32 * ROW_BYTES + ks * 32);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
+                for (int i = 0; i < MT; ++i) {
                     f32x16 c = acc[i][j];                    // smallest terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], b2, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], b0, c, 0, 0, 0);
                     acc[i][j] = c;
                 }
+            }
         }
-        __syncthreads();                                     // every wave is done reading this tile
-        if (kt + 1 < nk) {
-            store_tile();
+    };
+
+    load_A(0, a_even);
+    load_W(0);
+    if (nk > 1) load_A(1, a_odd);
+    store_tile(a_even);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; kt += 2) {
+        // tile kt is in LDS, a_odd holds tile kt+1 (issued a whole iteration ago)
+        if (kt + 1 < nk) load_W(kt + 1);
+        if (kt + 2 < nk) load_A(kt + 2, a_even);
+        compute();
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        store_tile(a_odd);
+        __syncthreads();
+        // tile kt+1 is in LDS, a_even holds tile kt+2
+        if (kt + 2 < nk) load_W(kt + 2);
+        if (kt + 3 < nk) load_A(kt + 3, a_odd);
+        compute();
+        __syncthreads();
+        if (kt + 2 < nk) {
+            store_tile(a_even);
             __syncthreads();
         }
     }
 
+    // ---- epilogue: y = acc*scale + shift (+ residual) (ReLU) --------------------------------------
+    const float relu_lo = p.relu ? 0.f : -INFINITY;
+    const bool vec_ok = ((p.N | p.ldc) & 3) == 0 && (!p.R || (p.ldr & 3) == 0);
+    if (vec_ok) {
+        // stage each 32-row slab of the wave's patch through (now free) LDS so that global traffic is whole
+        // 16-byte pieces of contiguous rows: 4x fewer store/load instructions than the per-register pattern
+        constexpr int ES = WN + 4;                           // padded row (floats)
+        float* stage = reinterpret_cast<float*>(smem) + wave * (32 * ES);
+        constexpr int C4 = WN / 4;                           // float4 per row
+        constexpr int RPI = 64 / C4;                         // rows covered per wave-instruction
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[((r & 3) + 8 * (r >> 2) + 4 * fh) * ES + j * 32 + fr] = acc[i][j][r];
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the slab is wave-private
+            const int c4 = (lane % C4) * 4;
+            const int n = n0 + wc * WN + c4;
+            const bool n_ok = n < p.N;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (n_ok && p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (n_ok && p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+            const bool use_r = p.R && n < p.r_cols;
+            f32x4 rv[32 / RPI];
+#pragma unroll
+            for (int t = 0; t < 32 / RPI; ++t) {
+                const int m = m0 + wr * WM + i * 32 + t * RPI + lane / C4;
+                rv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (use_r && n_ok && m < p.M) rv[t] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + n);
+            }
+#pragma unroll
+            for (int t = 0; t < 32 / RPI; ++t) {
+                const int row = t * RPI + lane / C4;
+                const int m = m0 + wr * WM + i * 32 + row;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ES + c4);
+                v = v * sc + sh + rv[t];
+                v[0] = fmaxf(v[0], relu_lo); v[1] = fmaxf(v[1], relu_lo);
+                v[2] = fmaxf(v[2], relu_lo); v[3] = fmaxf(v[3], relu_lo);
+                if (n_ok && m < p.M) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // reads done before the next slab overwrites
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + wc * WN + j * 32 + fr;
         const bool n_ok = n < p.N;
         const float sc = (n_ok && p.scale) ? p.scale[n] : 1.f;
         const float sh = (n_ok && p.shift) ? p.shift[n] : 0.f;
+        const bool use_r = p.R && n < p.r_cols;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (n_ok && m < p.M) {
-                    float v = acc[i][j][r];
-                    if (p.scale) v = v * sc + sh; else v = v + sh;
-                    if (p.R) v += p.R[(size_t)m * p.ldr + n];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.C[(size_t)m * p.ldc + n] = v;
+                    float v = acc[i][j][r] * sc + sh;
+                    if (use_r) v += p.R[(size_t)m * p.ldr + n];
+                    p.C[(size_t)m * p.ldc + n] = fmaxf(v, relu_lo);
                 }
             }
         }
@@ -307,19 +376,19 @@ extern "C" int gom_split_bf16x3(const float* W, int ldw, int N, int K, void* pla
     return gom_launch_status();
 }
 
-extern "C" int gom_gemm_f32_bf16x6(const float* A, const float* A2, const int* a_rows, int lda, const void* Wplanes,
+extern "C" int gom_gemm_f32_bf16x6(const float* A, const int* a_rows, int lda, const void* Wplanes,
                                    long w_plane_stride, int ldw, const float* scale, const float* shift,
-                                   const float* R, int ldr, int relu, float* C, int ldc, int M, int N, int K,
-                                   void* stream) {
+                                   const float* R, int ldr, int r_cols, int relu, float* C, int ldc, int M, int N,
+                                   int K, void* stream) {
     GOM_CHECK_ARG(A && Wplanes && C);
     GOM_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % 4) == 0);
     GOM_CHECK_ARG((lda % 4) == 0 && lda >= K && (ldw % 32) == 0 && ldw >= K && ldc >= N && (w_plane_stride % 8) == 0);
-    GOM_CHECK_ARG(!R || ldr >= N);
-    GOM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)Wplanes % 16) == 0 && (!A2 || ((uintptr_t)A2 % 16) == 0));
-    GOM_CHECK_ARG((long)M * lda < (1L << 31) || a_rows);
+    GOM_CHECK_ARG(!R || (r_cols > 0 && r_cols <= N && ldr >= r_cols));
+    GOM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)Wplanes % 16) == 0 && ((uintptr_t)C % 16) == 0);
+    GOM_CHECK_ARG((long)M * lda < (1L << 29) || a_rows);        // 32-bit byte offsets with a 2 GiB range check
     if (M == 0) return GOM_OK;
     Args a{};
-    a.A = A; a.A2 = A2; a.Wp = (const unsigned short*)Wplanes; a.w_plane_stride = w_plane_stride; a.C = C;
+    a.A = A; a.r_cols = r_cols; a.Wp = (const unsigned short*)Wplanes; a.w_plane_stride = w_plane_stride; a.C = C;
     a.scale = scale; a.shift = shift; a.R = R; a.a_rows = a_rows;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.relu = relu;
     return dispatch<0, 0>(a, (hipStream_t)stream);
@@ -333,12 +402,13 @@ extern "C" int gom_conv2d_nhwc_f32_bf16x6(const float* X, const void* Wplanes, l
     GOM_CHECK_ARG(B > 0 && H > 0 && Wd > 0 && Cin >= 4 && Cout > 0 && stride > 0 && pad >= 0);
     GOM_CHECK_ARG((Cin & (Cin - 1)) == 0);
     GOM_CHECK_ARG(KH == KW && (KH == 1 || KH == 3 || KH == 7));
-    GOM_CHECK_ARG((long)B * H * Wd * Cin < (1L << 31));
+    GOM_CHECK_ARG((long)B * H * Wd * Cin < (1L << 29));
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
     GOM_CHECK_ARG(OH > 0 && OW > 0);
     int lg = 0;
     while ((1 << lg) < Cin) ++lg;
     Args a{};
+    a.r_cols = Cout;
     a.A = X; a.Wp = (const unsigned short*)Wplanes; a.w_plane_stride = w_plane_stride; a.C = Y;
     a.scale = scale; a.shift = shift; a.R = R; a.relu = relu;
     a.M = B * OH * OW; a.N = Cout; a.K = KH * KW * Cin;

@@ -30,7 +30,7 @@ SIGNATURES = {
     "gom_gemm_f32_splitk": (I, [P, P, I, P, I, P, P, P, I, I, P, I, I, I, I, P, L, P]),
     "gom_conv2d_nhwc_f32": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P]),
     "gom_split_bf16x3": (I, [P, I, I, I, P, I, P]),
-    "gom_gemm_f32_bf16x6": (I, [P, P, P, I, P, L, I, P, P, P, I, I, P, I, I, I, I, P]),
+    "gom_gemm_f32_bf16x6": (I, [P, P, I, P, L, I, P, P, P, I, I, I, P, I, I, I, I, P]),
     "gom_conv2d_nhwc_f32_bf16x6": (I, [P, P, L, I, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P]),
     "gom_layernorm_f32": (I, [P, P, P, P, P, L, I, F, P]),
     "gom_groupnorm32_nhwc_f32": (I, [P, P, P, P, P, L, I, I, I, F, P]),

@@ -69,8 +69,12 @@ class DeepSolo:
                            sd[prefix + name + ".attention_weights.weight"]], 0)
             b = torch.cat([sd[prefix + name + ".sampling_offsets.bias"],
                            sd[prefix + name + ".attention_weights.bias"]], 0)
+            wv, bv = sd[prefix + name + ".value_proj.weight"], sd[prefix + name + ".value_proj.bias"]
             return {"raw": (ops.prep_weight(_dev(w, device)), _dev(b, device)), "value": lin(name + ".value_proj"),
-                    "out": lin(name + ".output_proj")}
+                    "out": lin(name + ".output_proj"),
+                    # encoder: offsets | attention logits | value projection as ONE [640, 256] GEMM
+                    "raw_value": (ops.prep_weight(_dev(torch.cat([w, wv], 0), device)),
+                                  _dev(torch.cat([b, bv], 0), device))}
 
         self.enc = []
         for i in range(self.n_enc):
@@ -135,8 +139,11 @@ class DeepSolo:
         lvl_pos = torch.empty((S, 256), dtype=_f32, device=dev)
         for l, (H, W) in enumerate(shapes):
             ops.pos_encoding_into(self.dim_t, self.level_embed[l], lvl_pos[int(lsi[l]):], H, W)
+        # (src + pos) @ W = src @ W + pos @ W, and pos is a per-resolution constant: the position term of every encoder
+        # layer's offsets/logits GEMM is a cached residual table instead of a second operand stream
+        pos_w = [ops.broadcast_rows(ops.gemm(lvl_pos, L["attn"]["raw"][0]), B).view(B * S, 384) for L in self.enc]
         geo = {
-            "S": S, "shapes": ss_d, "lsi": lsi_d, "lsi_host": [int(v) for v in lsi],
+            "S": S, "shapes": ss_d, "lsi": lsi_d, "lsi_host": [int(v) for v in lsi], "pos_w": pos_w,
             "lvl_pos": ops.broadcast_rows(lvl_pos, B).view(B * S, 256),
             "enc_ref": ops.broadcast_rows(ops.encoder_reference_points(ss_d, lsi_d, S), B).view(B * S, 1, 2),
             "valid": ops.proposal_valid(ss_d, lsi_d, S),
@@ -180,9 +187,11 @@ class DeepSolo:
 
     def encoder(self, src, geo, B):
         S = geo["S"]
-        for L in self.enc:
-            value = ops.gemm(src, L["attn"]["value"][0], bias=L["attn"]["value"][1])
-            samp = self._msda(L["attn"], src, geo["lvl_pos"], geo["enc_ref"], value, geo, B, S)
+        for li, L in enumerate(self.enc):
+            w, b = L["attn"]["raw_value"]
+            rv = ops.gemm(src, w, bias=b, R=geo["pos_w"][li], r_cols=384)             # [B*S, 384 | 256]
+            loc, aw = ops.msda_prepare(rv, geo["enc_ref"], geo["shapes"])
+            samp = ops.ms_deform_attn_forward_strided(rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], loc, aw, B, S)
             x = ops.gemm(samp, L["attn"]["out"][0], bias=L["attn"]["out"][1], R=src)
             src = ops.layernorm(x, *L["norm1"])
             h = ops.gemm(src, L["lin1"][0], bias=L["lin1"][1], relu=True)

@@ -97,21 +97,25 @@ def prep_conv_weight(w_ohwi):
     return w_ohwi
 
 
-def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M):
+def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols=None):
+    if A2 is not None:                                       # the bf16x6 kernel has one A operand: add first
+        assert rows is None
+        A = add(A.contiguous(), A2.contiguous())
     K, N = A.shape[1], W.N
     assert W.K == K
     lda = A.stride(0) if A.shape[0] > 1 else K
     if out is None:
         out = torch.empty((M, N), dtype=_f32, device=A.device)
     ldc = out.stride(0) if out.shape[0] > 1 else N
-    ldr = (R.stride(0) if R.shape[0] > 1 else N) if R is not None else 0
+    ldr = (R.stride(0) if R.shape[0] > 1 else R.shape[1]) if R is not None else 0
     pl = W.planes
     prof = _gemm_profile if (_gemm_profile is not None and M > 0) else None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_L().gom_gemm_f32_bf16x6(_p(A), _p(A2), _p(rows), lda, _p(pl), pl.stride(0), pl.stride(1), _p(scale),
-                                   _p(bias), _p(R), ldr, 1 if relu else 0, _p(out), ldc, M, N, K, _stream()),
+    rc = (r_cols if r_cols is not None else N) if R is not None else 0
+    check(_L().gom_gemm_f32_bf16x6(_p(A), _p(rows), lda, _p(pl), pl.stride(0), pl.stride(1), _p(scale),
+                                   _p(bias), _p(R), ldr, rc, 1 if relu else 0, _p(out), ldc, M, N, K, _stream()),
           "gom_gemm_f32_bf16x6")
     if prof is not None:
         e1.record()
@@ -119,7 +123,8 @@ def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M):
     return out
 
 
-def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, out=None, M=None, splitk=None):
+def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, out=None, M=None, splitk=None,
+         r_cols=None):
     """C = act((A[+A2])[M,K] @ W[N,K]^T * scale + bias + R).  A may be a 2-D row-strided view
     (stride(1) == 1); W likewise (row slices of a weight matrix)."""
     if isinstance(W, SplitWeight):
@@ -128,8 +133,18 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
             M = A.shape[0] if rows is None else rows.numel()
         if A2 is not None:
             assert A2.shape == A.shape and A2.stride() == A.stride()
-        return _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M)
+        return _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols)
     assert A.dim() == 2 and W.dim() == 2 and A.stride(1) == 1 and W.stride(1) == 1
+    if R is not None and r_cols is not None and r_cols < W.shape[0]:
+        # exact-fp32 kernel has no column-limited residual: run the two column blocks as two launches
+        Mrows = A.shape[0] if rows is None else rows.numel()
+        if out is None:
+            out = torch.empty((Mrows, W.shape[0]), dtype=_f32, device=A.device)
+        gemm(A, W[:r_cols], bias=None if bias is None else bias[:r_cols], scale=scale, A2=A2, rows=rows, R=R,
+             relu=relu, out=out[:, :r_cols], M=M)
+        gemm(A, W[r_cols:], bias=None if bias is None else bias[r_cols:], scale=scale, A2=A2, rows=rows, relu=relu,
+             out=out[:, r_cols:], M=M)
+        return out
     K = A.shape[1]
     assert W.shape[1] == K
     N = W.shape[0]

@@ -86,11 +86,12 @@ int gom_conv2d_nhwc_f32(const float* X, const float* Wt, const float* scale, con
 
 /* fp32-accurate variants on the bf16 matrix cores ("bf16x6": operands split into three bf16 planes, six MFMA
  * products of weight <= 2; error ~ one fp32 rounding per product; 2.67x the fp32 matrix rate).
- * The weight operand is pre-split once: planes_out [3][N][Kpad] bf16, Kpad a multiple of 32 (zero padded). */
+ * The weight operand is pre-split once: planes_out [3][N][Kpad] bf16, Kpad a multiple of 32 (zero padded).
+ * No second A operand; the residual R applies to columns < r_cols only (lets one launch serve fused heads). */
 int gom_split_bf16x3(const float* W, int ldw, int N, int K, void* planes_out, int Kpad, void* stream);
-int gom_gemm_f32_bf16x6(const float* A, const float* A2, const int* a_rows, int lda, const void* Wplanes,
-                        long w_plane_stride, int ldw, const float* scale, const float* shift, const float* R, int ldr,
-                        int relu, float* C, int ldc, int M, int N, int K, void* stream);
+int gom_gemm_f32_bf16x6(const float* A, const int* a_rows, int lda, const void* Wplanes, long w_plane_stride, int ldw,
+                        const float* scale, const float* shift, const float* R, int ldr, int r_cols, int relu, float* C,
+                        int ldc, int M, int N, int K, void* stream);
 int gom_conv2d_nhwc_f32_bf16x6(const float* X, const void* Wplanes, long w_plane_stride, int ldw, const float* scale,
                                const float* shift, const float* R, int relu, float* Y, int B, int H, int Wd, int Cin,
                                int Cout, int KH, int KW, int stride, int pad, void* stream);

@@ -47,11 +47,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--mode", default="bf16x6", choices=["bf16x6", "fp32"])
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
     a = ap.parse_args()
     ops.GEMM_MODE = a.mode
     dev = "cuda"
     tot_t = tot_f = 0.0
     for name, M, N, K, a2 in GEMMS:
+        if a.only and a.only not in name:
+            continue
         A = torch.randn(M, K, device=dev)
         A2 = torch.randn(M, K, device=dev) if a2 else None
         W = ops.prep_weight(torch.randn(N, K, device=dev))
@@ -63,6 +66,8 @@ def main():
         tot_f += fl
         print("%-26s M=%7d N=%5d K=%5d  %8.1f us  %6.1f TF" % (name, M, N, K, t * 1e6, fl / t / 1e12))
     for name, B, H, W_, Cin, Cout, k, s, p in CONVS:
+        if a.only and a.only not in name:
+            continue
         x = torch.randn(B, H, W_, Cin, device=dev)
         w = ops.prep_conv_weight(torch.randn(Cout, k, k, Cin, device=dev))
         sc, sh = torch.rand(Cout, device=dev), torch.randn(Cout, device=dev)
@@ -71,7 +76,8 @@ def main():
         fl = 2.0 * B * OH * OW * Cout * k * k * Cin
         print("%-26s M=%7d N=%5d K=%5d  %8.1f us  %6.1f TF" % (name, B * OH * OW, Cout, k * k * Cin, t * 1e6,
                                                              fl / t / 1e12))
-    print("GEMM list aggregate: %.1f TF" % (tot_f / tot_t / 1e12))
+    if tot_t:
+        print("GEMM list aggregate: %.1f TF" % (tot_f / tot_t / 1e12))
 
 
 if __name__ == "__main__":
