@@ -105,7 +105,92 @@ __global__ __launch_bounds__(256) void msda_prep_kernel(const float* __restrict_
     }
 }
 
+// Fused MSDeformAttn core (ms_deform_attn.py:136-151 minus the two projections): softmax over the 16 logits,
+// sampling-location arithmetic and the bilinear gather in ONE pass over the [Q, 384] offsets|logits rows, so
+// the [Q,8,4,4,2] locations and [Q,8,4,4] weights never exist in HBM (saves 3 x 457 MB of traffic per
+// encoder call at 8 x 37 171 tokens and one launch).  Same lane mapping as msda_fwd_kernel.
+template <int POINTS>
+__global__ __launch_bounds__(256) void msda_fused_kernel(const float* __restrict__ value,
+                                                         const int64_t* __restrict__ shapes,
+                                                         const int64_t* __restrict__ lsi,
+                                                         const float* __restrict__ raw, int ld_raw,
+                                                         const float* __restrict__ ref, float* __restrict__ out,
+                                                         int B, int Lq, long v_bs, int v_rs) {
+    constexpr int LP = LEVELS * POINTS;
+    const long q_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q_global >= (long)B * Lq) return;
+    const int lane = threadIdx.x & 63;
+    const int m = lane >> 3;
+    const int c4 = (lane & 7) * 4;
+    const int b = (int)(q_global / Lq);
+
+    const float* vb = value + (size_t)b * v_bs + m * CH + c4;
+    const float* op = raw + (size_t)q_global * ld_raw + m * (LP * 2);
+    const float* lp = raw + (size_t)q_global * ld_raw + HEADS * LP * 2 + m * LP;
+    f32x4 offv[LP / 2], lgv[LP / 4];
+#pragma unroll
+    for (int i = 0; i < LP / 2; ++i) offv[i] = *reinterpret_cast<const f32x4*>(op + 4 * i);
+#pragma unroll
+    for (int i = 0; i < LP / 4; ++i) lgv[i] = *reinterpret_cast<const f32x4*>(lp + 4 * i);
+    const float rx = ref[q_global * 2], ry = ref[q_global * 2 + 1];
+    float e[LP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { e[i] = lgv[i >> 2][i & 3]; mx = fmaxf(mx, e[i]); }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { e[i] = expf(e[i] - mx); sum += e[i]; }
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < LEVELS; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const float Hf = (float)H, Wf = (float)W;
+        const float* vl = vb + (size_t)lsi[l] * v_rs;
+#pragma unroll
+        for (int p = 0; p < POINTS; ++p) {
+            const int i = l * POINTS + p;
+            const float lx = rx + offv[i >> 1][(i & 1) * 2] / Wf;
+            const float ly = ry + offv[i >> 1][(i & 1) * 2 + 1] / Hf;
+            const float w = e[i] / sum;
+            const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+            if (h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf) {
+                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+                const float lh = h_im - h_low, lw = w_im - w_low;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const bool y0 = h_low >= 0, y1 = h_low + 1 <= H - 1;
+                const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
+                const float* base = vl + ((long)h_low * W + w_low) * (long)v_rs;
+                f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
+                if (y0 && x0) v1 = *reinterpret_cast<const f32x4*>(base);
+                if (y0 && x1) v2 = *reinterpret_cast<const f32x4*>(base + v_rs);
+                if (y1 && x0) v3 = *reinterpret_cast<const f32x4*>(base + (long)W * v_rs);
+                if (y1 && x1) v4 = *reinterpret_cast<const f32x4*>(base + (long)(W + 1) * v_rs);
+                const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                acc += val * w;
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)q_global * (HEADS * CH) + m * CH + c4) = acc;
+}
+
 }  // namespace
+
+extern "C" int gom_msda_fused_forward(const float* raw, int ld_raw, const float* ref, const float* value,
+                                      long value_batch_stride, int value_row_stride, const int64_t* spatial_shapes,
+                                      const int64_t* level_start_index, float* output, int batch, int num_query,
+                                      void* stream) {
+    GOM_CHECK_ARG(raw && ref && value && spatial_shapes && level_start_index && output);
+    GOM_CHECK_ARG(batch > 0 && num_query > 0 && ld_raw >= HEADS * LEVELS * 4 * 3 && (ld_raw % 4) == 0);
+    GOM_CHECK_ARG(value_row_stride >= HEADS * CH && (value_row_stride % 4) == 0 && (value_batch_stride % 4) == 0);
+    GOM_CHECK_ARG(((uintptr_t)raw % 16) == 0 && ((uintptr_t)value % 16) == 0);
+    const long nq = (long)batch * num_query;
+    hipLaunchKernelGGL((msda_fused_kernel<4>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
+                       spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
+                       value_batch_stride, value_row_stride);
+    return gom_launch_status();
+}
 
 extern "C" int gom_ms_deform_attn_forward(const float* value, const int64_t* spatial_shapes,
                                           const int64_t* level_start_index, const float* sampling_loc,

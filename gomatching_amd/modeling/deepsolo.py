@@ -190,8 +190,7 @@ class DeepSolo:
         for li, L in enumerate(self.enc):
             w, b = L["attn"]["raw_value"]
             rv = ops.gemm(src, w, bias=b, R=geo["pos_w"][li], r_cols=384)             # [B*S, 384 | 256]
-            loc, aw = ops.msda_prepare(rv, geo["enc_ref"], geo["shapes"])
-            samp = ops.ms_deform_attn_forward_strided(rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], loc, aw, B, S)
+            samp = ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S)
             x = ops.gemm(samp, L["attn"]["out"][0], bias=L["attn"]["out"][1], R=src)
             src = ops.layernorm(x, *L["norm1"])
             h = ops.gemm(src, L["lin1"][0], bias=L["lin1"][1], relu=True)
@@ -264,9 +263,7 @@ class DeepSolo:
     def _msda_strided(self, W, query, query_pos, ref, value_view, ld_value, geo, B, Lq):
         """Cross-attention sampling straight out of the fused [B*S, 1536] value buffer (no compaction copy)."""
         raw = ops.gemm(query, W["raw"][0], bias=W["raw"][1], A2=query_pos)
-        loc, w = ops.msda_prepare(raw, ref, geo["shapes"])
-        return ops.ms_deform_attn_forward_strided(value_view, geo["S"] * ld_value, geo["shapes"], geo["lsi"], loc, w,
-                                                  B, Lq)
+        return ops.msda_fused(raw, ref, value_view, geo["S"] * ld_value, geo["shapes"], geo["lsi"], B, Lq)
 
     def _mlp3(self, x, layers):
         h = ops.gemm(x, layers[0][0], bias=layers[0][1], relu=True)

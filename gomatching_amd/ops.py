@@ -256,6 +256,16 @@ def ms_deform_attn_forward_strided(value2d, batch_stride, shapes, lsi, loc, w, B
     return out
 
 
+def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq):
+    """raw [B*Lq, >=384] (offsets | logits, stride(1)==1), ref [B*Lq, 2], value2d [B*S, 256] column slice."""
+    assert raw.stride(1) == 1 and value2d.stride(1) == 1
+    _chk_f32(ref)
+    out = torch.empty((B * Lq, 256), dtype=_f32, device=raw.device)
+    check(_L().gom_msda_fused_forward(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride, value2d.stride(0),
+                                      _p(shapes), _p(lsi), _p(out), B, Lq, _stream()), "gom_msda_fused_forward")
+    return out
+
+
 def msda_prepare(raw, ref, spatial_shapes, ref_levels=1):
     """raw [Q, >=384] (offsets | logits), ref [Q, ref_levels, 2] -> loc [Q,8,4,4,2], w [Q,8,4,4]."""
     _chk_f32(ref)

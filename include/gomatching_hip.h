@@ -56,6 +56,12 @@ int gom_ms_deform_attn_forward_strided(const float* value, long value_batch_stri
                                        const float* sampling_loc, const float* attn_weight, float* output, int batch,
                                        int num_query, void* stream);
 
+/* Fused MSDeformAttn core: gom_msda_prepare + gom_ms_deform_attn_forward_strided in one pass (locations and
+ * weights never reach HBM).  raw/ref as for gom_msda_prepare with ref_levels = 1. */
+int gom_msda_fused_forward(const float* raw, int ld_raw, const float* ref, const float* value, long value_batch_stride,
+                           int value_row_stride, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                           float* output, int batch, int num_query, void* stream);
+
 /* Sampling-location + softmax arithmetic of MSDeformAttn.forward (ms_deform_attn.py:136-145).
  * raw [Q, ld_raw]: columns [0,256) = sampling_offsets output, [256,384) = attention_weights logits;
  * ref [Q, ref_levels, 2] (ref_levels 1 = same point on every level, the unpadded case). */

@@ -232,6 +232,12 @@ def test_msda_larger_vs_oracle_and_prepare():
                                      w.view(B, Lq, 8, 4, 4))
     exp = O.ms_deform_attn_forward(value, ss, lsi, loc_ref.view(B, Lq, 8, 4, 4, 2), w_ref.view(B, Lq, 8, 4, 4))
     _close(out, exp, 3e-5, 0, "msda vs oracle")
+    # fused prepare+sample, value read in place from a wider buffer
+    wide = torch.zeros(B * S, 640, device=DEV)
+    wide[:, 384:] = value.view(B * S, 256).to(DEV)
+    fused = ops.msda_fused(raw.to(DEV), ref.view(B * Lq, 2).to(DEV), wide[:, 384:], S * 640, ss.to(DEV),
+                           lsi.to(DEV), B, Lq)
+    _close(fused, exp.view(B * Lq, 256), 3e-5, 0, "fused msda vs oracle")
 
 
 # ------------------------------------------------------------------------------------------ attention
