@@ -76,6 +76,12 @@ def all_gather_records(local, group=None):
     if world == 1:
         return local
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # test configuration only (several ranks sharing one GPU): gloo moves host memory
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous(), group=group)
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     return out
 

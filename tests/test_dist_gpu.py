@@ -1,0 +1,72 @@
+"""GPU: the frame-sharded path end to end with two ranks sharing cuda:0 (gloo carries the records in this
+test; the product uses RCCL): every rank must reproduce the single-process track ids of the whole clip."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(hw, frames):
+    from gomatching_amd.synth import make_clip
+    clip = make_clip(frames, hw[0], hw[1], clip_id=1)
+    return [{"image": torch.as_tensor(f.astype("float32").transpose(2, 0, 1))} for f in clip]
+
+
+def _model():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import mini_cfg, golden, e2e_state_dict
+    from gomatching_amd.modeling import GoMatching
+    g = golden("e2e_lst.npz")
+    cfg = mini_cfg("icdar15", device="cuda")
+    return GoMatching(cfg, e2e_state_dict(cfg, g), device="cuda:0", frames_per_step=4), g
+
+
+def _tc():
+    return {k: 0.0 for k in ("pre_process", "backbone", "detector", "rescore", "tracker", "short_match", "long_match")}
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gomatching_amd.dist import sharded_batch_inference
+        model, g = _model()
+        hw = tuple(int(v) for v in g["hw"])
+        inputs = _inputs(hw, 8)
+        local = inputs[rank * 4:(rank + 1) * 4]
+        insts, id_count = sharded_batch_inference(model, local, 0, 0, [], _tc())
+        q.put((rank, int(id_count), [x.track_ids.cpu().tolist() for x in insts],
+               [np.round(x.scores.cpu().numpy(), 5).tolist() for x in insts]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_equals_single_process():
+    model, g = _model()
+    hw = tuple(int(v) for v in g["hw"])
+    insts, id_count = model.batch_inference(_inputs(hw, 8), 0, 0, [], _tc())
+    ref_ids = [x.track_ids.cpu().tolist() for x in insts]
+    assert ref_ids == [g["pre_ids_%d" % f].tolist() for f in range(8)]          # and both equal the reference's
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    for rank, idc, ids, scores in res:
+        assert idc == int(id_count), (rank, idc, id_count)
+        assert ids == ref_ids, rank
