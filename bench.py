@@ -31,6 +31,18 @@ PEAKS = {"fp32": ("gemm_f32_kernel<128,128,64,64,0,0>", 157.3, 1),
          "bf16x6": ("gemm_bf16x6_kernel<128,128,0,0>", 2500.0 / 6.0, 6)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
+    gfx950 per MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMCs itself."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return rec[kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def build_model(cfg, device):
     from gomatching_amd.modeling import GoMatching
     from gomatching_amd.weights import synth_state_dict
@@ -133,7 +145,10 @@ def main():
     inputs, hw = predictor.prepare(mine)                       # host resize etc.: outside the timed window
     inputs = [dict(x, image=x["image"].to(device)) for x in inputs]      # resident in HBM before timing starts
     net_hw = tuple(inputs[0]["image"].shape[-2:])
-    shift, re_shift = calibrate(model, inputs)
+    # every rank calibrates on the SAME frame (frame 0 of the clip) so that all ranks hold identical weights
+    cal_inputs, _ = predictor.prepare([clip[0][:, :, ::-1]])
+    cal_inputs = [dict(x, image=x["image"].to(device)) for x in cal_inputs]
+    shift, re_shift = calibrate(model, cal_inputs)
 
     def step(tc):
         insts, id_count = sharded_batch_inference(model, inputs, 0, 0, [], tc) if world > 1 else \
@@ -166,8 +181,9 @@ def main():
 
     total_frames = FRAMES_PER_GPU * world * args.steps
     fps = total_frames / elapsed
-    dur_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
-    flops = sum(f for _, _, f in prof)
+    dur_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
+    flops = sum(p[2] for p in prof)
+    alg_bytes = sum(p[3] for p in prof)
     achieved = flops / (dur_ms * 1e-3) / 1e12 if dur_ms > 0 else 0.0
     line = {
         "metric": "frames/sec (whole node), 1280x720 clip, 100 queries/frame",
@@ -183,11 +199,12 @@ def main():
                    "tracks": int(id_count)},
         "roofline": {"bound": "mfma", "kernel": PEAKS[args.gemm][0], "achieved": achieved,
                      "peak": PEAKS[args.gemm][1], "unit": "TFLOP/s", "frac": achieved / PEAKS[args.gemm][1],
-                     "traffic": None, "mfma_passes_per_product": PEAKS[args.gemm][2],
+                     "traffic": pmc_traffic(PEAKS[args.gemm][0]), "mfma_passes_per_product": PEAKS[args.gemm][2],
                      "peak_note": "algorithmic fp32-equivalent FLOP/s; bf16x6 = dense bf16 MFMA peak 2500 / 6 passes"
                      if args.gemm == "bf16x6" else "dense fp32-input MFMA peak", "launches_per_step": len(prof) // max(args.steps, 1),
                      "avg_launch_us": dur_ms * 1e3 / max(len(prof), 1),
                      "flops_per_launch_avg": flops / max(len(prof), 1),
+                     "algorithmic_bytes_per_launch_avg": alg_bytes / max(len(prof), 1),
                      "share_of_step_time": dur_ms / (elapsed * 1e3)},
         "stage_ms_per_step": {k: v / args.steps * 1e3 for k, v in tc.items() if isinstance(v, float) and v > 0},
     }

@@ -119,7 +119,8 @@ def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols=None):
           "gom_gemm_f32_bf16x6")
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K))
+        nbytes = 4.0 * M * K + 6.0 * N * pl.shape[2] + 4.0 * M * N + (4.0 * M * rc if R is not None else 0.0)
+        prof.append((e0, e1, 2.0 * M * N * K, nbytes))
     return out
 
 
