@@ -351,9 +351,16 @@ class GoMatching:
         self._ensure_pool(num_new_frames * self.cfg.MODEL.TRANSFORMER.NUM_QUERIES)   # no re-allocation mid-batch
 
     def detect_steps(self, batched_inputs, time_cost):
-        dets = []
-        for s0 in range(0, len(batched_inputs), self.frames_per_step):
-            dets.extend(self.inference(batched_inputs[s0:s0 + self.frames_per_step], time_cost))
+        """Detection in steps of <= frames_per_step consecutive frames of ONE size (mixed-resolution clips, e.g.
+        BASELINE config #5, simply start a new step at every size change)."""
+        dets, s0, n = [], 0, len(batched_inputs)
+        while s0 < n:
+            hw = tuple(batched_inputs[s0]["image"].shape[-2:])
+            s1 = s0 + 1
+            while s1 < n and s1 - s0 < self.frames_per_step and tuple(batched_inputs[s1]["image"].shape[-2:]) == hw:
+                s1 += 1
+            dets.extend(self.inference(batched_inputs[s0:s1], time_cost))
+            s0 = s1
         return dets
 
     def track_frames(self, dets, batch_id, id_count, instances, time_cost):

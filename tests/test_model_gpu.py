@@ -179,3 +179,51 @@ def test_batch_invariance_and_determinism():
     assert torch.equal(a[1].reid_features, b[0].reid_features)
     for x, y in zip(a, c):
         assert torch.equal(x.scores, y.scores) and torch.equal(x.recs, y.recs) and torch.equal(x.bd, y.bd)
+
+
+@pytest.mark.parametrize("builtin,hw,nframes", [("pp_dstext", (1280, 2276), 1), ("bovtext", (1000, 1778), 2)])
+def test_full_size_configs_run(builtin, hw, nframes):
+    """BASELINE configs #4 (300 queries, 1280x2276, GoMatching++) and #5 (voc 5462) at their full sizes: the path
+    runs, outputs are finite and in range, and the result is run-to-run identical (size-independent properties)."""
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.config import setup_cfg
+    from gomatching_amd.weights import synth_state_dict
+    cfg = setup_cfg(builtin=builtin)
+    cfg.MODEL.DEVICE = DEV
+    sd = synth_state_dict(cfg, seed=1, cls_bias={"detection_transformer.ctrl_point_class.0.bias": 0.3})
+    model = GoMatching(cfg, sd, device=DEV, frames_per_step=2)
+    g = torch.Generator().manual_seed(3)
+    inputs = [{"image": torch.rand(3, hw[0], hw[1], generator=g) * 255} for _ in range(nframes)]
+    a = model.inference(inputs, _time_cost())
+    b = model.inference(inputs, _time_cost())
+    nq, voc = cfg.MODEL.TRANSFORMER.NUM_QUERIES, cfg.MODEL.TRANSFORMER.VOC_SIZE
+    for x, y in zip(a, b):
+        n = len(x)
+        assert 0 < n <= nq
+        assert torch.isfinite(x.bd).all() and torch.isfinite(x.reid_features).all()
+        assert float(x.scores.min()) > cfg.MODEL.TRANSFORMER.INFERENCE_TH_TEST and float(x.scores.max()) <= 1.0
+        assert int(x.recs.min()) >= 0 and int(x.recs.max()) <= voc
+        assert float(x.bd[..., 0::2].max()) <= hw[1] + 1e-3 and float(x.bd[..., 1::2].max()) <= hw[0] + 1e-3
+        assert torch.equal(x.scores, y.scores) and torch.equal(x.recs, y.recs) and torch.equal(x.bd, y.bd)
+        s = x.scores.cpu()
+        assert bool((s[:-1] >= s[1:]).all())                    # NMS order = descending score
+
+
+def test_mixed_resolution_clip():
+    """Frames of different sizes in one batch_inference call are split into per-size steps (config #5)."""
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.weights import synth_state_dict
+    cfg = mini_cfg("icdar15", device=DEV)
+    sd = synth_state_dict(cfg, seed=7, cls_bias={"detection_transformer.ctrl_point_class.0.bias": 0.5})
+    model = GoMatching(cfg, sd, device=DEV, frames_per_step=4)
+    g = torch.Generator().manual_seed(9)
+    sizes = [(96, 128), (96, 128), (128, 96), (96, 128), (96, 128)]
+    inputs = [{"image": torch.rand(3, h, w, generator=g) * 255} for h, w in sizes]
+    insts, id_count = model.batch_inference(inputs, 0, 0, [], _time_cost())
+    assert [x.image_size for x in insts] == sizes
+    single = [model.inference([x], _time_cost())[0] for x in inputs]
+    for a, b in zip(insts, single):
+        assert torch.equal(a.scores, b.scores) and torch.equal(a.bd, b.bd)
+    for x in insts:
+        ids = x.track_ids.cpu().tolist()
+        assert len(ids) == len(set(ids))
