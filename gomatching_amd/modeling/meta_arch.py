@@ -353,11 +353,14 @@ class GoMatching:
     def detect_steps(self, batched_inputs, time_cost):
         """Detection in steps of <= frames_per_step consecutive frames of ONE size (mixed-resolution clips, e.g.
         BASELINE config #5, simply start a new step at every size change)."""
+        def size(x):
+            return tuple(x["image"].shape[-2:]) if "image" in x else None
+
         dets, s0, n = [], 0, len(batched_inputs)
         while s0 < n:
-            hw = tuple(batched_inputs[s0]["image"].shape[-2:])
+            hw = size(batched_inputs[s0])
             s1 = s0 + 1
-            while s1 < n and s1 - s0 < self.frames_per_step and tuple(batched_inputs[s1]["image"].shape[-2:]) == hw:
+            while s1 < n and s1 - s0 < self.frames_per_step and size(batched_inputs[s1]) == hw:
                 s1 += 1
             dets.extend(self.inference(batched_inputs[s0:s1], time_cost))
             s0 = s1
