@@ -96,6 +96,12 @@ def sharded_batch_inference(model, local_inputs, batch_id, id_count, instances, 
         return model.batch_inference(local_inputs, batch_id, id_count, instances, time_cost)
     model.begin_batch(instances, len(local_inputs) * world)
     dets = model.detect_steps(local_inputs, time_cost)
+    return exchange_and_track(model, dets, batch_id, id_count, instances, time_cost, group)
+
+
+def exchange_and_track(model, dets, batch_id, id_count, instances, time_cost, group=None):
+    """Second half of the sharded step: pack this rank's detections, ONE all-gather, replicated tracker."""
+    T = model.cfg.MODEL.TRANSFORMER
     hw = dets[0].image_size
     rec = pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, model.device)
     allrec = all_gather_records(rec, group)

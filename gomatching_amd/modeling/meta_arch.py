@@ -98,6 +98,12 @@ class GoMatching:
 
     def inference(self, batched_inputs, time_cost):
         """Detection + re-id embedding for a step of frames (gom_lstmatcher.py:268-351), batched."""
+        return self.detect_finish(self.detect_launch(batched_inputs, time_cost), time_cost)
+
+    def detect_launch(self, batched_inputs, time_cost):
+        """Asynchronous half of `inference`: queues every detector kernel of the step on the current stream, ends
+        with a non-blocking D2H copy of the nq-padded detection summary and an event.  No host sync, no tracker
+        state touched -- a caller may queue the next step's detection before finishing this one."""
         assert not self.training
         sync = torch.cuda.synchronize if time_cost.get("_sync") else (lambda: None)
         t0 = time.time()
@@ -114,22 +120,38 @@ class GoMatching:
             t0 = time.time()
             re = self.roi_heads.rescoring_head(out["query_features"])
             sync(); time_cost["rescore"] += time.time() - t0
-        return self._detect_and_embed(out, re, len(batched_inputs), hw, time_cost)
-
-    def _detect_and_embed(self, out, re, B, hw, time_cost):
         T = self.cfg.MODEL.TRANSFORMER
-        nq, P = T.NUM_QUERIES, T.NUM_POINTS
+        B, nq, P = len(batched_inputs), T.NUM_QUERIES, T.NUM_POINTS
         recs = ops.argmax_rows(out["pred_text_logits"])
         det = ops.detect_post(out["pred_logits"], re, out["pred_ctrl_points"], out["pred_bd_points"], recs, B, nq, P,
                               hw[0], hw[1], self.test_score_threshold, self.nms_thresh,
                               self.roi_heads.asso_thresh_test)
+        host = torch.empty(det["small"].shape, dtype=torch.int32, pin_memory=True)
+        host.copy_(det["small"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return {"query_features": out["query_features"], "det": det, "host": host, "event": ev, "B": B, "hw": hw}
+
+    def detect_finish(self, h, time_cost):
+        """Second half: wait for the step's event (the one host sync of the step), embed the kept detections
+        (FCHead4Query into the re-id pool) and build the per-frame Instances.  Runs on the CURRENT stream, which
+        may differ from the one `detect_launch` used (it is made to wait on the event)."""
+        det, B, hw = h["det"], h["B"], h["hw"]
+        T = self.cfg.MODEL.TRANSFORMER
+        nq, P = T.NUM_QUERIES, T.NUM_POINTS
         t0 = time.time()
-        small = det["small"].cpu().numpy()                    # the one host sync (and D2H copy) of the step
+        cur = torch.cuda.current_stream()
+        cur.wait_event(h["event"])
+        h["event"].synchronize()
+        for tns in (h["query_features"], det["small"], det["ctrl"], det["bd"], det["recs"]):
+            tns.record_stream(cur)
+        small = h["host"].numpy()
         o1, o2, o3 = det["small_layout"]
         counts = small[:o1]
         keep = small[o1:o2].reshape(B, nq)
         scores_h = small[o2:o3].view(np.float32).reshape(B, nq)
         boxes_h = small[o3:].view(np.float32).reshape(B, nq, 4)
+        out = {"query_features": h["query_features"]}
         n_total = int(counts.sum())
         rows = np.concatenate([keep[b, :counts[b]] for b in range(B)]) if n_total else np.zeros((0,), np.int32)
         self._ensure_pool(n_total)
@@ -333,11 +355,33 @@ class GoMatching:
         return full_instances, id_count
 
     def batch_inference(self, batched_inputs, batch_id, id_count, instances, time_cost):
-        """gom_lstmatcher.py:366-403: detection runs per step of `frames_per_step` frames, the id recurrence
-        stays strictly per frame."""
+        """gom_lstmatcher.py:366-403.  Detection runs per step of `frames_per_step` same-size frames on the current
+        stream; the id recurrence stays strictly per frame and runs on a second (high-priority) stream, so the
+        tracker of step j (host bookkeeping + small kernels + syncs) overlaps the detector of step j+1."""
         self.begin_batch(instances, len(batched_inputs))
-        dets = self.detect_steps(batched_inputs, time_cost)
-        return self.track_frames(dets, batch_id, id_count, instances, time_cost)
+        steps = self._steps(batched_inputs)
+        if not steps:
+            return instances, id_count
+        main, trk = torch.cuda.current_stream(), self._tracker_stream()
+        h = self.detect_launch(batched_inputs[steps[0][0]:steps[0][1]], time_cost)
+        offset = 0
+        for j in range(len(steps)):
+            h_next = None
+            if j + 1 < len(steps):
+                h_next = self.detect_launch(batched_inputs[steps[j + 1][0]:steps[j + 1][1]], time_cost)
+            with torch.cuda.stream(trk):
+                dets = self.detect_finish(h, time_cost)
+                instances, id_count = self.track_frames(dets, batch_id, id_count, instances, time_cost,
+                                                        frame_offset=offset)
+            offset += len(dets)
+            h = h_next
+        main.wait_stream(trk)
+        return instances, id_count
+
+    def _tracker_stream(self):
+        if getattr(self, "_trk_stream", None) is None:
+            self._trk_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        return self._trk_stream
 
     def begin_batch(self, instances, num_new_frames):
         """Keep the carried-over window's embeddings addressable, drop everything older, size the pool."""
@@ -350,25 +394,32 @@ class GoMatching:
             self._reid_rows(x, np.ones((len(x),), bool))
         self._ensure_pool(num_new_frames * self.cfg.MODEL.TRANSFORMER.NUM_QUERIES)   # no re-allocation mid-batch
 
-    def detect_steps(self, batched_inputs, time_cost):
-        """Detection in steps of <= frames_per_step consecutive frames of ONE size (mixed-resolution clips, e.g.
+    def _steps(self, batched_inputs):
+        """[s0, s1) ranges of <= frames_per_step consecutive frames of ONE size (mixed-resolution clips, e.g.
         BASELINE config #5, simply start a new step at every size change)."""
         def size(x):
             return tuple(x["image"].shape[-2:]) if "image" in x else None
 
-        dets, s0, n = [], 0, len(batched_inputs)
+        steps, s0, n = [], 0, len(batched_inputs)
         while s0 < n:
             hw = size(batched_inputs[s0])
             s1 = s0 + 1
             while s1 < n and s1 - s0 < self.frames_per_step and size(batched_inputs[s1]) == hw:
                 s1 += 1
-            dets.extend(self.inference(batched_inputs[s0:s1], time_cost))
+            steps.append((s0, s1))
             s0 = s1
+        return steps
+
+    def detect_steps(self, batched_inputs, time_cost):
+        dets = []
+        for s0, s1 in self._steps(batched_inputs):
+            dets.extend(self.inference(batched_inputs[s0:s1], time_cost))
         return dets
 
-    def track_frames(self, dets, batch_id, id_count, instances, time_cost):
-        """The per-frame id recurrence of gom_lstmatcher.py:369-403 over already detected frames."""
-        start_frame_id = batch_id * 100
+    def track_frames(self, dets, batch_id, id_count, instances, time_cost, frame_offset=0):
+        """The per-frame id recurrence of gom_lstmatcher.py:369-403 over already detected frames
+        (`frame_offset` = number of this batch's frames already tracked by earlier calls)."""
+        start_frame_id = batch_id * 100 + frame_offset
         t0 = time.time()
         base = len(instances)
         window = ([instances[-1]] if base else []) + list(dets)

@@ -123,3 +123,32 @@ def boundary_to_polygon(bd):
     bd = np.asarray(bd)
     top, bottom = np.hsplit(bd, 2)
     return np.vstack([top, bottom[::-1]])
+
+
+class ClipPipeline:
+    """Depth-1 software pipeline over consecutive steps (clips or batches of a stream): the detector of step i+1
+    is queued on the caller's stream BEFORE the tracker of step i runs on the model's tracker stream, so the
+    tracker's host bookkeeping, small kernels and syncs hide under the next step's detection.
+    `finish(handle)` receives a `GoMatching.detect_launch` handle and returns the step's result."""
+
+    def __init__(self, model, finish):
+        self.model, self.finish, self.pending = model, finish, None
+
+    def _run(self, h):
+        trk = self.model._tracker_stream()
+        with torch.cuda.stream(trk):
+            res = self.finish(h)
+        trk.synchronize()
+        return res
+
+    def push(self, inputs, time_cost):
+        """Queue detection of `inputs`; returns the result of the PREVIOUS step (None for the first)."""
+        h = self.model.detect_launch(inputs, time_cost)
+        res = self._run(self.pending) if self.pending is not None else None
+        self.pending = h
+        return res
+
+    def flush(self):
+        res = self._run(self.pending) if self.pending is not None else None
+        self.pending = None
+        return res
