@@ -70,6 +70,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own libamdhip64; loading ours before it would put two HIP runtimes in the process
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise GomError("libgomatching_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(expected at %s)" % LIB_PATH)
