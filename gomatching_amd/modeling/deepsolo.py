@@ -160,14 +160,6 @@ class DeepSolo:
         return self._invalid_logit
 
     # --------------------------------------------------------------------------------- pieces
-    def _msda(self, W, query, query_pos, ref, value, geo, B, Lq):
-        """MSDeformAttn minus value_proj/output_proj (ms_deform_attn.py:136-151)."""
-        raw = ops.gemm(query, W["raw"][0], bias=W["raw"][1], A2=query_pos)
-        loc, w = ops.msda_prepare(raw, ref, geo["shapes"])
-        S = geo["S"]
-        return ops.ms_deform_attn_forward(value.view(B, S, 8, 32), geo["shapes"], geo["lsi"],
-                                          loc.view(B, Lq, 8, 4, 4, 2), w.view(B, Lq, 8, 4, 4)).view(B * Lq, 256)
-
     def input_tokens(self, feats, B):
         """A4 + A5: input_proj (conv + GroupNorm) of the 3 backbone levels + the stride-2 extra level,
         written level by level into the flattened token buffer."""

@@ -47,10 +47,6 @@ def _chk_f32(*ts):
                 t.dtype, t.device, t.is_contiguous()))
 
 
-def empty(shape, like=None, dtype=_f32, device=None):
-    return torch.empty(shape, dtype=dtype, device=device if device is not None else like.device)
-
-
 # ------------------------------------------------------------------------------------------ GEMM
 # "bf16x6": weights of the big contractions are pre-split into three bf16 planes and multiplied on the bf16
 # matrix cores with fp32-level accuracy (csrc/gemm_bf16x6.hip); "fp32": exact-fp32 MFMA everywhere.
