@@ -36,6 +36,11 @@ SIGNATURES = {
     "gom_layernorm_f32": (I, [P, P, P, P, P, L, I, F, P]),
     "gom_groupnorm32_nhwc_f32": (I, [P, P, P, P, P, L, I, I, I, F, P]),
     "gom_mha_core_f32": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.POINTER(c_long), P]),
+    "gom_resample_ksize_bilinear": (I, [I, I]),
+    "gom_resample_coeffs_bilinear": (I, [I, I, P, P, I]),
+    "gom_resize_bilinear_u8_hwc3": (I, [P, I, I, I, P, P, I, P, P, I, P, I, I, I, P]),
+    "gom_ingest_u8_hwc3_to_nhwc4": (I, [P, I, I, I, P, P, I, P, P, I, ctypes.POINTER(c_float),
+                                        ctypes.POINTER(c_float), P, I, I, I, P]),
     "gom_preprocess_nchw_to_nhwc4": (I, [P, ctypes.POINTER(c_float), ctypes.POINTER(c_float), P, I, I, I, P]),
     "gom_maxpool3x3s2_nhwc_f32": (I, [P, P, I, I, I, I, P]),
     "gom_pos_encoding_2d_f32": (I, [P, P, P, I, I, P]),

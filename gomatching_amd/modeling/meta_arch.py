@@ -78,7 +78,20 @@ class GoMatching:
 
     # ------------------------------------------------------------------------------------ detection
     def preprocess_image(self, batched_inputs):
-        """gom_lstmatcher.py:164-170 for same-size frames: normalise + channels-last (no padding needed)."""
+        """gom_lstmatcher.py:164-170 for same-size frames: normalise + channels-last (no padding needed).
+        Inputs carry either the reference's `image` (f32 [3,H,W], already resized) or -- the device ingest of
+        SURVEY §8-f2 -- `frame_u8` (u8 [H0,W0,3] as read from disk) + `resize_hw` (+ `flip_channels`), in which
+        case resize/flip/float conversion/normalisation run as one kernel (`ops.ingest`)."""
+        if "frame_u8" in batched_inputs[0]:
+            first = batched_inputs[0]
+            hw, flip = tuple(first["resize_hw"]), bool(first.get("flip_channels", False))
+            frames = [x["frame_u8"] for x in batched_inputs]
+            for x in batched_inputs:
+                if tuple(x["resize_hw"]) != hw or tuple(x["frame_u8"].shape) != tuple(frames[0].shape) \
+                        or bool(x.get("flip_channels", False)) != flip:
+                    raise ValueError("frames of one step must share source size, target size and channel order")
+            u8 = torch.stack([f.to(self.device, non_blocking=True) for f in frames]).contiguous()
+            return ops.ingest(u8, hw[0], hw[1], self.pixel_mean, self.pixel_std, flip), hw
         imgs = [x["image"] for x in batched_inputs]
         hw = tuple(imgs[0].shape[-2:])
         for im in imgs:
@@ -398,6 +411,8 @@ class GoMatching:
         """[s0, s1) ranges of <= frames_per_step consecutive frames of ONE size (mixed-resolution clips, e.g.
         BASELINE config #5, simply start a new step at every size change)."""
         def size(x):
+            if "frame_u8" in x:
+                return tuple(x["frame_u8"].shape[:2]) + tuple(x["resize_hw"]) + (bool(x.get("flip_channels", False)),)
             return tuple(x["image"].shape[-2:]) if "image" in x else None
 
         steps, s0, n = [], 0, len(batched_inputs)

@@ -294,6 +294,57 @@ def preprocess(images, mean, std):
     return out
 
 
+_resample_tables = {}
+
+
+def resample_tables(in_size, out_size, device):
+    """Pillow-bilinear coefficient tables of one axis on `device` (cached): (bounds i32 [out,2], kk i32 [out,ks], ks)."""
+    key = (in_size, out_size, str(device))
+    hit = _resample_tables.get(key)
+    if hit is None:
+        ks = _L().gom_resample_ksize_bilinear(in_size, out_size)
+        if ks <= 0:
+            raise ValueError("bad resample sizes %d -> %d" % (in_size, out_size))
+        bounds = torch.empty((out_size, 2), dtype=torch.int32)
+        kk = torch.empty((out_size, ks), dtype=torch.int32)
+        check(_L().gom_resample_coeffs_bilinear(in_size, out_size, _p(bounds), _p(kk), ks), "gom_resample_coeffs")
+        hit = (bounds.to(device), kk.to(device), ks)
+        _resample_tables[key] = hit
+    return hit
+
+
+def _chk_frames(frames):
+    if frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous() or frames.dim() != 4 \
+            or frames.shape[3] != 3:
+        raise ValueError("frames must be a contiguous CUDA uint8 [B,H,W,3] tensor")
+
+
+def resize_u8(frames, out_h, out_w, flip=False):
+    """[B,H,W,3] u8 -> [B,out_h,out_w,3] u8, bit-exact with PIL.Image.resize(BILINEAR)."""
+    _chk_frames(frames)
+    B, H, W, _ = frames.shape
+    xb, xk, xks = resample_tables(W, out_w, frames.device)
+    yb, yk, yks = resample_tables(H, out_h, frames.device)
+    out = torch.empty((B, out_h, out_w, 3), dtype=torch.uint8, device=frames.device)
+    check(_L().gom_resize_bilinear_u8_hwc3(_p(frames), B, H, W, _p(xb), _p(xk), xks, _p(yb), _p(yk), yks, _p(out),
+                                           out_h, out_w, int(flip), _stream()), "gom_resize_bilinear_u8_hwc3")
+    return out
+
+
+def ingest(frames, out_h, out_w, mean, std, flip):
+    """[B,H,W,3] u8 frames -> normalised [B,out_h,out_w,4] f32 backbone input (resize + flip + (x-mean)/std)."""
+    _chk_frames(frames)
+    B, H, W, _ = frames.shape
+    xb, xk, xks = resample_tables(W, out_w, frames.device)
+    yb, yk, yks = resample_tables(H, out_h, frames.device)
+    out = torch.empty((B, out_h, out_w, 4), dtype=_f32, device=frames.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    check(_L().gom_ingest_u8_hwc3_to_nhwc4(_p(frames), B, H, W, _p(xb), _p(xk), xks, _p(yb), _p(yk), yks, m, s,
+                                           _p(out), out_h, out_w, int(flip), _stream()), "gom_ingest_u8_hwc3_to_nhwc4")
+    return out
+
+
 def maxpool3x3s2(x):
     _chk_f32(x)
     B, H, W, C = x.shape

@@ -122,6 +122,22 @@ int gom_mha_core_f32(const float* q, const float* k, const float* v, float* o, i
 /* mean3/std3 are [host] arrays.  images [B,3,H,W] -> out [B,H,W,4] (4th channel 0). */
 int gom_preprocess_nchw_to_nhwc4(const float* images, const float* mean3, const float* std3, float* out, int B, int H,
                                  int W, void* stream);
+/* ---- f2: frame ingest (text_track_visualizer.py:315-324 + gom_lstmatcher.py:159-170) -----------------------
+ * Replaces the host-side `aug.get_transform(frame).apply_image(frame)` (Detectron2 ResizeShortestEdge ->
+ * Pillow Image.resize(BILINEAR) on uint8), the BGR->RGB flip (:316-318), `astype("float32")` (:321) and
+ * the model's normaliser for uint8 frames resident in HBM.  Bit-exact with Pillow's fixed-point resampler.
+ * Coefficient tables come from the [host] helper (Pillow Resample.c precompute_coeffs/normalize_coeffs_8bpc):
+ * bounds [out,2] = (first tap, tap count), kk [out,ksize] 22-bit fixed point; upload both before the launch. */
+int gom_resample_ksize_bilinear(int in_size, int out_size);                        /* [host], -1 on bad sizes */
+int gom_resample_coeffs_bilinear(int in_size, int out_size, int* bounds, int* kk, int ksize);   /* [host] */
+/* src [B,H,W,3] u8 -> dst [B,OH,OW,3] u8 (flip_channels != 0 swaps channels 0 and 2). */
+int gom_resize_bilinear_u8_hwc3(const uint8_t* src, int B, int H, int W, const int* xbounds, const int* xkk,
+                                int xksize, const int* ybounds, const int* ykk, int yksize, uint8_t* dst, int OH,
+                                int OW, int flip_channels, void* stream);
+/* src [B,H,W,3] u8 -> dst [B,OH,OW,4] f32 = (resized[flipped] - mean) / std, 4th channel 0 (the stem's layout). */
+int gom_ingest_u8_hwc3_to_nhwc4(const uint8_t* src, int B, int H, int W, const int* xbounds, const int* xkk,
+                                int xksize, const int* ybounds, const int* ykk, int yksize, const float* mean3,
+                                const float* std3, float* dst, int OH, int OW, int flip_channels, void* stream);
 int gom_maxpool3x3s2_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, void* stream);
 /* out [H*W, 256] = PositionalEncoding2D(normalize=True) + level_embed, for an unpadded H x W level. */
 int gom_pos_encoding_2d_f32(const float* dim_t128, const float* level_embed256, float* out, int H, int W,
