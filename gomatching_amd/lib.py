@@ -33,6 +33,9 @@ SIGNATURES = {
     "gom_split_bf16x3": (I, [P, I, I, I, P, I, P]),
     "gom_gemm_f32_bf16x6": (I, [P, P, I, P, L, I, P, P, P, I, I, I, P, I, I, I, I, P]),
     "gom_conv2d_nhwc_f32_bf16x6": (I, [P, P, L, I, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P]),
+    "gom_gemm_small_f32": (I, [P, P, I, P, I, P, P, P, I, I, P, I, I, I, I, P]),
+    "gom_split_rows_bf16x3": (I, [P, L, L, I, P, I, L, P]),
+    "gom_gemm_planes_bf16x6": (I, [P, L, I, P, L, I, P, P, P, I, I, I, P, I, P, L, I, I, I, I, P]),
     "gom_layernorm_f32": (I, [P, P, P, P, P, L, I, F, P]),
     "gom_groupnorm32_nhwc_f32": (I, [P, P, P, P, P, L, I, I, I, F, P]),
     "gom_mha_core_f32": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.POINTER(c_long), P]),
@@ -59,6 +62,8 @@ SIGNATURES = {
     "gom_gather_rows_f32": (I, [P, P, P, I, I, P]),
     "gom_asso_activate_f32": (I, [P, I, P, I, I, P, I, P]),
     "gom_track_score_f32": (I, [P, I, P, P, P, F, F, I, I, I, I, F, P, P]),
+    "gom_match_workspace_floats": (L, [I, I, I, I]),
+    "gom_match_scores_f32": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
     "gom_linear_sum_assignment": (I, [ctypes.POINTER(ctypes.c_double), L, L, ctypes.POINTER(c_long),
                                       ctypes.POINTER(c_long)]),
 }

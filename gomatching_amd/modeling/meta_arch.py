@@ -212,9 +212,50 @@ class GoMatching:
         return g
 
     def _set_ids(self, inst, ids):
-        ids = np.asarray(ids, dtype=np.int64)
-        self._host(inst)["ids"] = ids
-        inst._fields["track_ids"] = torch.from_numpy(ids.copy()).to(self.device)
+        """Inside `track_frames` ids live on the host while the recurrence runs and `_flush_ids` uploads them once."""
+        g = self._host(inst)
+        g["ids"] = np.asarray(ids, dtype=np.int64)
+        g["ids_dirty"] = True
+        if not getattr(self, "_defer_ids", False):               # direct callers of run_*_match get device ids at once
+            self._flush_ids([inst])
+
+    def _flush_ids(self, instances):
+        """One packed host->device copy of every frame whose ids changed; `track_ids` become views of it."""
+        dirty = [x for x in instances if getattr(x, "_gom", None) is not None and x._gom.get("ids_dirty")]
+        if not dirty:
+            return
+        flat = self._h2d(np.concatenate([x._gom["ids"] for x in dirty]).astype(np.int64))
+        o = 0
+        for x in dirty:
+            n = len(x._gom["ids"])
+            x._fields["track_ids"] = flat[o:o + n]
+            x._gom["ids_dirty"] = False
+            o += n
+
+    def _h2d(self, arr):
+        """numpy -> device through a pinned staging ring (a pageable copy costs ~40 us and stalls the stream; the
+        tracker issues one per match).  A slot is rewritten only after the event recorded behind its last copy."""
+        arr = np.ascontiguousarray(arr)
+        t = torch.from_numpy(arr)
+        nbytes = arr.nbytes
+        if nbytes == 0:
+            return t.to(self.device)
+        ring = getattr(self, "_pin_ring", None)
+        if ring is None or ring[0][0].numel() < nbytes:
+            cap = max(1 << 16, 2 * nbytes)
+            ring = [[torch.empty((cap,), dtype=torch.uint8, pin_memory=True), None] for _ in range(4)]
+            self._pin_ring, self._pin_next = ring, 0            # old slots stay alive until their copies retire
+        slot = ring[self._pin_next]
+        self._pin_next = (self._pin_next + 1) % len(ring)
+        if slot[1] is not None:
+            slot[1].synchronize()
+        host = slot[0][:nbytes].view(t.dtype).view(t.shape)
+        host.copy_(t)
+        dev = host.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        slot[1] = ev
+        return dev
 
     def _reid_rows(self, inst, sel):
         """Pool rows of the selected detections of one frame (re-homes foreign features into the pool)."""
@@ -269,14 +310,12 @@ class GoMatching:
             dec = np.power(np.float32(self.decay_time), dts).astype(np.float32)
         # one packed host->device copy per match: rows | frame offsets | meta | boxes (f32 bits) | decay (f32 bits)
         parts = [rows, offs, meta, boxes.reshape(-1).view(np.int32)] + ([dec.view(np.int32)] if dec is not None else [])
-        buf = torch.from_numpy(np.concatenate(parts)).to(self.device)
+        buf = self._h2d(np.concatenate(parts))
         o0 = len(rows); o1 = o0 + len(offs); o2 = o1 + len(meta); o3 = o2 + 4 * N
-        src = ops.gather_rows(self._pool, buf[:o0])
-        asso = self.roi_heads._forward_transformer(src, n_t, k, short_term=short_term)
-        act = ops.asso_activate(asso, buf[o0:o1], T)
-        traj = ops.track_score(act, buf[o1:o2], buf[o3:].view(torch.float32) if dec is not None else None,
-                               buf[o2:o3].view(torch.float32), hw[1], hw[0], n_k, Np, M, self.with_iou,
-                               self.max_center_dist if not short_term else 0.0)
+        traj = self.roi_heads.match_scores(self._pool, buf[:o0], buf[o0:o1], buf[o1:o2], buf[o2:o3].view(torch.float32),
+                                           buf[o3:].view(torch.float32) if dec is not None else None, n_t, k,
+                                           short_term, hw, M, self.with_iou,
+                                           self.max_center_dist if not short_term else 0.0)
         return traj.cpu().numpy(), uniq
 
     def _assign(self, traj, uniq, ids_nonk, n_k):
@@ -308,7 +347,7 @@ class GoMatching:
         if not pairs:
             return {}
         rows_d = torch.from_numpy(np.concatenate(rows).astype(np.int32)).to(self.device)
-        boxes_d = torch.from_numpy(np.concatenate(boxes).astype(np.float32)).to(self.device)
+        boxes_d = torch.from_numpy(np.concatenate(boxes).astype(np.float32)).to(self.device)     # once per call: pageable
         src_all = ops.gather_rows(self._pool, rows_d)
         scores = self.roi_heads.short_term_scores(src_all, pairs, boxes_d, frames[1].image_size)
         flat = torch.cat([s.reshape(-1) for s in scores]).cpu().numpy()      # the one sync of the short-term path
@@ -441,35 +480,40 @@ class GoMatching:
         st = self.precompute_short_term(window)                  # keyed by index into `window`
         shift = 1 if base else 0
         time_cost["short_match"] += time.time() - t0
-        for frame_id in range(len(dets)):
-            instances.append(dets[frame_id])
-            real_frame_id = start_frame_id + frame_id
-            S = st.get(frame_id + shift)
-            if real_frame_id == 0:
-                n0 = len(instances[0])
-                self._set_ids(instances[0], np.arange(1, n0 + 1))
-                id_count = n0 + 1
-            elif real_frame_id == 1:
-                t0 = time.time()
-                instances[0:2], id_count = self.run_short_term_match(instances[0:2], id_count=id_count, S=S)
-                time_cost["short_match"] += time.time() - t0
-            else:
-                t0 = time.time()
-                instances[real_frame_id - 1: real_frame_id + 1], cur_id = self.run_short_term_match(
-                    instances[real_frame_id - 1: real_frame_id + 1], S=S)
-                time_cost["short_match"] += time.time() - t0
-                if -1 in cur_id:
-                    win_st = max(0, real_frame_id + 1 - self.test_len)
-                    win_ed = real_frame_id + 1
+        self._defer_ids = True
+        try:
+            for frame_id in range(len(dets)):
+                instances.append(dets[frame_id])
+                real_frame_id = start_frame_id + frame_id
+                S = st.get(frame_id + shift)
+                if real_frame_id == 0:
+                    n0 = len(instances[0])
+                    self._set_ids(instances[0], np.arange(1, n0 + 1))
+                    id_count = n0 + 1
+                elif real_frame_id == 1:
                     t0 = time.time()
-                    instances[win_st:win_ed], id_count = self.run_long_term_match(
-                        instances[win_st:win_ed], k=min(self.test_len - 1, real_frame_id), id_count=id_count,
-                        cur_id=cur_id)
-                    time_cost["long_match"] += time.time() - t0
-            ids = self._host(instances[-1])["ids"]
-            assert len(ids) == len(np.unique(ids))
-            if real_frame_id - self.test_len >= 0:
-                instances[real_frame_id - self.test_len].remove("reid_features")
+                    instances[0:2], id_count = self.run_short_term_match(instances[0:2], id_count=id_count, S=S)
+                    time_cost["short_match"] += time.time() - t0
+                else:
+                    t0 = time.time()
+                    instances[real_frame_id - 1: real_frame_id + 1], cur_id = self.run_short_term_match(
+                        instances[real_frame_id - 1: real_frame_id + 1], S=S)
+                    time_cost["short_match"] += time.time() - t0
+                    if -1 in cur_id:
+                        win_st = max(0, real_frame_id + 1 - self.test_len)
+                        win_ed = real_frame_id + 1
+                        t0 = time.time()
+                        instances[win_st:win_ed], id_count = self.run_long_term_match(
+                            instances[win_st:win_ed], k=min(self.test_len - 1, real_frame_id), id_count=id_count,
+                            cur_id=cur_id)
+                        time_cost["long_match"] += time.time() - t0
+                ids = self._host(instances[-1])["ids"]
+                assert len(ids) == len(np.unique(ids))
+                if real_frame_id - self.test_len >= 0:
+                    instances[real_frame_id - self.test_len].remove("reid_features")
+        finally:
+            self._defer_ids = False
+        self._flush_ids(dets)
         return instances, id_count
 
     def _remove_short_track(self, instances):

@@ -7,6 +7,7 @@ Only the shipped-config shape is built (NUM_WEIGHT_LAYERS 0 -> bare dot-product 
 NORM False, NO_DECODER_SELF_ATT): other shapes raise at construction.  Training methods
 (`loss_res`, `_get_asso_gt`, `detr_asso_loss`) are out of scope.
 """
+import numpy as np
 import torch
 
 from .. import ops
@@ -40,6 +41,9 @@ class _MatcherTransformer:
                 L["lin1"] = (g(p + "linear1.weight"), g(p + "linear1.bias"))
                 L["lin2"] = (g(p + "linear2.weight"), g(p + "linear2.bias"))
             self.dec.append(L)
+        self.ffn = self.enc[0]["lin1"][0].shape[0] if self.enc else \
+            (self.dec[0]["lin1"][0].shape[0] if self.dec and "lin1" in self.dec[0] else 0)
+        self._enc_c, self._dec_c = ops.matcher_layers(self.enc), ops.matcher_layers(self.dec)   # native-runtime view
 
     def _attend(self, q, k, v, ld_q, ld_kv, Lq, Lk):
         out = torch.empty((Lq, self.d), dtype=_f32, device=q.device)
@@ -53,24 +57,24 @@ class _MatcherTransformer:
         N, E = src.shape
         memory = src
         for L in self.enc:                                   # forward_post, norms = Identity (transformer.py:180-195)
-            qkv = ops.gemm(memory, L["in"][0], bias=L["in"][1])                       # [N, 3E]
+            qkv = ops.gemm(memory, L["in"][0], bias=L["in"][1], small=True)                       # [N, 3E]
             f = qkv.view(-1)
             a = self._attend(f, f[E:], f[2 * E:], 3 * E, 3 * E, N, N)
-            memory = ops.gemm(a, L["out"][0], bias=L["out"][1], R=memory)
-            h = ops.gemm(memory, L["lin1"][0], bias=L["lin1"][1], relu=True)
-            memory = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=memory)
+            memory = ops.gemm(a, L["out"][0], bias=L["out"][1], R=memory, small=True)
+            h = ops.gemm(memory, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True)
+            memory = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=memory, small=True)
         tgt = src[lo:hi]                                     # tgt = src[query_inds] (transformer.py:80-84)
         M = hi - lo
         for L in self.dec:                                   # no decoder self-attention (transformer.py:270-294)
             w, b = L["in"]
-            q = ops.gemm(tgt, w[:E], bias=b[:E])
-            kv = ops.gemm(memory, w[E:], bias=b[E:])                                  # [N, 2E]
+            q = ops.gemm(tgt, w[:E], bias=b[:E], small=True)
+            kv = ops.gemm(memory, w[E:], bias=b[E:], small=True)                                  # [N, 2E]
             f = kv.view(-1)
             a = self._attend(q, f, f[E:], E, 2 * E, M, N)
-            tgt = ops.gemm(a, L["out"][0], bias=L["out"][1], R=tgt)
+            tgt = ops.gemm(a, L["out"][0], bias=L["out"][1], R=tgt, small=True)
             if not self.only_crs:
-                h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True)
-                tgt = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt)
+                h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True)
+                tgt = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt, small=True)
         return tgt, memory
 
 
@@ -84,15 +88,15 @@ class _MatcherTransformer:
         Nall = src_all.shape[0]
         memory = src_all
         for L in self.enc:
-            qkv = ops.gemm(memory, L["in"][0], bias=L["in"][1])
+            qkv = ops.gemm(memory, L["in"][0], bias=L["in"][1], small=True)
             a = torch.empty((Nall, E), dtype=_f32, device=src_all.device)
             for off, n_prev, n_cur in pairs:
                 n = n_prev + n_cur
                 f = qkv[off:off + n].view(-1)
                 self._attend_into(a[off:off + n], f, f[E:], f[2 * E:], 3 * E, 3 * E, n, n)
-            memory = ops.gemm(a, L["out"][0], bias=L["out"][1], R=memory)
-            h = ops.gemm(memory, L["lin1"][0], bias=L["lin1"][1], relu=True)
-            memory = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=memory)
+            memory = ops.gemm(a, L["out"][0], bias=L["out"][1], R=memory, small=True)
+            h = ops.gemm(memory, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True)
+            memory = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=memory, small=True)
         cur_rows = torch.cat([torch.arange(off + n_prev, off + n_prev + n_cur, dtype=torch.int32)
                               for off, n_prev, n_cur in pairs]).to(src_all.device)
         tgt = ops.gather_rows(src_all, cur_rows)
@@ -102,19 +106,19 @@ class _MatcherTransformer:
             cur_off.append(cur_off[-1] + n_cur)
         for L in self.dec:
             w, b = L["in"]
-            q = ops.gemm(tgt, w[:E], bias=b[:E])
-            kv = ops.gemm(memory, w[E:], bias=b[E:])
+            q = ops.gemm(tgt, w[:E], bias=b[:E], small=True)
+            kv = ops.gemm(memory, w[E:], bias=b[E:], small=True)
             a = torch.empty((M, E), dtype=_f32, device=src_all.device)
             for i, (off, n_prev, n_cur) in enumerate(pairs):
                 n = n_prev + n_cur
                 f = kv[off:off + n].view(-1)
                 self._attend_into(a[cur_off[i]:cur_off[i + 1]], q[cur_off[i]:cur_off[i + 1]], f, f[E:], E, 2 * E,
                                   n_cur, n)
-            tgt = ops.gemm(a, L["out"][0], bias=L["out"][1], R=tgt)
+            tgt = ops.gemm(a, L["out"][0], bias=L["out"][1], R=tgt, small=True)
             if not self.only_crs:
-                h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True)
-                tgt = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt)
-        return [ops.gemm(tgt[cur_off[i]:cur_off[i + 1]], memory[off:off + n_prev + n_cur])
+                h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True)
+                tgt = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt, small=True)
+        return [ops.gemm(tgt[cur_off[i]:cur_off[i + 1]], memory[off:off + n_prev + n_cur], small=True)
                 for i, (off, n_prev, n_cur) in enumerate(pairs)]
 
     def _attend_into(self, out, q, k, v, ld_q, ld_kv, Lq, Lk):
@@ -157,7 +161,25 @@ class _MatcherBase:
         """lstmatcher.py:333-370 (eval; no positional/temporal embedding): returns asso logits [n_k, N]."""
         lo, hi = sum(n_t[:query_frame]), sum(n_t[:query_frame + 1])
         feats, memory = self._matcher(short_term).forward(reid_features, lo, hi)
-        return ops.gemm(feats, memory)                        # ATTWeightHead with 0 layers: q . k^T
+        return ops.gemm(feats, memory, small=True)            # ATTWeightHead with 0 layers: q . k^T
+
+    def match_scores(self, pool, rows, frame_offsets, meta, boxes, decay, n_t, query_frame, short_term, hw, num_tracks,
+                     with_iou, max_center_dist):
+        """Device side of one match (gom_lstmatcher.py:405-445 / 467-547 minus the host LSA): trajectory scores
+        [n_k, num_tracks] of frame `query_frame`'s selected detections.  One native call (csrc/matcher_rt.cpp), or --
+        ops.NATIVE_MATCHER = False -- the same chain composed kernel by kernel from Python; both give the same bits."""
+        N, T = sum(n_t), len(n_t)
+        lo, hi = sum(n_t[:query_frame]), sum(n_t[:query_frame + 1])
+        m = self._matcher(short_term)
+        if ops.NATIVE_MATCHER:
+            return ops.match_scores(pool, rows, frame_offsets, meta, boxes, decay, N, T, lo, hi, num_tracks, m._enc_c,
+                                    len(m.enc), m._dec_c, len(m.dec), m.d, m.heads, m.ffn, hw[1], hw[0], with_iou,
+                                    max_center_dist)
+        src = ops.gather_rows(pool, rows)
+        asso = self._forward_transformer(src, n_t, query_frame, short_term=short_term)
+        act = ops.asso_activate(asso, frame_offsets, T)
+        return ops.track_score(act, meta, decay, boxes, hw[1], hw[0], hi - lo, N - (hi - lo), num_tracks, with_iou,
+                               max_center_dist)
 
     def short_term_scores(self, src_all, pairs, boxes_all, image_size):
         """For every (prev, cur) pair: S[i, j] = max(activated association of cur i with prev j, IoU(i, j)).
@@ -166,14 +188,22 @@ class _MatcherBase:
         whole device side of short-term matching is id-independent and is done here for all pairs at once.
         boxes_all [sum N_p, 4] px, same row order as src_all.  Returns a list of device tensors [n_cur, n_prev]."""
         logits = self._matcher(True).forward_pairs(src_all, pairs)
+        # one packed host->device copy of every pair's frame offsets and (nonk | col_of | last | k) index lists
+        parts, where, o = [], [], 0
+        for off, n_prev, n_cur in pairs:
+            ident = np.arange(n_prev, dtype=np.int32)
+            p = np.concatenate([np.array([0, n_prev, n_prev + n_cur], np.int32), ident, ident, ident,
+                                np.arange(n_prev, n_prev + n_cur, dtype=np.int32)])
+            parts.append(p)
+            where.append(o)
+            o += len(p)
+        buf = torch.from_numpy(np.concatenate(parts)).to(self.device)
         out = []
-        for (off, n_prev, n_cur), lg in zip(pairs, logits):
-            act = self._activate_asso(lg, [n_prev, n_cur])
-            ident = list(range(n_prev))
-            meta = torch.tensor(ident + ident + ident + list(range(n_prev, n_prev + n_cur)), dtype=torch.int32)
-            out.append(ops.track_score(act, meta.to(self.device), None, boxes_all[off:off + n_prev + n_cur],
-                                       image_size[1], image_size[0], n_cur, n_prev, n_prev,
-                                       self.cfg.VIDEO_TEST.WITH_IOU, 0.0))
+        for (off, n_prev, n_cur), lg, o in zip(pairs, logits, where):
+            act = ops.asso_activate(lg, buf[o:o + 3], 2)
+            out.append(ops.track_score(act, buf[o + 3:o + 3 + 3 * n_prev + n_cur], None,
+                                       boxes_all[off:off + n_prev + n_cur], image_size[1], image_size[0], n_cur, n_prev,
+                                       n_prev, self.cfg.VIDEO_TEST.WITH_IOU, 0.0))
         return out
 
     def _activate_asso(self, asso_logits, n_t):

@@ -35,7 +35,13 @@ def _p(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw hipStream_t of torch's current stream; the private accessor costs ~0.3 us against ~8 us for
+    # torch.cuda.current_stream().cuda_stream, which matters on the launch-bound tracker path
+    return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or \
+    (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
 
 
 def _chk_f32(*ts):
@@ -120,8 +126,88 @@ def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols=None):
     return out
 
 
+SPLITK_MAX_ROWS = 1024
+SMALL_GEMM_OUTPUTS = 1 << 16         # M*N up to which gemm(..., small=True) runs one-wave-per-output (tracker logits)
+
+
+class Planes:
+    """An activation matrix [M, K] held as three bf16 planes [3, M, ld] (x = p0 + p1 + p2, the GEMM's own split)."""
+
+    def __init__(self, t, K):
+        assert t.dtype == torch.bfloat16 and t.dim() == 3 and t.shape[0] == 3 and t.stride(2) == 1
+        self.t, self.K = t, K
+
+    @property
+    def shape(self):
+        return (self.t.shape[1], self.K)
+
+    def rows(self, a, b):
+        return Planes(self.t[:, a:b], self.K)
+
+    def float(self):
+        return (self.t[0].float() + self.t[1].float() + self.t[2].float())[:, :self.K]
+
+
+def new_planes(M, K, device):
+    ld = (K + 31) // 32 * 32
+    return Planes(torch.empty((3, M, ld), dtype=torch.bfloat16, device=device), K)
+
+
+def split_rows(x, out=None):
+    """fp32 [M, K] (row-strided) -> Planes."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == _f32
+    M, K = x.shape
+    if out is None:
+        out = new_planes(M, K, x.device)
+    t = out.t
+    check(_L().gom_split_rows_bf16x3(_p(x), x.stride(0) if M > 1 else K, M, K, _p(t), t.stride(1), t.stride(0),
+                                     _stream()), "gom_split_rows_bf16x3")
+    return out
+
+
+def gemm_planes(A, W, bias=None, scale=None, R=None, relu=False, out=None, out_planes=None, r_cols=None,
+                want="f32"):
+    """C = act(A @ W^T * scale + bias + R) with A a `Planes` and W a `SplitWeight`; `want` in {"f32","planes","both"}
+    selects fp32 rows and/or bf16 planes of the result (returned in that order)."""
+    assert isinstance(A, Planes) and isinstance(W, SplitWeight)
+    M, K = A.shape
+    N = W.N
+    assert W.K == K and K % 32 == 0 and N % 4 == 0
+    dev = A.t.device
+    if want in ("f32", "both") and out is None:
+        out = torch.empty((M, N), dtype=_f32, device=dev)
+    if want in ("planes", "both") and out_planes is None:
+        out_planes = new_planes(M, N, dev)
+    if want == "planes":
+        out = None
+    if want == "f32":
+        out_planes = None
+    ldc = (out.stride(0) if out.shape[0] > 1 else N) if out is not None else 0
+    ldr = (R.stride(0) if R.shape[0] > 1 else R.shape[1]) if R is not None else 0
+    rc = (r_cols if r_cols is not None else N) if R is not None else 0
+    pl, ap = W.planes, A.t
+    cp = out_planes.t if out_planes is not None else None
+    prof = _gemm_profile if (_gemm_profile is not None and M > 0) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().gom_gemm_planes_bf16x6(_p(ap), ap.stride(0), ap.stride(1), _p(pl), pl.stride(0), pl.stride(1),
+                                      _p(scale), _p(bias), _p(R), ldr, rc, 1 if relu else 0, _p(out), ldc,
+                                      _p(cp), cp.stride(0) if cp is not None else 0,
+                                      cp.stride(1) if cp is not None else 0, M, N, K, _stream()),
+          "gom_gemm_planes_bf16x6")
+    if prof is not None:
+        e1.record()
+        nbytes = 6.0 * M * K + 6.0 * N * pl.shape[2] + (4.0 * M * N if out is not None else 0.0) \
+            + (6.0 * M * N if cp is not None else 0.0) + (4.0 * M * rc if R is not None else 0.0)
+        prof.append((e0, e1, 2.0 * M * N * K, nbytes))
+    if want == "both":
+        return out, out_planes
+    return out if want == "f32" else out_planes
+
+
 def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, out=None, M=None, splitk=None,
-         r_cols=None):
+         r_cols=None, small=False):
     """C = act((A[+A2])[M,K] @ W[N,K]^T * scale + bias + R).  A may be a 2-D row-strided view
     (stride(1) == 1); W likewise (row slices of a weight matrix)."""
     if isinstance(W, SplitWeight):
@@ -160,6 +246,16 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
         ldr = R.stride(0) if R.shape[0] > 1 else N
     if rows is not None:
         assert rows.dtype == torch.int32 and rows.is_contiguous()
+    # `small` marks the tracker's latency-bound products (kernel choice must never depend on how many frames share a
+    # step, so this is an explicit request): up to SMALL_GEMM_OUTPUTS outputs one wave owns a column for 8 rows on the
+    # VALU (7-20 us); larger ones take the deterministic split-K (20-50 us) instead of looping the whole K in few
+    # workgroups (85-95 us whatever M is; tools/skinny_bench.py)
+    if small and A2 is None and M > 0:
+        if M * N <= SMALL_GEMM_OUTPUTS and K % 4 == 0 and lda % 4 == 0 and ldw % 4 == 0:
+            check(_L().gom_gemm_small_f32(_p(A), _p(rows), lda, _p(W), ldw, _p(scale), _p(bias), _p(R), ldr,
+                                          1 if relu else 0, _p(out), ldc, M, N, K, _stream()), "gom_gemm_small_f32")
+            return out
+        splitk = M <= SPLITK_MAX_ROWS                        # beyond that the partial sums cost more than they save
     if splitk is None:
         splitk = 0 < M <= 128 and N * K >= (1 << 18) and K >= 256      # skinny, weight-read bound
     if splitk and A2 is None and M > 0:
@@ -482,6 +578,42 @@ def track_score(act, meta, decay, boxes, img_w, img_h, n_k, Np, M, with_iou, max
     check(_L().gom_track_score_f32(_p(act), act.shape[1], _p(meta), _p(decay), _p(boxes), float(img_w), float(img_h),
                                    n_k, Np, M, 1 if with_iou else 0, float(max_center_dist), _p(traj), _stream()),
           "gom_track_score_f32")
+    return traj
+
+
+NATIVE_MATCHER = True      # False: compose the match from per-kernel calls in Python (kept for the A/B parity test)
+
+
+class MatcherLayer(ctypes.Structure):
+    """Mirror of `gom_matcher_layer` (include/gomatching_hip.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("in_w", "in_b", "out_w", "out_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b")]
+
+
+def matcher_layers(layers):
+    """layers: list of dicts {"in": (w, b), "out": (w, b), ["lin1": (w, b), "lin2": (w, b)]} of fp32 CUDA tensors ->
+    ctypes array for gom_match_scores_f32 (the tensors must outlive it: the caller keeps `layers`)."""
+    arr = (MatcherLayer * max(len(layers), 1))()
+    for i, L in enumerate(layers):
+        for key in ("in", "out", "lin1", "lin2"):
+            w, b = L.get(key, (None, None))
+            if w is not None:
+                _chk_f32(w, b)
+            setattr(arr[i], key + "_w", w.data_ptr() if w is not None else None)
+            setattr(arr[i], key + "_b", b.data_ptr() if b is not None else None)
+    return arr
+
+
+def match_scores(pool, rows, frame_offsets, meta, boxes, decay, N, T, lo, hi, num_tracks, enc, n_enc, dec, n_dec, d,
+                 heads, ffn, img_w, img_h, with_iou, max_center_dist):
+    """One FFI crossing for the whole device chain of a match (gom_match_scores_f32): returns traj [hi-lo, num_tracks]."""
+    n_k = hi - lo
+    nws = _L().gom_match_workspace_floats(N, n_k, d, ffn)
+    ws = torch.empty((nws,), dtype=_f32, device=pool.device)
+    traj = torch.empty((n_k, num_tracks), dtype=_f32, device=pool.device)
+    check(_L().gom_match_scores_f32(_p(pool), pool.stride(0), _p(rows), _p(frame_offsets), _p(meta), _p(boxes),
+                                    _p(decay), N, T, lo, hi, num_tracks, enc, n_enc, dec, n_dec, d, heads, ffn,
+                                    float(img_w), float(img_h), 1 if with_iou else 0, float(max_center_dist), _p(ws),
+                                    nws, _p(traj), _stream()), "gom_match_scores_f32")
     return traj
 
 

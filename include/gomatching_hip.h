@@ -90,6 +90,12 @@ int gom_conv2d_nhwc_f32(const float* X, const float* Wt, const float* scale, con
                         int relu, float* Y, int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride,
                         int pad, void* stream);
 
+/* Tiny products (tracker association logits tgt . memory^T, transformer.py:92-96; at most 2^22 outputs): one wave per
+ * output element on the VALU, K % 4 == 0, same epilogue as gom_gemm_f32 (no A2).  Deterministic. */
+int gom_gemm_small_f32(const float* A, const int* a_rows, int lda, const float* W, int ldw, const float* scale,
+                       const float* shift, const float* R, int ldr, int relu, float* C, int ldc, int M, int N, int K,
+                       void* stream);
+
 /* fp32-accurate variants on the bf16 matrix cores ("bf16x6": operands split into three bf16 planes, six MFMA
  * products of weight <= 2; error ~ one fp32 rounding per product; 2.67x the fp32 matrix rate).
  * The weight operand is pre-split once: planes_out [3][N][Kpad] bf16, Kpad a multiple of 32 (zero padded).
@@ -101,6 +107,18 @@ int gom_gemm_f32_bf16x6(const float* A, const int* a_rows, int lda, const void* 
 int gom_conv2d_nhwc_f32_bf16x6(const float* X, const void* Wplanes, long w_plane_stride, int ldw, const float* scale,
                                const float* shift, const float* R, int relu, float* Y, int B, int H, int Wd, int Cin,
                                int Cout, int KH, int KW, int stride, int pad, void* stream);
+
+/* Same product with the ACTIVATION operand already split: Aplanes [3][M][lda] bf16 written by a producer
+ * (gom_split_rows_bf16x3, or the plane outputs of gom_gemm_planes_bf16x6 / gom_layernorm_planes_f32 /
+ * gom_msda_fused_forward_planes).  Both operands stream HBM -> LDS by LDS-DMA, no in-loop VALU.  K % 32 == 0, N % 4 == 0.
+ * Output: fp32 C and/or bf16 planes Cplanes [3][M][ldcp] of the same epilogue value (either may be NULL, not both).
+ * Bit-identical to gom_gemm_f32_bf16x6 on the same values. */
+int gom_split_rows_bf16x3(const float* X, long ld_in, long M, int K, void* planes_out, int ld_out, long plane_stride,
+                          void* stream);
+int gom_gemm_planes_bf16x6(const void* Aplanes, long a_plane_stride, int lda, const void* Wplanes, long w_plane_stride,
+                           int ldw, const float* scale, const float* shift, const float* R, int ldr, int r_cols,
+                           int relu, float* C, int ldc, void* Cplanes, long c_plane_stride, int ldcp, int M, int N,
+                           int K, void* stream);
 
 /* ---- normalisation ---------------------------------------------------------------------------------*/
 /* out = LayerNorm(x + residual) * gamma + beta over rows of dim 256 or 1024 (residual may be NULL). */
@@ -186,6 +204,30 @@ int gom_asso_activate_f32(const float* logits, int ld, const int* frame_offsets,
 int gom_track_score_f32(const float* act, int ld, const int* meta, const float* decay, const float* boxes, float img_w,
                         float img_h, int n_k, int Np, int M, int with_iou, float max_center_dist, float* traj,
                         void* stream);
+/* [host runtime] The whole device chain of one association match -- gather of the window's embeddings, the matcher
+ * transformer (roi_heads/transformer.py:60-96: n_enc post-norm encoder layers over all N rows, n_dec cross-attention
+ * decoder layers for the query rows [lo, hi), norms Identity), q.k^T logits, `_activate_asso` (lstmatcher.py:373-381)
+ * and the trajectory score (gom_lstmatcher.py:429-445 / 510-547) -- queued on `stream` by ONE call.  Replaces ~18
+ * per-kernel FFI crossings of the launch-bound tracker recurrence.  Layer weights are nn.MultiheadAttention / Linear
+ * tensors as stored in the checkpoint (in_w [3d,d], out_w [d,d], lin1_w [ffn,d], lin2_w [d,ffn]; lin* NULL for the
+ * cross-attention-only decoder of SHA_FFN_CRSATTN).  workspace: device floats, gom_match_workspace_floats(...).
+ * traj [hi-lo, num_tracks] device. */
+typedef struct gom_matcher_layer {
+    const float* in_w;
+    const float* in_b;
+    const float* out_w;
+    const float* out_b;
+    const float* lin1_w;
+    const float* lin1_b;
+    const float* lin2_w;
+    const float* lin2_b;
+} gom_matcher_layer;
+long gom_match_workspace_floats(int N, int n_k, int d, int ffn);
+int gom_match_scores_f32(const float* pool, int ld_pool, const int* rows, const int* frame_offsets, const int* meta,
+                         const float* boxes, const float* decay, int N, int T, int lo, int hi, int num_tracks,
+                         const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec, int n_dec, int d,
+                         int heads, int ffn, float img_w, float img_h, int with_iou, float max_center_dist,
+                         float* workspace, long workspace_floats, float* traj, void* stream);
 /* [host] rectangular assignment, SciPy-compatible tie-breaking (gom_lstmatcher.py:447,549).  Returns the number
  * of assigned pairs (min(nr,nc)) or a negative error. */
 int gom_linear_sum_assignment(const double* cost, long nr, long nc, long* row_ind, long* col_ind);

@@ -97,8 +97,18 @@ def test_matcher_heads_golden(builtin, tag):
         _close(rh._activate_asso(logits, n_t), g["asso%d_out" % ci], 1e-4, "asso act")
 
 
+@pytest.fixture(params=["native", "python"])
+def matcher_runtime(request):
+    """The per-match device chain issued by the native runtime (one FFI call) or composed kernel by kernel in Python."""
+    from gomatching_amd import ops
+    old = ops.NATIVE_MATCHER
+    ops.NATIVE_MATCHER = request.param == "native"
+    yield request.param
+    ops.NATIVE_MATCHER = old
+
+
 @pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
-def test_tracker_trace_golden(builtin, tag):
+def test_tracker_trace_golden(builtin, tag, matcher_runtime):
     """The reference's 16-frame id trace (empty frame, births, drop-outs, long-term re-association)."""
     from gomatching_amd.weights import synth_state_dict
     from gomatching_amd.modeling import GoMatching
@@ -125,6 +135,44 @@ def test_tracker_trace_golden(builtin, tag):
     kept = model._remove_short_track(insts)
     for f in range(frames):
         assert kept[f].track_ids.cpu().tolist() == g["kept_ids_%d" % f].tolist(), f
+
+
+@pytest.mark.parametrize("builtin", ["icdar15", "pp_dstext"])
+@pytest.mark.parametrize("n_t,k", [([7, 0, 12, 5], 3), ([60, 70, 90], 2), ([1, 1], 1), ([3, 140], 1)])
+def test_native_match_runtime_equals_python_composition(builtin, n_t, k):
+    """gom_match_scores_f32 (matcher_rt.cpp) returns the same bits as the per-kernel Python composition, for the
+    long- and the short-term matcher, rows below and above the 128-row kernel switch, an empty frame in the window."""
+    from gomatching_amd import ops
+    from gomatching_amd.modeling.roi_heads import build_roi_heads
+    from gomatching_amd.weights import synth_state_dict
+    cfg = mini_cfg(builtin, device=DEV)
+    heads = build_roi_heads(cfg, synth_state_dict(cfg, seed=11), torch.device(DEV))
+    g = torch.Generator().manual_seed(sum(n_t) + k)
+    N, T, n_k = sum(n_t), len(n_t), n_t[k]
+    pool = torch.randn(N + 9, heads.feature_dim, generator=g).to(DEV)
+    rows = torch.randperm(N + 9, generator=g)[:N].to(torch.int32).to(DEV)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(n_t)]), dtype=torch.int32, device=DEV)
+    Np = N - n_k
+    lo = sum(n_t[:k])
+    M = max(1, Np // 2)
+    col_of = np.arange(Np) % M
+    last = np.array([np.nonzero(col_of == m)[0].max() for m in range(M)])
+    nonk = np.concatenate([np.arange(0, lo), np.arange(lo + n_k, N)])
+    meta = torch.tensor(np.concatenate([nonk, col_of, last, np.arange(lo, lo + n_k)]), dtype=torch.int32, device=DEV)
+    xy = torch.rand(N, 2, generator=g) * 80
+    boxes = torch.cat([xy, xy + 10 + torch.rand(N, 2, generator=g) * 30], 1).to(DEV)
+    decay = (0.9 ** torch.arange(Np).float()).to(DEV)
+    out = {}
+    for short_term in (False, True):
+        for native in (True, False):
+            ops.NATIVE_MATCHER = native
+            try:
+                out[native] = heads.match_scores(pool, rows, offs, meta, boxes, None if short_term else decay, n_t, k,
+                                                 short_term, (96, 128), M, True, 0.0 if short_term else 50.0)
+            finally:
+                ops.NATIVE_MATCHER = True
+        assert out[True].shape == (n_k, M) and torch.isfinite(out[True]).all()
+        assert torch.equal(out[True], out[False])
 
 
 @pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])

@@ -83,6 +83,46 @@ def test_gemm_bf16x6_epilogue_gather_and_extremes():
     assert float(((out.cpu().double() - ref).abs() / scale).max()) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 64, 256), (300, 384, 256), (513, 132, 1024), (2000, 640, 64), (129, 1024, 32)])
+def test_gemm_planes_identical_to_bf16x6(M, N, K):
+    """Pre-split activation operand (LDS-DMA kernel): same bits as the in-loop-split kernel on the same values, for
+    fp32 output, plane output (p0+p1+p2 reproduces the fp32 result exactly) and both at once; ragged M and N."""
+    from gomatching_amd import ops
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=DEV) * (torch.rand(M, 1, device=DEV) * 8)
+    W = ops.split_weight(torch.randn(N, K, device=DEV))
+    b, sc = torch.randn(N, device=DEV), torch.rand(N, device=DEV) + 0.5
+    R = torch.randn(M, N, device=DEV)
+    Ap = ops.split_rows(A)
+    assert torch.equal(Ap.float(), A)                                  # the three planes carry all 24 mantissa bits
+    rc = (N // 2) // 4 * 4 or None
+    for relu in (False, True):
+        ref = ops.gemm(A, W, bias=b, scale=sc, R=R, relu=relu, r_cols=rc)
+        got = ops.gemm_planes(Ap, W, bias=b, scale=sc, R=R, relu=relu, r_cols=rc)
+        assert torch.equal(got, ref)
+        both_f, both_p = ops.gemm_planes(Ap, W, bias=b, scale=sc, R=R, relu=relu, r_cols=rc, want="both")
+        only_p = ops.gemm_planes(Ap, W, bias=b, scale=sc, R=R, relu=relu, r_cols=rc, want="planes")
+        assert torch.equal(both_f, ref) and torch.equal(both_p.float(), ref) and torch.equal(only_p.float(), ref)
+
+
+def test_gemm_planes_chain_and_bad_args():
+    """FFN-style chain through plane outputs: relu(A W1^T) as planes feeds the next product without an fp32 round trip."""
+    from gomatching_amd import ops, lib
+    torch.manual_seed(5)
+    A = torch.randn(777, 256, device=DEV)
+    W1, W2 = ops.split_weight(torch.randn(1024, 256, device=DEV) * 0.1), ops.split_weight(torch.randn(256, 1024, device=DEV) * 0.1)
+    h_ref = ops.gemm(A, W1, relu=True)
+    y_ref = ops.gemm(h_ref, W2, R=A)
+    h = ops.gemm_planes(ops.split_rows(A), W1, relu=True, want="planes")
+    y = ops.gemm_planes(h, W2, R=A)
+    assert torch.equal(y, y_ref)
+    with pytest.raises(AssertionError):
+        ops.gemm_planes(ops.split_rows(torch.randn(8, 40, device=DEV)), ops.split_weight(torch.randn(64, 40, device=DEV)))
+    L = lib.load()
+    assert L.gom_gemm_planes_bf16x6(None, 0, 0, None, 0, 0, None, None, None, 0, 0, 0, None, 0, None, 0, 0, 1, 4, 32,
+                                    None) == 1
+
+
 def test_gemm_epilogue_and_gather():
     ops = _ops()
     g = torch.Generator().manual_seed(3)
@@ -123,6 +163,28 @@ def test_gemm_skinny_splitk(M, N, K):
     rows = torch.randint(0, M, (max(M // 2, 1),), generator=g)
     out = ops.gemm(Ad, Wd, bias=bd, rows=rows.to(torch.int32).to(DEV))
     _close(out, (A[rows].double() @ W.double().t()).float() + b, 2e-5, 1e-5, "splitk gather")
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 4), (5, 55, 1024), (59, 118, 1024), (26, 49, 1024), (128, 255, 260), (21, 3072, 1024), (7, 300, 36)])
+def test_gemm_small_products(M, N, K):
+    """One-wave-per-output kernel behind ops.gemm for the tracker's tiny products: fp64 reference, epilogue, row
+    gather, strided operands, run-to-run identical bits."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 31 + N)
+    A = torch.randn(M + 3, K + 8, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, sc, R = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(M, N, generator=g)
+    Ad, Wd = A.to(DEV), W.to(DEV)
+    assert M * N <= ops.SMALL_GEMM_OUTPUTS
+    out = ops.gemm(Ad[:M, :K], Wd, bias=b.to(DEV), scale=sc.to(DEV), R=R.to(DEV), relu=True, small=True)
+    ref = F.relu((A[:M, :K].double() @ W.double().t()) * sc.double() + b.double() + R.double())
+    _close(out, ref, 2e-5, 1e-5, "small gemm %s" % ((M, N, K),))
+    assert torch.equal(out, ops.gemm(Ad[:M, :K], Wd, bias=b.to(DEV), scale=sc.to(DEV), R=R.to(DEV), relu=True, small=True))
+    rows = torch.randint(0, M + 3, (M,), generator=g)
+    out = ops.gemm(Ad[:, :K], Wd, rows=rows.to(torch.int32).to(DEV), small=True)
+    _close(out, A[rows, :K].double() @ W.double().t(), 2e-5, 1e-5, "small gemm gather")
+    out = ops.gemm(Ad[:M, :K], Ad[:M, :K], small=True)                  # association-logit form: X . X^T
+    _close(out, A[:M, :K].double() @ A[:M, :K].double().t(), 3e-5 * math.sqrt(K), 1e-5, "x.xT")
 
 
 def test_gemm_rejects_bad_args():
