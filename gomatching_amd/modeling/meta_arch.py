@@ -29,7 +29,7 @@ _f32 = torch.float32
 
 
 class GoMatching:
-    def __init__(self, cfg, state_dict, device=None, frames_per_step=8):
+    def __init__(self, cfg, state_dict, device=None, frames_per_step=8, use_graphs=True):
         self.cfg = cfg
         self.device = torch.device(device if device is not None else cfg.MODEL.DEVICE)
         if self.device.type != "cuda":
@@ -54,6 +54,8 @@ class GoMatching:
         self.pixel_mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
         self.pixel_std = [float(v) for v in cfg.MODEL.PIXEL_STD]
         self.frames_per_step = frames_per_step
+        self.use_graphs = use_graphs                             # hipGraph replay of the detector (see _detect_graphed)
+        self._graphs = {}
         self.training = False
 
         sd = normalize_state_dict(state_dict)
@@ -77,28 +79,42 @@ class GoMatching:
         raise NotImplementedError("training forward (losses) is outside the MI355X inference path (SURVEY.md §8-f4)")
 
     # ------------------------------------------------------------------------------------ detection
-    def preprocess_image(self, batched_inputs):
-        """gom_lstmatcher.py:164-170 for same-size frames: normalise + channels-last (no padding needed).
-        Inputs carry either the reference's `image` (f32 [3,H,W], already resized) or -- the device ingest of
-        SURVEY §8-f2 -- `frame_u8` (u8 [H0,W0,3] as read from disk) + `resize_hw` (+ `flip_channels`), in which
-        case resize/flip/float conversion/normalisation run as one kernel (`ops.ingest`)."""
-        if "frame_u8" in batched_inputs[0]:
-            first = batched_inputs[0]
+    def _raw_input(self, batched_inputs, out=None):
+        """The step's frames as ONE device tensor (`out` = a static buffer to fill, for graph replay) + how to
+        normalise it: ("u8", net hw, flip) for the device ingest of SURVEY §8-f2 -- `frame_u8` (u8 [H0,W0,3] as read
+        from disk) + `resize_hw` (+ `flip_channels`) -- or ("f32", hw, None) for the reference's `image` (f32 [3,H,W],
+        already resized).  gom_lstmatcher.py:164-170 for same-size frames (no padding needed)."""
+        first = batched_inputs[0]
+        if "frame_u8" in first:
             hw, flip = tuple(first["resize_hw"]), bool(first.get("flip_channels", False))
             frames = [x["frame_u8"] for x in batched_inputs]
             for x in batched_inputs:
                 if tuple(x["resize_hw"]) != hw or tuple(x["frame_u8"].shape) != tuple(frames[0].shape) \
                         or bool(x.get("flip_channels", False)) != flip:
                     raise ValueError("frames of one step must share source size, target size and channel order")
-            u8 = torch.stack([f.to(self.device, non_blocking=True) for f in frames]).contiguous()
-            return ops.ingest(u8, hw[0], hw[1], self.pixel_mean, self.pixel_std, flip), hw
-        imgs = [x["image"] for x in batched_inputs]
-        hw = tuple(imgs[0].shape[-2:])
-        for im in imgs:
-            if tuple(im.shape[-2:]) != hw:
-                raise ValueError("frames of one step must share a size (got %s and %s)" % (hw, tuple(im.shape[-2:])))
-        x = torch.stack([im.to(self.device, non_blocking=True).to(_f32) for im in imgs]).contiguous()
-        return ops.preprocess(x, self.pixel_mean, self.pixel_std), hw
+            kind, dtype = ("u8", hw, flip), torch.uint8
+        else:
+            frames = [x["image"] for x in batched_inputs]
+            hw = tuple(frames[0].shape[-2:])
+            for im in frames:
+                if tuple(im.shape[-2:]) != hw:
+                    raise ValueError("frames of one step must share a size (got %s and %s)" % (hw, tuple(im.shape[-2:])))
+            kind, dtype = ("f32", hw, None), _f32
+        if out is None:
+            out = torch.empty((len(frames),) + tuple(frames[0].shape), dtype=dtype, device=self.device)
+        for i, f in enumerate(frames):
+            out[i].copy_(f, non_blocking=True)
+        return out, kind
+
+    def _normalise(self, raw, kind):
+        if kind[0] == "u8":
+            return ops.ingest(raw, kind[1][0], kind[1][1], self.pixel_mean, self.pixel_std, kind[2])
+        return ops.preprocess(raw, self.pixel_mean, self.pixel_std)
+
+    def preprocess_image(self, batched_inputs):
+        """Normalised channels-last network input of a step + its (H, W)."""
+        raw, kind = self._raw_input(batched_inputs)
+        return self._normalise(raw, kind), kind[1]
 
     def _ensure_pool(self, extra_rows):
         need = self._pool_used + extra_rows
@@ -113,14 +129,13 @@ class GoMatching:
         """Detection + re-id embedding for a step of frames (gom_lstmatcher.py:268-351), batched."""
         return self.detect_finish(self.detect_launch(batched_inputs, time_cost), time_cost)
 
-    def detect_launch(self, batched_inputs, time_cost):
-        """Asynchronous half of `inference`: queues every detector kernel of the step on the current stream, ends
-        with a non-blocking D2H copy of the nq-padded detection summary and an event.  No host sync, no tracker
-        state touched -- a caller may queue the next step's detection before finishing this one."""
-        assert not self.training
+    def _detect_core(self, raw, kind, time_cost):
+        """Every detector kernel of a step, queued on the current stream: no host sync, no host<->device copy, shapes
+        fixed by (B, input kind) -- which is what lets `_detect_graphed` capture it."""
         sync = torch.cuda.synchronize if time_cost.get("_sync") else (lambda: None)
+        hw = kind[1]
         t0 = time.time()
-        x, hw = self.preprocess_image(batched_inputs)
+        x = self._normalise(raw, kind)
         sync(); time_cost["pre_process"] += time.time() - t0
         t0 = time.time()
         feats = self.backbone.forward(x)
@@ -134,16 +149,78 @@ class GoMatching:
             re = self.roi_heads.rescoring_head(out["query_features"])
             sync(); time_cost["rescore"] += time.time() - t0
         T = self.cfg.MODEL.TRANSFORMER
-        B, nq, P = len(batched_inputs), T.NUM_QUERIES, T.NUM_POINTS
+        B, nq, P = raw.shape[0], T.NUM_QUERIES, T.NUM_POINTS
         recs = ops.argmax_rows(out["pred_text_logits"])
         det = ops.detect_post(out["pred_logits"], re, out["pred_ctrl_points"], out["pred_bd_points"], recs, B, nq, P,
                               hw[0], hw[1], self.test_score_threshold, self.nms_thresh,
                               self.roi_heads.asso_thresh_test)
+        return out["query_features"], det
+
+    def _detect_graphed(self, batched_inputs, time_cost):
+        """hipGraph replay of `_detect_core` (~870 launches per 8-frame step become one graph launch: the host is
+        free for the tracker of the previous step, and the in-stream launch gaps disappear).  Per (B, input kind): the
+        first call runs eagerly (warms every per-resolution cache), the second captures, later ones replay.  Outputs
+        are copied out of the graph's static buffers, so a replay never overwrites what an unfinished step reads.
+        Returns None when this step is not (yet) graphed."""
+        B = len(batched_inputs)
+        first = batched_inputs[0]
+        src = first["frame_u8"] if "frame_u8" in first else first["image"]
+        key = (B, tuple(src.shape), str(src.dtype), tuple(first.get("resize_hw", ())), bool(first.get("flip_channels")))
+        state = self._graphs.get(key)
+        if state is None:
+            self._graphs[key] = "warm"                          # this call: eager
+            return None
+        if time_cost.get("_sync"):
+            return None                                         # per-stage timing needs the eager path
+        if state == "warm":
+            try:
+                raw, kind = self._raw_input(batched_inputs)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                tc = {k: 0.0 for k in time_cost if k != "_sync"}
+                with torch.cuda.graph(g):
+                    qf, det = self._detect_core(raw, kind, tc)
+                state = {"graph": g, "raw": raw, "kind": kind, "qf": qf, "det": det}
+                self._graphs[key] = state
+            except Exception as e:                              # capture unsupported here: stay eager, loudly
+                import warnings
+                warnings.warn("hipGraph capture of the detector failed (%s: %s); running eagerly" % (type(e).__name__, e))
+                self.use_graphs = False
+                return None
+        t0 = time.time()
+        self._raw_input(batched_inputs, out=state["raw"])
+        state["graph"].replay()
+        det = {k: (v.clone() if isinstance(v, torch.Tensor) and k in ("small", "ctrl", "bd", "recs") else v)
+               for k, v in state["det"].items()}
+        small = det["small"]
+        o1, o2, o3 = det["small_layout"]
+        nq = self.cfg.MODEL.TRANSFORMER.NUM_QUERIES
+        det["count"], det["keep_idx"] = small[:o1], small[o1:o2].view(B, nq)
+        det["scores"], det["boxes"] = small[o2:o3].view(_f32).view(B, nq), small[o3:].view(_f32).view(B, nq, 4)
+        qf = state["qf"].clone()
+        time_cost["detector"] += time.time() - t0
+        return qf, det, state["kind"][1]
+
+    def detect_launch(self, batched_inputs, time_cost):
+        """Asynchronous half of `inference`: queues every detector kernel of the step on the current stream, ends
+        with a non-blocking D2H copy of the nq-padded detection summary and an event.  No host sync, no tracker
+        state touched -- a caller may queue the next step's detection before finishing this one."""
+        assert not self.training
+        B = len(batched_inputs)
+        graphed = self._detect_graphed(batched_inputs, time_cost) if self.use_graphs else None
+        if graphed is not None:
+            qf, det, hw = graphed
+        else:
+            t0 = time.time()
+            raw, kind = self._raw_input(batched_inputs)
+            time_cost["pre_process"] += time.time() - t0
+            qf, det = self._detect_core(raw, kind, time_cost)
+            hw = kind[1]
         host = torch.empty(det["small"].shape, dtype=torch.int32, pin_memory=True)
         host.copy_(det["small"], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return {"query_features": out["query_features"], "det": det, "host": host, "event": ev, "B": B, "hw": hw}
+        return {"query_features": qf, "det": det, "host": host, "event": ev, "B": B, "hw": hw}
 
     def detect_finish(self, h, time_cost):
         """Second half: wait for the step's event (the one host sync of the step), embed the kept detections

@@ -1,0 +1,36 @@
+"""Analyse a rocprofv3 --kernel-trace CSV: per queue, busy time, gaps between consecutive kernels, and the longest /
+most frequent kernels -- used to see what the tracker stream's serial chain waits for beside a saturated detector."""
+import collections
+import csv
+import sys
+
+
+def main(path, top=14):
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"),
+                         r.get("Stream_Id", "?"), r["Kernel_Name"][:70]))
+    rows.sort()
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    print("kernels %d  span %.1f ms" % (len(rows), (t1 - t0) / 1e6))
+    byq = collections.defaultdict(list)
+    for r in rows:
+        byq[(r[2], r[3])].append(r)
+    for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
+        busy = sum(e - s for s, e, *_ in rs)
+        gaps = [rs[i + 1][0] - rs[i][1] for i in range(len(rs) - 1)]
+        small = [g for g in gaps if 0 <= g < 200000]
+        print("queue/stream %s: %d kernels, busy %.1f ms, median gap %.1f us, mean gap(<200us) %.1f us, mean dur %.1f us"
+              % (q, len(rs), busy / 1e6, sorted(gaps)[len(gaps) // 2] / 1e3 if gaps else 0,
+                 sum(small) / max(len(small), 1) / 1e3, busy / len(rs) / 1e3))
+        agg = collections.defaultdict(lambda: [0, 0])
+        for s, e, _, _, n in rs:
+            agg[n][0] += 1
+            agg[n][1] += e - s
+        for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+            print("    %-70s x%-5d %8.1f us avg  %7.2f ms" % (n, c, t / c / 1e3, t / 1e6))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
