@@ -17,9 +17,18 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
                                                        const float* __restrict__ v, float* __restrict__ o,
                                                        int Lq, int Lk, int inner, long q_bo, long q_bi, long q_ss,
                                                        long k_bo, long k_bi, long k_ss, long v_bo, long v_bi,
-                                                       long v_ss, long o_bo, long o_bi, long o_ss, float scale) {
+                                                       long v_ss, long o_bo, long o_bi, long o_ss, float scale,
+                                                       const int* __restrict__ seg) {
     constexpr int KS = HD + 4;  // padded K-tile row (conflict-free ds_read_b128 across keys)
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // ragged batch: block x = segment s with its own (first query row, Lq, first key row, Lk); q_bo / k_bo / v_bo / o_bo
+    // are then the ROW strides applied to those first rows
+    if (seg) {
+        const int* d = seg + 4 * blockIdx.x;
+        Lq = d[1];
+        Lk = d[3];
+        if ((int)blockIdx.z * QT >= Lq || Lk <= 0) return;      // uniform per block: no barrier is skipped by a subset
+    }
     const int Lkp = (Lk + KT - 1) / KT * KT;
     float* Qs = smem;                       // [QT][HD]
     float* KVs = Qs + QT * HD;              // [KT][KS]
@@ -28,10 +37,10 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.z * QT, h = blockIdx.y;
     const long bo = blockIdx.x / inner, bi = blockIdx.x % inner;   // batch = outer x inner, two strides each
-    const float* qb = q + bo * q_bo + bi * q_bi + h * HD;
-    const float* kb = k + bo * k_bo + bi * k_bi + h * HD;
-    const float* vb = v + bo * v_bo + bi * v_bi + h * HD;
-    float* ob = o + bo * o_bo + bi * o_bi + h * HD;
+    const float* qb = q + (seg ? seg[4 * blockIdx.x] * q_ss : bo * q_bo + bi * q_bi) + h * HD;
+    const float* kb = k + (seg ? seg[4 * blockIdx.x + 2] * k_ss : bo * k_bo + bi * k_bi) + h * HD;
+    const float* vb = v + (seg ? seg[4 * blockIdx.x + 2] * v_ss : bo * v_bo + bi * v_bi) + h * HD;
+    float* ob = o + (seg ? seg[4 * blockIdx.x] * o_ss : bo * o_bo + bi * o_bi) + h * HD;
 
     for (int u = tid; u < QT * HD / 4; u += 256) {
         const int r = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
 
 template <int HD, int QT>
 int launch(const float* q, const float* k, const float* v, float* o, int outer, int inner, int heads, int Lq, int Lk,
-           const long* st, float scale, hipStream_t s, bool* fits) {
+           const long* st, float scale, hipStream_t s, bool* fits, const int* seg = nullptr) {
     const int Lkp = (Lk + KT - 1) / KT * KT;
     const size_t lds = sizeof(float) * ((size_t)QT * HD + (size_t)KT * (HD + 4) + (size_t)QT * Lkp);
     *fits = lds <= 160 * 1024;
@@ -132,7 +141,7 @@ int launch(const float* q, const float* k, const float* v, float* o, int outer, 
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(outer * inner), (unsigned)heads, (unsigned)cdiv(Lq, QT)), dim3(256), lds, s,
                        q, k, v, o, Lq, Lk, inner, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9],
-                       st[10], st[11], scale);
+                       st[10], st[11], scale, seg);
     return gom_launch_status();
 }
 
@@ -161,4 +170,25 @@ extern "C" int gom_mha_core_f32(const float* q, const float* k, const float* v, 
     }
 #undef TRY
     return GOM_ERR_UNSUPPORTED;  // more keys than one workgroup's LDS can hold
+}
+
+// Ragged batch of independent attention problems over row ranges of the same q / k / v / o matrices (the short-term
+// matcher's per-pair attention: transformer.py:60-96 applied to every (previous, current) frame pair of a clip at once).
+// segments [device] int32 [S][4] = (first query row, Lq, first key row, Lk); ld_* are row strides in floats; max_Lq /
+// max_Lk bound the grid and the LDS score rows.
+extern "C" int gom_mha_core_segments_f32(const float* q, const float* k, const float* v, float* o, const int* segments,
+                                         int num_segments, int heads, int head_dim, int ld_q, int ld_k, int ld_v,
+                                         int ld_o, int max_Lq, int max_Lk, void* stream) {
+    GOM_CHECK_ARG(q && k && v && o && segments && num_segments >= 0 && heads > 0 && head_dim == 128);
+    GOM_CHECK_ARG((ld_q % 4) == 0 && (ld_k % 4) == 0 && (ld_v % 4) == 0 && max_Lq >= 0 && max_Lk >= 0);
+    if (num_segments == 0 || max_Lq == 0 || max_Lk == 0) return GOM_OK;
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    const long st[12] = {0, 0, ld_q, 0, 0, ld_k, 0, 0, ld_v, 0, 0, ld_o};
+    bool fits = false;
+    int rc = launch<128, 32>(q, k, v, o, num_segments, 1, heads, max_Lq, max_Lk, st, scale, (hipStream_t)stream, &fits,
+                             segments);
+    if (rc != GOM_OK || fits) return rc;
+    rc = launch<128, 8>(q, k, v, o, num_segments, 1, heads, max_Lq, max_Lk, st, scale, (hipStream_t)stream, &fits, segments);
+    if (rc != GOM_OK || fits) return rc;
+    return GOM_ERR_UNSUPPORTED;
 }

@@ -79,6 +79,77 @@ __global__ __launch_bounds__(256) void track_score_kernel(const float* __restric
     traj[idx] = s;
 }
 
+// Short-term matching, all (previous, current) frame pairs of a clip in one launch (gom_lstmatcher.py:405-445 with the
+// id-independent reading of roi_heads.short_term_scores): one wave per current-frame detection i of pair p computes
+//   logits l_j = tgt_i . memory_j over the PREVIOUS frame's rows j (ATTWeightHead, 0 layers),
+//   a_j = softmax over {l_j} U {0} (lstmatcher.py:373-381; the current frame's own block never feeds a track score),
+//   S[i, j] = max(a_j, IoU(box_i, box_j)) (with_iou) -- the trajectory score of a track seen once.
+// pair descriptors [device] int32 [P][6] = (first memory row, n_prev, n_cur, first tgt row, first box row, S offset);
+// row_pair [total cur rows] = pair of each tgt row.
+constexpr int ST_CHUNKS = 5;                                 // previous-frame detections per pair <= 320
+
+__global__ __launch_bounds__(256) void short_term_pairs_kernel(const float* __restrict__ tgt, const float* __restrict__ mem,
+                                                               int d, const int* __restrict__ pairs,
+                                                               const int* __restrict__ row_pair,
+                                                               const float* __restrict__ boxes, float img_w, float img_h,
+                                                               int with_iou, int total_rows, float* __restrict__ S) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= total_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int* p = pairs + 6 * row_pair[w];
+    const int m0 = p[0], n_prev = p[1], t0 = p[3], b0 = p[4];
+    const int i = w - t0;
+    const float* a = tgt + (size_t)w * d;
+    float* out = S + p[5] + (size_t)i * n_prev;
+    // logits stay in registers: lane l keeps columns l, l+64, ... (n_prev <= 64 * ST_CHUNKS, checked by the host)
+    float lg[ST_CHUNKS];
+    float mx = 0.f;
+#pragma unroll
+    for (int c = 0; c < ST_CHUNKS; ++c) {
+        lg[c] = -INFINITY;
+        const int jend = min(n_prev, (c + 1) * 64);
+        for (int j = c * 64; j < jend; ++j) {
+            const float* b = mem + (size_t)(m0 + j) * d;
+            float acc = 0.f;
+            for (int k = lane * 4; k < d; k += 256) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(a + k);
+                const f32x4 y = *reinterpret_cast<const f32x4*>(b + k);
+                acc = fmaf(x[0], y[0], acc);
+                acc = fmaf(x[1], y[1], acc);
+                acc = fmaf(x[2], y[2], acc);
+                acc = fmaf(x[3], y[3], acc);
+            }
+            acc = wave_sum(acc);
+            mx = fmaxf(mx, acc);
+            if (lane == (j & 63)) lg[c] = acc;
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < ST_CHUNKS; ++c)
+        if (c * 64 + lane < n_prev) sum += expf(lg[c] - mx);
+    sum = wave_sum(sum) + expf(0.f - mx);
+    const float* kb = boxes + (size_t)(b0 + n_prev + i) * 4;
+    const float kx0 = kb[0] / img_w, ky0 = kb[1] / img_h, kx1 = kb[2] / img_w, ky1 = kb[3] / img_h;
+#pragma unroll
+    for (int c = 0; c < ST_CHUNKS; ++c) {
+        const int j = c * 64 + lane;
+        if (j >= n_prev) continue;
+        float s = expf(lg[c] - mx) / sum;
+        if (with_iou) {
+            const float* lb = boxes + (size_t)(b0 + j) * 4;
+            const float lx0 = lb[0] / img_w, ly0 = lb[1] / img_h, lx1 = lb[2] / img_w, ly1 = lb[3] / img_h;
+            const float ww = fmaxf(fminf(kx1, lx1) - fmaxf(kx0, lx0), 0.f);
+            const float hh = fmaxf(fminf(ky1, ly1) - fmaxf(ky0, ly0), 0.f);
+            const float inter = ww * hh;
+            const float a1 = (kx1 - kx0) * (ky1 - ky0), a2 = (lx1 - lx0) * (ly1 - ly0);
+            const float iou = inter > 0.f ? inter / (a1 + a2 - inter) : 0.f;
+            s = fmaxf(s, iou);
+        }
+        out[j] = s;
+    }
+}
+
 }  // namespace
 
 extern "C" int gom_gather_rows_f32(const float* src, const int* rows, float* out, int n, int dim, void* stream) {
@@ -105,5 +176,16 @@ extern "C" int gom_track_score_f32(const float* act, int ld, const int* meta, co
     if (n_k == 0 || M == 0) return GOM_OK;
     hipLaunchKernelGGL(track_score_kernel, dim3((unsigned)cdiv((long)n_k * M, 256)), dim3(256), 0, (hipStream_t)stream,
                        act, ld, meta, decay, boxes, img_w, img_h, n_k, Np, M, with_iou, max_center_dist, traj);
+    return gom_launch_status();
+}
+
+extern "C" int gom_short_term_pairs_f32(const float* tgt, const float* memory, int d, const int* pairs,
+                                        const int* row_pair, const float* boxes, float img_w, float img_h, int with_iou,
+                                        int total_cur_rows, int max_prev, float* S, void* stream) {
+    GOM_CHECK_ARG(tgt && memory && pairs && row_pair && boxes && S && d > 0 && (d % 4) == 0 && total_cur_rows >= 0);
+    GOM_CHECK_ARG(max_prev >= 0 && max_prev <= 64 * ST_CHUNKS);
+    if (total_cur_rows == 0) return GOM_OK;
+    hipLaunchKernelGGL(short_term_pairs_kernel, dim3((unsigned)cdiv(total_cur_rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       tgt, memory, d, pairs, row_pair, boxes, img_w, img_h, with_iou, total_cur_rows, S);
     return gom_launch_status();
 }

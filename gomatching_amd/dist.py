@@ -44,10 +44,15 @@ def pack_records(dets, nq, feature_dim, num_points, device):
 
 
 def unpack_records(buf, image_size, feature_dim, num_points):
-    """[F, nq+1, D] -> list of Instances (device tensors are views into `buf`) with host mirrors attached."""
+    """[F, nq+1, D] -> list of Instances (device tensors are views into `buf` / into per-call bulk conversions, so
+    the number of kernels does not grow with F) with host mirrors attached."""
     P = num_points
     counts = buf[:, 0, 0].cpu().numpy().astype(np.int64)
     small = buf[:, 1:, feature_dim:feature_dim + 5].cpu().numpy()          # boxes + score, one D2H
+    o_rec = feature_dim + 5 + 6 * P
+    recs_all = buf[:, 1:, o_rec:o_rec + P].to(torch.int64)                  # one conversion for every frame
+    nmax = int(counts.max()) if len(counts) else 0
+    classes = torch.zeros((max(nmax, 1),), dtype=torch.int64, device=buf.device)
     out = []
     for f in range(buf.shape[0]):
         n = int(counts[f])
@@ -57,13 +62,12 @@ def unpack_records(buf, image_size, feature_dim, num_points):
         r.reid_features = row[:, :feature_dim]
         r.pred_boxes = Boxes(row[:, o:o + 4])
         r.scores = row[:, o + 4]
-        r.pred_classes = torch.zeros((n,), dtype=torch.int64, device=buf.device)
+        r.pred_classes = classes[:n]
         o += 5
         r.ctrl_points = row[:, o:o + 2 * P]
         o += 2 * P
         r.bd = row[:, o:o + 4 * P].reshape(n, P, 4)
-        o += 4 * P
-        r.recs = row[:, o:o + P].to(torch.int64)
+        r.recs = recs_all[f, :n]
         r._gom = {"boxes": small[f, :n, :4].copy(), "scores": small[f, :n, 4].copy(), "row0": None, "ids": None}
         out.append(r)
     return out

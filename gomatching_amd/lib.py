@@ -62,6 +62,8 @@ SIGNATURES = {
     "gom_gather_rows_f32": (I, [P, P, P, I, I, P]),
     "gom_asso_activate_f32": (I, [P, I, P, I, I, P, I, P]),
     "gom_track_score_f32": (I, [P, I, P, P, P, F, F, I, I, I, I, F, P, P]),
+    "gom_short_term_pairs_f32": (I, [P, P, I, P, P, P, F, F, I, I, I, P, P]),
+    "gom_mha_core_segments_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "gom_match_workspace_floats": (L, [I, I, I, I]),
     "gom_match_scores_f32": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
     "gom_linear_sum_assignment": (I, [ctypes.POINTER(ctypes.c_double), L, L, ctypes.POINTER(c_long),

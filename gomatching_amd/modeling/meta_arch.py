@@ -347,6 +347,24 @@ class GoMatching:
             self._pool_used += n
         return g["row0"] + np.nonzero(sel)[0]
 
+    def _home_features(self, frames):
+        """Move the embeddings of every frame that still lives outside the pool (records unpacked from the all-gather)
+        into it with ONE batched copy instead of one per frame."""
+        foreign = [x for x in frames if len(x) and x.has("reid_features")
+                   and (self._host(x)["row0"] is None or not self._in_pool(x))]
+        if not foreign:
+            return
+        total = sum(len(x) for x in foreign)
+        self._ensure_pool(total)
+        r0 = self._pool_used
+        torch.cat([x.reid_features for x in foreign], out=self._pool[r0:r0 + total])
+        for x in foreign:
+            n = len(x)
+            self._host(x)["row0"] = r0
+            x._fields["reid_features"] = self._pool[r0:r0 + n]
+            r0 += n
+        self._pool_used = r0
+
     def _in_pool(self, inst):
         if self._pool is None or not inst.has("reid_features"):
             return False
@@ -554,6 +572,7 @@ class GoMatching:
         t0 = time.time()
         base = len(instances)
         window = ([instances[-1]] if base else []) + list(dets)
+        self._home_features(window)
         st = self.precompute_short_term(window)                  # keyed by index into `window`
         shift = 1 if base else 0
         time_cost["short_match"] += time.time() - t0
@@ -601,6 +620,8 @@ class GoMatching:
         for k in range(len(instances)):
             hid = self._host(instances[k])["ids"]
             keep = np.array([int(t) not in short for t in hid], dtype=bool)
+            if keep.all():                                       # nothing to drop: skip seven index kernels
+                continue
             g = instances[k]._gom
             idx = torch.from_numpy(np.nonzero(keep)[0]).to(self.device)
             new = instances[k][idx]

@@ -78,27 +78,36 @@ class _MatcherTransformer:
         return tgt, memory
 
 
-    def forward_pairs(self, src_all, pairs):
+    def forward_pairs(self, src_all, pairs, seg=None):
         """Batched forward over independent (previous frame, current frame) pairs -- the short-term matcher input
         depends only on the two frames' embeddings, never on track ids, so all pairs of a batch of frames share
-        every GEMM (weights streamed once) and only the tiny attention cores run per pair.
+        every GEMM (weights streamed once); the attention cores run as ONE ragged launch per layer when `seg` =
+        (enc segments, dec segments, cur rows, max n, max n_cur) device descriptors are given, else per pair.
         src_all [sum N_p, F]: per pair the previous frame's rows then the current frame's.
-        pairs: list of (row offset, n_prev, n_cur).  Returns per-pair association logits [n_cur, N_p]."""
-        E = self.d
+        pairs: list of (row offset, n_prev, n_cur).  Returns (tgt [sum n_cur, F], memory [sum N_p, F], cur_off)."""
+        E, H = self.d, self.heads
         Nall = src_all.shape[0]
         memory = src_all
         for L in self.enc:
             qkv = ops.gemm(memory, L["in"][0], bias=L["in"][1], small=True)
             a = torch.empty((Nall, E), dtype=_f32, device=src_all.device)
-            for off, n_prev, n_cur in pairs:
-                n = n_prev + n_cur
-                f = qkv[off:off + n].view(-1)
-                self._attend_into(a[off:off + n], f, f[E:], f[2 * E:], 3 * E, 3 * E, n, n)
+            if seg is not None:
+                f = qkv.view(-1)
+                ops.mha_core_segments(f, f[E:], f[2 * E:], a, seg[0], len(pairs), H, E // H, 3 * E, 3 * E, 3 * E, E,
+                                      seg[3], seg[3])
+            else:
+                for off, n_prev, n_cur in pairs:
+                    n = n_prev + n_cur
+                    f = qkv[off:off + n].view(-1)
+                    self._attend_into(a[off:off + n], f, f[E:], f[2 * E:], 3 * E, 3 * E, n, n)
             memory = ops.gemm(a, L["out"][0], bias=L["out"][1], R=memory, small=True)
             h = ops.gemm(memory, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True)
             memory = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=memory, small=True)
-        cur_rows = torch.cat([torch.arange(off + n_prev, off + n_prev + n_cur, dtype=torch.int32)
-                              for off, n_prev, n_cur in pairs]).to(src_all.device)
+        if seg is not None:
+            cur_rows = seg[2]
+        else:
+            cur_rows = torch.cat([torch.arange(off + n_prev, off + n_prev + n_cur, dtype=torch.int32)
+                                  for off, n_prev, n_cur in pairs]).to(src_all.device)
         tgt = ops.gather_rows(src_all, cur_rows)
         M = tgt.shape[0]
         cur_off = [0]
@@ -109,17 +118,20 @@ class _MatcherTransformer:
             q = ops.gemm(tgt, w[:E], bias=b[:E], small=True)
             kv = ops.gemm(memory, w[E:], bias=b[E:], small=True)
             a = torch.empty((M, E), dtype=_f32, device=src_all.device)
-            for i, (off, n_prev, n_cur) in enumerate(pairs):
-                n = n_prev + n_cur
-                f = kv[off:off + n].view(-1)
-                self._attend_into(a[cur_off[i]:cur_off[i + 1]], q[cur_off[i]:cur_off[i + 1]], f, f[E:], E, 2 * E,
-                                  n_cur, n)
+            if seg is not None:
+                f = kv.view(-1)
+                ops.mha_core_segments(q, f, f[E:], a, seg[1], len(pairs), H, E // H, E, 2 * E, 2 * E, E, seg[4], seg[3])
+            else:
+                for i, (off, n_prev, n_cur) in enumerate(pairs):
+                    n = n_prev + n_cur
+                    f = kv[off:off + n].view(-1)
+                    self._attend_into(a[cur_off[i]:cur_off[i + 1]], q[cur_off[i]:cur_off[i + 1]], f, f[E:], E, 2 * E,
+                                      n_cur, n)
             tgt = ops.gemm(a, L["out"][0], bias=L["out"][1], R=tgt, small=True)
             if not self.only_crs:
                 h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True)
                 tgt = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt, small=True)
-        return [ops.gemm(tgt[cur_off[i]:cur_off[i + 1]], memory[off:off + n_prev + n_cur], small=True)
-                for i, (off, n_prev, n_cur) in enumerate(pairs)]
+        return tgt, memory, cur_off
 
     def _attend_into(self, out, q, k, v, ld_q, ld_kv, Lq, Lk):
         hd = self.d // self.heads
@@ -187,7 +199,38 @@ class _MatcherBase:
         (gom_lstmatcher.py:429-445) is exactly S[i, j_m] with j_m the previous-frame detection carrying id m: the
         whole device side of short-term matching is id-independent and is done here for all pairs at once.
         boxes_all [sum N_p, 4] px, same row order as src_all.  Returns a list of device tensors [n_cur, n_prev]."""
-        logits = self._matcher(True).forward_pairs(src_all, pairs)
+        max_prev = max(p[1] for p in pairs)
+        if ops.BATCHED_SHORT_TERM and max_prev <= ops.SHORT_TERM_MAX_PREV:
+            # every pair in one launch per op: ragged attention (2 layers), fused logits + softmax + IoU
+            P = len(pairs)
+            seg_enc, seg_dec, desc, row_pair, cur_rows = [], [], [], [], []
+            cur_off = s_off = 0
+            for i, (off, n_prev, n_cur) in enumerate(pairs):
+                n = n_prev + n_cur
+                seg_enc += [off, n, off, n]
+                seg_dec += [cur_off, n_cur, off, n]
+                desc += [off, n_prev, n_cur, cur_off, off, s_off]
+                row_pair.append(np.full((n_cur,), i, np.int32))
+                cur_rows.append(np.arange(off + n_prev, off + n, dtype=np.int32))
+                cur_off += n_cur
+                s_off += n_cur * n_prev
+            parts = [np.asarray(seg_enc, np.int32), np.asarray(seg_dec, np.int32), np.asarray(desc, np.int32),
+                     np.concatenate(row_pair), np.concatenate(cur_rows)]
+            buf = torch.from_numpy(np.concatenate(parts)).to(self.device)
+            o = np.cumsum([0] + [len(p) for p in parts])
+            seg = (buf[o[0]:o[1]], buf[o[1]:o[2]], buf[o[4]:o[5]], max(p[1] + p[2] for p in pairs),
+                   max(p[2] for p in pairs))
+            tgt, memory, _ = self._matcher(True).forward_pairs(src_all, pairs, seg)
+            S = ops.short_term_pairs(tgt, memory, buf[o[2]:o[3]], buf[o[3]:o[4]], boxes_all, image_size[1], image_size[0],
+                                     self.cfg.VIDEO_TEST.WITH_IOU, cur_off, max_prev, s_off)
+            out, s_off = [], 0
+            for off, n_prev, n_cur in pairs:
+                out.append(S[s_off:s_off + n_cur * n_prev].view(n_cur, n_prev))
+                s_off += n_cur * n_prev
+            return out
+        tgt, memory, cur_off = self._matcher(True).forward_pairs(src_all, pairs)
+        logits = [ops.gemm(tgt[cur_off[i]:cur_off[i + 1]], memory[off:off + n_prev + n_cur], small=True)
+                  for i, (off, n_prev, n_cur) in enumerate(pairs)]
         # one packed host->device copy of every pair's frame offsets and (nonk | col_of | last | k) index lists
         parts, where, o = [], [], 0
         for off, n_prev, n_cur in pairs:

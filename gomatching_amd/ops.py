@@ -378,6 +378,13 @@ def mha_core(q, k, v, out, outer, inner, heads, head_dim, Lq, Lk, strides):
     return out
 
 
+def mha_core_segments(q, k, v, out, segments, num_segments, heads, head_dim, ld_q, ld_k, ld_v, ld_o, max_Lq, max_Lk):
+    """Ragged batch: segments int32 [S,4] (device) = (first query row, Lq, first key row, Lk) over shared matrices."""
+    check(_L().gom_mha_core_segments_f32(_p(q), _p(k), _p(v), _p(out), _p(segments), num_segments, heads, head_dim,
+                                         ld_q, ld_k, ld_v, ld_o, max_Lq, max_Lk, _stream()), "gom_mha_core_segments_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ glue
 def preprocess(images, mean, std):
     _chk_f32(images)
@@ -579,6 +586,19 @@ def track_score(act, meta, decay, boxes, img_w, img_h, n_k, Np, M, with_iou, max
                                    n_k, Np, M, 1 if with_iou else 0, float(max_center_dist), _p(traj), _stream()),
           "gom_track_score_f32")
     return traj
+
+
+BATCHED_SHORT_TERM = True  # False: per-pair kernels (kept for the A/B parity test and for > 320 detections per frame)
+SHORT_TERM_MAX_PREV = 320
+
+
+def short_term_pairs(tgt, memory, pairs, row_pair, boxes, img_w, img_h, with_iou, total_rows, max_prev, s_floats):
+    """All pairs' S = max(softmax-with-background(q.k^T), IoU) in one launch; returns the packed fp32 buffer."""
+    S = torch.empty((max(s_floats, 1),), dtype=_f32, device=tgt.device)
+    check(_L().gom_short_term_pairs_f32(_p(tgt), _p(memory), tgt.shape[1], _p(pairs), _p(row_pair), _p(boxes),
+                                        float(img_w), float(img_h), 1 if with_iou else 0, total_rows, max_prev, _p(S),
+                                        _stream()), "gom_short_term_pairs_f32")
+    return S
 
 
 NATIVE_MATCHER = True      # False: compose the match from per-kernel calls in Python (kept for the A/B parity test)

@@ -136,6 +136,13 @@ int gom_groupnorm32_nhwc_f32(const float* x, const float* gamma, const float* be
 int gom_mha_core_f32(const float* q, const float* k, const float* v, float* o, int batch_outer, int batch_inner,
                      int heads, int head_dim, int Lq, int Lk, const long* strides, void* stream);
 
+/* Ragged batch of independent attention problems over row ranges of shared q / k / v / o matrices (every frame pair
+ * of the short-term matcher at once).  segments [device] int32 [S][4] = (first query row, Lq, first key row, Lk);
+ * ld_* row strides in floats; head_dim 128. */
+int gom_mha_core_segments_f32(const float* q, const float* k, const float* v, float* o, const int* segments,
+                              int num_segments, int heads, int head_dim, int ld_q, int ld_k, int ld_v, int ld_o, int max_Lq,
+                              int max_Lk, void* stream);
+
 /* ---- glue (A1, A2 stem pool, A3, A5, A8, A9) ----------------------------------------------------------*/
 /* mean3/std3 are [host] arrays.  images [B,3,H,W] -> out [B,H,W,4] (4th channel 0). */
 int gom_preprocess_nchw_to_nhwc4(const float* images, const float* mean3, const float* std3, float* out, int B, int H,
@@ -204,6 +211,14 @@ int gom_asso_activate_f32(const float* logits, int ld, const int* frame_offsets,
 int gom_track_score_f32(const float* act, int ld, const int* meta, const float* decay, const float* boxes, float img_w,
                         float img_h, int n_k, int Np, int M, int with_iou, float max_center_dist, float* traj,
                         void* stream);
+/* Short-term matching for ALL (previous, current) frame pairs of a clip in one launch: per current detection i of pair
+ * p, q.k^T logits against the previous frame's rows, softmax with the zero background logit (lstmatcher.py:373-381) and
+ * S[i,j] = max(a_j, IoU(i,j)) (gom_lstmatcher.py:429-445 for tracks seen once).  pairs [device] int32 [P][6] =
+ * (first memory row, n_prev, n_cur, first tgt row, first box row, offset of the pair's [n_cur, n_prev] block in S);
+ * row_pair [total_cur_rows]; boxes [rows,4] px in memory-row order; max_prev <= 320. */
+int gom_short_term_pairs_f32(const float* tgt, const float* memory, int d, const int* pairs, const int* row_pair,
+                             const float* boxes, float img_w, float img_h, int with_iou, int total_cur_rows, int max_prev,
+                             float* S, void* stream);
 /* [host runtime] The whole device chain of one association match -- gather of the window's embeddings, the matcher
  * transformer (roi_heads/transformer.py:60-96: n_enc post-norm encoder layers over all N rows, n_dec cross-attention
  * decoder layers for the query rows [lo, hi), norms Identity), q.k^T logits, `_activate_asso` (lstmatcher.py:373-381)

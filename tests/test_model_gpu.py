@@ -175,6 +175,37 @@ def test_native_match_runtime_equals_python_composition(builtin, n_t, k):
         assert torch.equal(out[True], out[False])
 
 
+@pytest.mark.parametrize("builtin", ["icdar15", "pp_dstext"])
+def test_batched_short_term_equals_per_pair(builtin):
+    """All frame pairs in one ragged launch per op (segmented attention + fused logits/softmax/IoU kernel) give the same
+    scores as the per-pair kernels: ragged sizes, a single-detection frame, > 64 detections in a frame."""
+    from gomatching_amd import ops
+    from gomatching_amd.modeling.roi_heads import build_roi_heads
+    from gomatching_amd.weights import synth_state_dict
+    cfg = mini_cfg(builtin, device=DEV)
+    heads = build_roi_heads(cfg, synth_state_dict(cfg, seed=11), torch.device(DEV))
+    g = torch.Generator().manual_seed(3)
+    sizes = [(5, 9), (9, 1), (1, 70), (70, 33), (33, 33)]
+    pairs, off = [], 0
+    for n_prev, n_cur in sizes:
+        pairs.append((off, n_prev, n_cur))
+        off += n_prev + n_cur
+    src = torch.randn(off, heads.feature_dim, generator=g).to(DEV)
+    xy = torch.rand(off, 2, generator=g) * 80
+    boxes = torch.cat([xy, xy + 10 + torch.rand(off, 2, generator=g) * 30], 1).to(DEV)
+    res = {}
+    for batched in (True, False):
+        ops.BATCHED_SHORT_TERM = batched
+        try:
+            res[batched] = [x.clone() for x in heads.short_term_scores(src, pairs, boxes, (96, 128))]
+        finally:
+            ops.BATCHED_SHORT_TERM = True
+    for (_, n_prev, n_cur), a, b in zip(pairs, res[True], res[False]):
+        assert a.shape == b.shape == (n_cur, n_prev)
+        assert torch.isfinite(a).all() and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+        _close(a, b.cpu(), 1e-6, "batched vs per-pair short-term scores")
+
+
 @pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
 @pytest.mark.parametrize("step", [8, 3])
 def test_end_to_end_clip_golden(builtin, tag, step, gemm_mode):
