@@ -613,32 +613,74 @@ class GoMatching:
         return instances, id_count
 
     def _remove_short_track(self, instances):
-        """gom_lstmatcher.py:566-577."""
+        """gom_lstmatcher.py:566-577.  The per-frame boolean indexing of the reference (seven index kernels and a
+        host->device copy per frame) is done for all frames at once: one copy of the kept positions, then one
+        cat + one index_select per field, the per-frame results being views of the selected rows."""
         ids = np.concatenate([self._host(x)["ids"] for x in instances]) if instances else np.zeros((0,), np.int64)
         uniq, counts = np.unique(ids, return_counts=True)
         short = set(int(u) for u, c in zip(uniq, counts) if c < self.min_track_len)
+        todo, keeps, gidx, off = [], [], [], 0
         for k in range(len(instances)):
             hid = self._host(instances[k])["ids"]
             keep = np.array([int(t) not in short for t in hid], dtype=bool)
-            if keep.all():                                       # nothing to drop: skip seven index kernels
+            if keep.all():                                       # nothing to drop in this frame
                 continue
-            g = instances[k]._gom
-            idx = torch.from_numpy(np.nonzero(keep)[0]).to(self.device)
-            new = instances[k][idx]
-            new._gom = {"boxes": g["boxes"][keep], "ids": hid[keep], "row0": None}
+            todo.append(k)
+            keeps.append(keep)
+            gidx.append(off + np.nonzero(keep)[0])
+            off += len(hid)
+        if not todo:
+            return instances
+        idx = self._h2d(np.concatenate(gidx).astype(np.int64))
+        frames = [instances[k] for k in todo]
+        common = [f for f in frames[0]._fields if all(x.has(f) for x in frames)]
+        n_keep = [int(kp.sum()) for kp in keeps]
+        picked = {}
+        for f in common:
+            vals = [x._fields[f] for x in frames]
+            boxes = isinstance(vals[0], Boxes)
+            cat = torch.cat([(v.tensor if boxes else v) for v in vals])
+            sel, o, outs = cat.index_select(0, idx), 0, []
+            for n in n_keep:
+                outs.append(Boxes(sel[o:o + n]) if boxes else sel[o:o + n])
+                o += n
+            picked[f] = outs
+        for j, k in enumerate(todo):
+            old, keep = instances[k], keeps[j]
+            new = Instances(old.image_size)
+            local = None
+            for f, v in old._fields.items():
+                if f in picked:
+                    new.set(f, picked[f][j])
+                else:                                            # a field only some frames carry (reid_features)
+                    if local is None:
+                        local = torch.from_numpy(np.nonzero(keep)[0]).to(self.device)
+                    new.set(f, v[local])
+            g = old._gom
+            new._gom = {"boxes": g["boxes"][keep], "ids": g["ids"][keep], "row0": None}
             instances[k] = new
         return instances
 
     def batch_postprocess(self, instances, image_sizes):
         """gom_lstmatcher.py:353-364 + detector_postprocess :78-111 (non-ViTAE branch): scale ctrl_points and
-        bd to the original frame size; pred_boxes stay in network-input pixels."""
-        processed = []
-        for r, image_size in zip(instances, image_sizes):
-            height, width = image_size[0], image_size[1]
-            sx, sy = width / r.image_size[1], height / r.image_size[0]
-            if r.has("ctrl_points"):
-                r._fields["ctrl_points"] = ops.scale_xy_(r.ctrl_points.contiguous(), sx, sy)
-            if r.has("pred_boxes") and not isinstance(r.bd, list):
-                r._fields["bd"] = ops.scale_xy_(r.bd.contiguous(), sx, sy)
-            processed.append({"instances": r})
-        return processed
+        bd to the original frame size; pred_boxes stay in network-input pixels.  Frames that share the scale factors
+        (a whole video normally) are scaled by ONE kernel per field over their concatenated rows."""
+        groups = {}
+        for i, (r, image_size) in enumerate(zip(instances, image_sizes)):
+            key = (image_size[1] / r.image_size[1], image_size[0] / r.image_size[0], r.has("ctrl_points"),
+                   r.has("pred_boxes") and not isinstance(r.bd, list))
+            groups.setdefault(key, []).append(i)
+        for (sx, sy, has_ctrl, has_bd), idxs in groups.items():
+            for field, on in (("ctrl_points", has_ctrl), ("bd", has_bd)):
+                if not on:
+                    continue
+                vals = [instances[i]._fields[field] for i in idxs]
+                if len(vals) == 1:
+                    instances[idxs[0]]._fields[field] = ops.scale_xy_(vals[0].contiguous(), sx, sy)
+                    continue
+                cat = ops.scale_xy_(torch.cat(vals), sx, sy)       # cat allocates: the per-frame inputs stay intact
+                o = 0
+                for i, v in zip(idxs, vals):
+                    instances[i]._fields[field] = cat[o:o + v.shape[0]]
+                    o += v.shape[0]
+        return [{"instances": r} for r in instances]

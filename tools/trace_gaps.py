@@ -32,5 +32,23 @@ def main(path, top=14):
             print("    %-70s x%-5d %8.1f us avg  %7.2f ms" % (n, c, t / c / 1e3, t / 1e6))
 
 
+def window(path, queue, start_frac=0.8, count=70):
+    """Consecutive kernels of one queue: start offset, duration and gap to the previous one (us)."""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Queue_Id") == queue:
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60]))
+    rows.sort()
+    i0 = int(len(rows) * start_frac)
+    base = rows[i0][0]
+    for i in range(i0, min(i0 + count, len(rows))):
+        s, e, n = rows[i]
+        print("%9.1f  dur %7.1f  gap %7.1f  %s" % ((s - base) / 1e3, (e - s) / 1e3, (s - rows[i - 1][1]) / 1e3, n))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 2:
+        window(sys.argv[1], sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.8)
+    else:
+        main(sys.argv[1])
