@@ -44,6 +44,9 @@ struct Args {
     int relu;
     int r_cols;                                  // residual applies to columns < r_cols
     int H, Wd, cin_log2, OH, OW, stride, pad;
+    // split-K (few output tiles, long K): blockIdx.y owns k-tiles [y*kt_per_split, ...) and stores raw partial sums
+    int kt_per_split;
+    float* partial;                              // [splits][M][N] or nullptr
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -145,7 +148,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(const Args p) {
     f32x4 a_even[A_UNITS], a_odd[A_UNITS];                 // two k-tiles of A in flight (HBM latency > one MFMA phase)
     u32x4 w_reg[3][W_UNITS];
 
-    auto load_A = [&](int kt, f32x4 (&a_reg)[A_UNITS]) {
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int ktb = p.partial ? (int)blockIdx.y * p.kt_per_split : 0;   // first k-tile of this workgroup
+    const int nk = p.partial ? max(0, min(nk_all - ktb, p.kt_per_split)) : nk_all;
+
+    auto load_A = [&](int kt_rel, f32x4 (&a_reg)[A_UNITS]) {
+        const int kt = kt_rel + ktb;
         unsigned koff = (unsigned)(kt * BK) * 4u;            // plain GEMM: columns kt*BK..
         const bool k_ok = kt * BK + kq * 4 < p.K;            // K tail reads nothing (weights are zero there anyway)
         int kh = 0, kw = 0;
@@ -169,8 +177,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(const Args p) {
             a_reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
         }
     };
-    auto load_W = [&](int kt) {
-        const unsigned koff = (unsigned)(kt * BK) * 2u;      // planes are zero-padded to ldw (multiple of 32)
+    auto load_W = [&](int kt_rel) {
+        const unsigned koff = (unsigned)((kt_rel + ktb) * BK) * 2u;      // planes are zero-padded to ldw (multiple of 32)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -205,7 +213,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(const Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
     const int fr = lane & 31, fh = lane >> 5;
     const unsigned char* a_base = As + (wr * WM + fr) * ROW_BYTES + fh * 16;
     const unsigned char* w_base = Ws + (wc * WN + fr) * ROW_BYTES + fh * 16;
@@ -239,10 +246,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(const Args p) {
         }
     };
 
-    load_A(0, a_even);
-    load_W(0);
-    if (nk > 1) load_A(1, a_odd);
-    store_tile(a_even);
+    if (nk > 0) {
+        load_A(0, a_even);
+        load_W(0);
+        if (nk > 1) load_A(1, a_odd);
+        store_tile(a_even);
+    }
     __syncthreads();
 
     for (int kt = 0; kt < nk; kt += 2) {
@@ -267,6 +276,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(const Args p) {
 
     // ---- epilogue: y = acc*scale + shift (+ residual) (ReLU) --------------------------------------
     const float relu_lo = p.relu ? 0.f : -INFINITY;
+    if (p.partial) {                                         // split-K: raw sums, the reducer applies the epilogue
+        float* dst = p.partial + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wc * WN + j * 32 + fr;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (n < p.N && m < p.M) dst[(size_t)m * p.N + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     const bool vec_ok = ((p.N | p.ldc) & 3) == 0 && (!p.R || (p.ldr & 3) == 0);
     if (vec_ok) {
         // stage each 32-row slab of the wave's patch through (now free) LDS so that global traffic is whole
@@ -333,20 +357,35 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(const Args p) {
     }
 }
 
+// sums the split-K partials in split order (deterministic) and applies the epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const Args p, int splits) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)p.M * p.N) return;
+    const int m = (int)(i / p.N), n = (int)(i % p.N);
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += p.partial[(size_t)s * p.M * p.N + i];
+    v = v * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+    if (p.R && n < p.r_cols) v += p.R[(size_t)m * p.ldr + n];
+    if (p.relu) v = fmaxf(v, 0.f);
+    p.C[(size_t)m * p.ldc + n] = v;
+}
+
 template <int BM, int BN, int KH, int KW>
-int launch(const Args& a, hipStream_t s) {
+int launch(const Args& a, hipStream_t s, int splits = 1) {
     const long tiles = (long)cdiv(a.M, BM) * cdiv(a.N, BN);
     if (tiles <= 0) return GOM_OK;
     const int lds = 3 * (BM + BN) * ROW_BYTES;
     auto kern = gemm_bf16x6_kernel<BM, BN, KH, KW>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, s, a);
+    if (a.partial)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv((long)a.M * a.N, 256)), dim3(256), 0, s, a, splits);
     return gom_launch_status();
 }
 
 template <int KH, int KW>
-int dispatch(const Args& a, hipStream_t s) {
-    if (a.N <= 64) return launch<128, 64, KH, KW>(a, s);
-    return launch<128, 128, KH, KW>(a, s);
+int dispatch(const Args& a, hipStream_t s, int splits = 1) {
+    if (a.N <= 64) return launch<128, 64, KH, KW>(a, s, splits);
+    return launch<128, 128, KH, KW>(a, s, splits);
 }
 
 // fp32 [N, ldw_in] -> three bf16 planes [3][N][Kpad] (zero padded in K)
@@ -394,10 +433,31 @@ extern "C" int gom_gemm_f32_bf16x6(const float* A, const int* a_rows, int lda, c
     return dispatch<0, 0>(a, (hipStream_t)stream);
 }
 
+// Number of K slices for a problem with few output tiles and a long K (0 = do not split): e.g. input_proj[3], a 3x3 s2
+// conv 2048 -> 256 on res5 (M = 3584 pixels, K = 18432): 56 tiles of 576 k-tiles each leave 200 of the 256 CUs idle.
+extern "C" int gom_conv_bf16x6_splits(int M, int N, int K) {
+    const long tiles = (long)cdiv(M, 128) * cdiv(N, N <= 64 ? 64 : 128);
+    const int nk = cdiv(K, BK);
+    if (tiles <= 0 || tiles >= 128 || nk < 64) return 0;
+    int s = (int)(512 / tiles);
+    if (s > 16) s = 16;
+    if (s > nk / 16) s = nk / 16;
+    return s < 2 ? 0 : s;
+}
+
 extern "C" int gom_conv2d_nhwc_f32_bf16x6(const float* X, const void* Wplanes, long w_plane_stride, int ldw,
                                           const float* scale, const float* shift, const float* R, int relu, float* Y,
                                           int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                           void* stream) {
+    return gom_conv2d_nhwc_f32_bf16x6_splitk(X, Wplanes, w_plane_stride, ldw, scale, shift, R, relu, Y, B, H, Wd, Cin,
+                                             Cout, KH, KW, stride, pad, nullptr, 0, 0, stream);
+}
+
+extern "C" int gom_conv2d_nhwc_f32_bf16x6_splitk(const float* X, const void* Wplanes, long w_plane_stride, int ldw,
+                                                 const float* scale, const float* shift, const float* R, int relu,
+                                                 float* Y, int B, int H, int Wd, int Cin, int Cout, int KH, int KW,
+                                                 int stride, int pad, void* workspace, long workspace_bytes, int splits,
+                                                 void* stream) {
     GOM_CHECK_ARG(X && Wplanes && Y);
     GOM_CHECK_ARG(B > 0 && H > 0 && Wd > 0 && Cin >= 4 && Cout > 0 && stride > 0 && pad >= 0);
     GOM_CHECK_ARG((Cin & (Cin - 1)) == 0);
@@ -416,11 +476,18 @@ extern "C" int gom_conv2d_nhwc_f32_bf16x6(const float* X, const void* Wplanes, l
     a.H = H; a.Wd = Wd; a.cin_log2 = lg; a.OH = OH; a.OW = OW; a.stride = stride; a.pad = pad;
     GOM_CHECK_ARG(ldw >= a.K && (ldw % 32) == 0 && (long)a.M * Cout < (1L << 31));
     hipStream_t s = (hipStream_t)stream;
+    if (splits > 1) {
+        GOM_CHECK_ARG(workspace && workspace_bytes >= (long)sizeof(float) * splits * a.M * a.N);
+        a.partial = (float*)workspace;
+        a.kt_per_split = cdiv(cdiv(a.K, BK), splits);
+    } else {
+        splits = 1;
+    }
     if (KH == 1 && stride == 1 && pad == 0) {
         a.H = a.Wd = a.OH = a.OW = 0;
-        return dispatch<0, 0>(a, s);
+        return dispatch<0, 0>(a, s, splits);
     }
-    if (KH == 1) return dispatch<1, 1>(a, s);
-    if (KH == 3) return dispatch<3, 3>(a, s);
-    return dispatch<7, 7>(a, s);
+    if (KH == 1) return dispatch<1, 1>(a, s, splits);
+    if (KH == 3) return dispatch<3, 3>(a, s, splits);
+    return dispatch<7, 7>(a, s, splits);
 }

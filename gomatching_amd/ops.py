@@ -291,9 +291,16 @@ def conv2d_nhwc(x, w_ohwi, scale=None, shift=None, R=None, relu=False, stride=1,
         assert R.shape == y.shape
     if split:
         pl = w_ohwi.planes
-        check(_L().gom_conv2d_nhwc_f32_bf16x6(_p(x), _p(pl), pl.stride(0), pl.stride(1), _p(scale), _p(shift), _p(R),
-                                              1 if relu else 0, _p(y), B, H, Wd, Cin, Cout, KH, KW, stride, pad,
-                                              _stream()), "gom_conv2d_nhwc_f32_bf16x6")
+        M = B * OH * OW
+        splits = _L().gom_conv_bf16x6_splits(M, Cout, KH * KW * Cin)     # few tiles x long K (input_proj[3]): slice K
+        ws, nbytes = None, 0
+        if splits > 1:
+            nbytes = 4 * splits * M * Cout
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        check(_L().gom_conv2d_nhwc_f32_bf16x6_splitk(_p(x), _p(pl), pl.stride(0), pl.stride(1), _p(scale), _p(shift),
+                                                     _p(R), 1 if relu else 0, _p(y), B, H, Wd, Cin, Cout, KH, KW, stride,
+                                                     pad, _p(ws), nbytes, splits, _stream()),
+              "gom_conv2d_nhwc_f32_bf16x6_splitk")
         return y
     check(_L().gom_conv2d_nhwc_f32(_p(x), _p(w_ohwi), _p(scale), _p(shift), _p(R), 1 if relu else 0, _p(y), B, H, Wd,
                                    Cin, Cout, KH, KW, stride, pad, _stream()), "gom_conv2d_nhwc_f32")

@@ -108,6 +108,16 @@ int gom_conv2d_nhwc_f32_bf16x6(const float* X, const void* Wplanes, long w_plane
                                const float* shift, const float* R, int relu, float* Y, int B, int H, int Wd, int Cin,
                                int Cout, int KH, int KW, int stride, int pad, void* stream);
 
+/* Split-K form for convolutions with few output tiles and a long K (input_proj[3]: 3x3 s2 2048 -> 256 on res5, M = 3584,
+ * K = 18432): `splits` K-slices run as separate workgroups into workspace [splits][M][Cout] fp32, a second kernel sums
+ * them in slice order (deterministic) and applies the epilogue.  gom_conv_bf16x6_splits: recommended slice count, 0 =
+ * do not split. */
+int gom_conv_bf16x6_splits(int M, int N, int K);
+int gom_conv2d_nhwc_f32_bf16x6_splitk(const float* X, const void* Wplanes, long w_plane_stride, int ldw,
+                                      const float* scale, const float* shift, const float* R, int relu, float* Y, int B,
+                                      int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                      void* workspace, long workspace_bytes, int splits, void* stream);
+
 /* Same product with the ACTIVATION operand already split: Aplanes [3][M][lda] bf16 written by a producer
  * (gom_split_rows_bf16x3, or the plane outputs of gom_gemm_planes_bf16x6 / gom_layernorm_planes_f32 /
  * gom_msda_fused_forward_planes).  Both operands stream HBM -> LDS by LDS-DMA, no in-loop VALU.  K % 32 == 0, N % 4 == 0.

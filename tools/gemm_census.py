@@ -20,6 +20,7 @@ def main():
     cfg = setup_cfg(builtin="icdar15")
     cfg.MODEL.DEVICE = "cuda"
     model, sd = bench.build_model(cfg, dev)
+    model.use_graphs = False                                  # per-launch events need eager launches
     h, w = resized_shape(720, 1280, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
     clip = make_clip(8, h, w, clip_id=0)
     inputs = [{"image": torch.as_tensor(f.astype("float32").transpose(2, 0, 1)).to(dev), "height": 720, "width": 1280}
