@@ -102,8 +102,11 @@ class GoMatching:
             kind, dtype = ("f32", hw, None), _f32
         if out is None:
             out = torch.empty((len(frames),) + tuple(frames[0].shape), dtype=dtype, device=self.device)
-        for i, f in enumerate(frames):
-            out[i].copy_(f, non_blocking=True)
+        if all(f.device == self.device and f.dtype == dtype for f in frames):
+            torch.stack(frames, out=out)                         # one launch for the whole step
+        else:
+            for i, f in enumerate(frames):
+                out[i].copy_(f, non_blocking=True)
         return out, kind
 
     def _normalise(self, raw, kind):
@@ -178,7 +181,8 @@ class GoMatching:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 tc = {k: 0.0 for k in time_cost if k != "_sync"}
-                with torch.cuda.graph(g):
+                # thread_local: API calls of other threads (RCCL's watchdog polling its events) must not void the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     qf, det = self._detect_core(raw, kind, tc)
                 state = {"graph": g, "raw": raw, "kind": kind, "qf": qf, "det": det}
                 self._graphs[key] = state
