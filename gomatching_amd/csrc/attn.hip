@@ -127,6 +127,73 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
     }
 }
 
+// Row-per-lane form for the DeepSolo decoder's two attentions (head_dim 32; 25 points x batch B*nq and nq queries x
+// batch 25*B, deformable_transformer.py:386-404): the tile kernel above spends a 256-thread workgroup with 64-key
+// tiles and five barriers on a 25 x 25 problem.  Here one workgroup = one (batch, head), one LANE = one query row with
+// q and the output row in registers; K and V of the (batch, head) sit in LDS and are read as wave-uniform (broadcast)
+// ds_read_b128.  Two passes over the keys (max, then exp / sum / PV with the scores recomputed) keep the softmax exact
+// without storing a score row; normalisation by the row sum is applied to the accumulated output.
+template <int HD>
+__global__ __launch_bounds__(512) void mha_rows_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, float* __restrict__ o, int Lq, int Lk,
+                                                       int inner, long q_bo, long q_bi, long q_ss, long k_bo, long k_bi,
+                                                       long k_ss, long v_bo, long v_bi, long v_ss, long o_bo, long o_bi,
+                                                       long o_ss, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                       // [Lk][HD]
+    float* Vs = smem + (size_t)Lk * HD;     // [Lk][HD]
+    const int tid = threadIdx.x, h = blockIdx.y;
+    const long bo = blockIdx.x / inner, bi = blockIdx.x % inner;
+    const float* qb = q + bo * q_bo + bi * q_bi + h * HD;
+    const float* kb = k + bo * k_bo + bi * k_bi + h * HD;
+    const float* vb = v + bo * v_bo + bi * v_bi + h * HD;
+    float* ob = o + bo * o_bo + bi * o_bi + h * HD;
+    for (int u = tid; u < Lk * (HD / 4); u += blockDim.x) {
+        const int r = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
+        *reinterpret_cast<f32x4*>(Ks + r * HD + d4) = *reinterpret_cast<const f32x4*>(kb + r * k_ss + d4);
+        *reinterpret_cast<f32x4*>(Vs + r * HD + d4) = *reinterpret_cast<const f32x4*>(vb + r * v_ss + d4);
+    }
+    const int i = tid;
+    const bool live = i < Lq;
+    f32x4 qv[HD / 4];
+#pragma unroll
+    for (int d = 0; d < HD / 4; ++d)
+        qv[d] = live ? *reinterpret_cast<const f32x4*>(qb + (long)i * q_ss + 4 * d) * scale : f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    auto score = [&](int j) {
+        const float* kr = Ks + j * HD;
+        float s0 = 0.f, s1 = 0.f;                            // two chains: half the dependent-FMA latency
+#pragma unroll
+        for (int d = 0; d < HD / 4; d += 2) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(kr + 4 * d);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(kr + 4 * d + 4);
+            s0 = fmaf(qv[d][0], a[0], s0); s0 = fmaf(qv[d][1], a[1], s0);
+            s0 = fmaf(qv[d][2], a[2], s0); s0 = fmaf(qv[d][3], a[3], s0);
+            s1 = fmaf(qv[d + 1][0], b[0], s1); s1 = fmaf(qv[d + 1][1], b[1], s1);
+            s1 = fmaf(qv[d + 1][2], b[2], s1); s1 = fmaf(qv[d + 1][3], b[3], s1);
+        }
+        return s0 + s1;
+    };
+    float mx = -INFINITY;
+    for (int j = 0; j < Lk; ++j) mx = fmaxf(mx, score(j));
+    f32x4 acc[HD / 4];
+#pragma unroll
+    for (int d = 0; d < HD / 4; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float sum = 0.f;
+    for (int j = 0; j < Lk; ++j) {
+        const float e = expf(score(j) - mx);
+        sum += e;
+        const float* vr = Vs + j * HD;
+#pragma unroll
+        for (int d = 0; d < HD / 4; ++d) acc[d] += *reinterpret_cast<const f32x4*>(vr + 4 * d) * e;
+    }
+    if (live) {
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int d = 0; d < HD / 4; ++d) *reinterpret_cast<f32x4*>(ob + (long)i * o_ss + 4 * d) = acc[d] * inv;
+    }
+}
+
 template <int HD, int QT>
 int launch(const float* q, const float* k, const float* v, float* o, int outer, int inner, int heads, int Lq, int Lk,
            const long* st, float scale, hipStream_t s, bool* fits, const int* seg = nullptr) {
@@ -164,6 +231,20 @@ extern "C" int gom_mha_core_f32(const float* q, const float* k, const float* v, 
     rc = launch<HD, QT>(q, k, v, o, batch_outer, batch_inner, heads, Lq, Lk, strides, scale, s, &fits);        \
     if (rc != GOM_OK || fits) return rc;
     if (head_dim == 32) {
+        const size_t rows_lds = (size_t)2 * Lk * 32 * sizeof(float);
+        if (Lq <= 512 && rows_lds <= 128 * 1024 && ((strides[9] | strides[10] | strides[11]) % 4) == 0) {   // lane = query row
+            auto kern = mha_rows_kernel<32>;
+            if (rows_lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)rows_lds);
+                if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+            }
+            const int threads = (Lq + 63) / 64 * 64;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(batch_outer * batch_inner), (unsigned)heads), dim3(threads), rows_lds, s,
+                               q, k, v, o, Lq, Lk, batch_inner, strides[0], strides[1], strides[2], strides[3], strides[4],
+                               strides[5], strides[6], strides[7], strides[8], strides[9], strides[10], strides[11], scale);
+            return gom_launch_status();
+        }
         TRY(32, 32) TRY(32, 8)
     } else {
         TRY(128, 32) TRY(128, 8)
