@@ -28,7 +28,11 @@ SRC_HW = (720, 1280)
 # MI355X_MICROARCH.md "Matrix cores": fp32-input MFMA 157.3 TFLOP/s dense; bf16 MFMA ~2500 TFLOP/s dense.  The
 # bf16x6 kernel issues 6 bf16 MFMA passes per fp32-equivalent product, so its ceiling in ALGORITHMIC flops is 2500/6.
 PEAKS = {"fp32": ("gemm_f32_kernel<128,128,64,64,0,0>", 157.3, 1),
-         "bf16x6": ("gemm_bf16x6_kernel<128,128,0,0>", 2500.0 / 6.0, 6)}
+         "bf16x6": ("gemm_bf16x6_kernel<128,128,0,0>", 2500.0 / 6.0, 6),
+         "f16x3": ("gemm_f16x3_kernel<128,128,0,0>", 2500.0 / 3.0, 3)}
+DTYPES = {"fp32": "f32 (exact fp32 MFMA)",
+          "bf16x6": "f32 (bf16x6 split MFMA: 24-bit significand products, fp32 accumulate)",
+          "f16x3": "f32 (f16x3 split MFMA: 22-bit significand products, fp32 accumulate; parity tests at fp32 tolerances)"}
 
 
 def pmc_traffic(kernel):
@@ -113,8 +117,9 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="N=1 diagnostic: run the replicated tracker over W copies of this GPU's records per step, i.e. "
                          "the tracker load of a W-GPU run, beside one GPU's detection (value still counts 8 frames/step)")
-    ap.add_argument("--gemm", default="bf16x6", choices=["bf16x6", "fp32"],
-                    help="contraction back-end: split-bf16 on the bf16 matrix cores (default) or exact-fp32 MFMA")
+    ap.add_argument("--gemm", default="f16x3", choices=["f16x3", "bf16x6", "fp32"],
+                    help="contraction back-end: two-plane fp16 split on the fp16 matrix cores (default), three-plane bf16 "
+                         "split, or exact-fp32 MFMA")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -234,7 +239,7 @@ def main():
         "metric": "frames/sec (whole node), 1280x720 clip, 100 queries/frame",
         "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.gemm == "fp32" else "f32 (bf16x6 split MFMA, fp32 accumulate)", "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPES[args.gemm], "data": "synthetic",
         "config": {"workload": "configs[1]: 1280x720 ICDAR15-video clip -> %dx%d net input, %d frames/GPU, "
                                "100 queries, GoMatching_ICDAR15 (R-50 + DeepSolo + LSTMatcher, rescoring), "
                                "random-init synthetic weights" % (net_hw[0], net_hw[1], FRAMES_PER_GPU),
@@ -246,8 +251,9 @@ def main():
         "roofline": {"bound": "mfma", "kernel": PEAKS[args.gemm][0], "achieved": achieved,
                      "peak": PEAKS[args.gemm][1], "unit": "TFLOP/s", "frac": achieved / PEAKS[args.gemm][1],
                      "traffic": pmc_traffic(PEAKS[args.gemm][0]), "mfma_passes_per_product": PEAKS[args.gemm][2],
-                     "peak_note": "algorithmic fp32-equivalent FLOP/s; bf16x6 = dense bf16 MFMA peak 2500 / 6 passes"
-                     if args.gemm == "bf16x6" else "dense fp32-input MFMA peak", "launches_per_step": len(prof) // PROFILE_STEPS,
+                     "peak_note": {"fp32": "dense fp32-input MFMA peak",
+                                   "bf16x6": "algorithmic fp32-equivalent FLOP/s; dense bf16 MFMA peak 2500 / 6 passes",
+                                   "f16x3": "algorithmic fp32-equivalent FLOP/s; dense fp16 MFMA peak 2500 / 3 passes"}[args.gemm], "launches_per_step": len(prof) // PROFILE_STEPS,
                      "avg_launch_us": dur_ms * 1e3 / max(len(prof), 1),
                      "flops_per_launch_avg": flops / max(len(prof), 1),
                      "algorithmic_bytes_per_launch_avg": alg_bytes / max(len(prof), 1),

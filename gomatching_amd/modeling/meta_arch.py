@@ -220,8 +220,9 @@ class GoMatching:
             time_cost["pre_process"] += time.time() - t0
             qf, det = self._detect_core(raw, kind, time_cost)
             hw = kind[1]
-        host = torch.empty(det["small"].shape, dtype=torch.int32, pin_memory=True)
-        host.copy_(det["small"], non_blocking=True)
+        host = torch.empty((det["small"].numel() + 1,), dtype=torch.int32, pin_memory=True)
+        host[:-1].copy_(det["small"], non_blocking=True)
+        host[-1:].copy_(ops.range_flag(self.device), non_blocking=True)   # f16x3 kernels: "a result was not finite"
         ev = torch.cuda.Event()
         ev.record()
         return {"query_features": qf, "det": det, "host": host, "event": ev, "B": B, "hw": hw}
@@ -240,6 +241,9 @@ class GoMatching:
         for tns in (h["query_features"], det["small"], det["ctrl"], det["bd"], det["recs"]):
             tns.record_stream(cur)
         small = h["host"].numpy()
+        if small[-1] != 0:                                       # never a silent wrong result (gemm_f16x3.hip)
+            ops.check_range_flag(self.device)
+        small = small[:-1]
         o1, o2, o3 = det["small_layout"]
         counts = small[:o1]
         keep = small[o1:o2].reshape(B, nq)

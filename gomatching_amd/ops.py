@@ -56,14 +56,15 @@ def _chk_f32(*ts):
 # ------------------------------------------------------------------------------------------ GEMM
 # "bf16x6": weights of the big contractions are pre-split into three bf16 planes and multiplied on the bf16
 # matrix cores with fp32-level accuracy (csrc/gemm_bf16x6.hip); "fp32": exact-fp32 MFMA everywhere.
-GEMM_MODE = "bf16x6"
+GEMM_MODE = "f16x3"
 
 
 class SplitWeight:
-    """[3, N, Kpad] bf16 planes of an fp32 weight [N, K] (row slices keep the plane stride)."""
+    """Pre-split planes of an fp32 weight [N, K] (row slices keep the plane stride): kind "bf16x6" = [3, N, Kpad] bf16,
+    kind "f16x3" = [2, N, Kpad] fp16 of the power-of-two-scaled rows + `inv_scale` [N] fp32."""
 
-    def __init__(self, planes, N, K, conv_shape=None):
-        self.planes, self.N, self.K, self.conv_shape = planes, N, K, conv_shape
+    def __init__(self, planes, N, K, conv_shape=None, kind="bf16x6", inv_scale=None):
+        self.planes, self.N, self.K, self.conv_shape, self.kind, self.inv_scale = planes, N, K, conv_shape, kind, inv_scale
 
     @property
     def shape(self):
@@ -72,28 +73,60 @@ class SplitWeight:
     def __getitem__(self, sl):
         assert isinstance(sl, slice) and sl.step in (None, 1)
         a, b, _ = sl.indices(self.N)
-        return SplitWeight(self.planes[:, a:b], b - a, self.K)
+        return SplitWeight(self.planes[:, a:b], b - a, self.K, kind=self.kind,
+                           inv_scale=None if self.inv_scale is None else self.inv_scale[a:b])
 
 
-def split_weight(w, conv_shape=None):
-    """w: fp32 [N, K] (contiguous) on the GPU -> SplitWeight."""
+def split_weight(w, conv_shape=None, kind=None):
+    """w: fp32 [N, K] (contiguous) on the GPU -> SplitWeight of the current GEMM_MODE's kind."""
     _chk_f32(w)
+    kind = kind or (GEMM_MODE if GEMM_MODE in ("bf16x6", "f16x3") else "bf16x6")
     N, K = w.shape
     Kpad = (K + 31) // 32 * 32
+    if kind == "f16x3":
+        planes = torch.empty((2, N, Kpad), dtype=torch.float16, device=w.device)
+        inv = torch.empty((N,), dtype=_f32, device=w.device)
+        check(_L().gom_split_f16x2(_p(w), K, N, K, _p(planes), Kpad, _p(inv), _stream()), "gom_split_f16x2")
+        return SplitWeight(planes, N, K, conv_shape, "f16x3", inv)
     planes = torch.empty((3, N, Kpad), dtype=torch.bfloat16, device=w.device)
     check(_L().gom_split_bf16x3(_p(w), K, N, K, _p(planes), Kpad, _stream()), "gom_split_bf16x3")
     return SplitWeight(planes, N, K, conv_shape)
 
 
+_range_flags = {}
+
+
+def _dev_index(device):
+    d = torch.device(device)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def range_flag(device):
+    """Device word the f16x3 kernels set when a result is not finite (an activation beyond fp16's range)."""
+    key = _dev_index(device)
+    if key not in _range_flags:
+        _range_flags[key] = torch.zeros((1,), dtype=torch.int32, device=torch.device("cuda", key))
+    return _range_flags[key]
+
+
+def check_range_flag(device):
+    """Host check at a sync point: raises instead of letting an out-of-range activation pass as a result."""
+    f = _range_flags.get(_dev_index(device))
+    if f is not None and int(f.item()) != 0:
+        f.zero_()
+        raise _lib_mod.GomError("f16x3 GEMM produced a non-finite value: an activation left fp16's range (|x| > 65504) "
+                                "or the input was not finite; run with ops.GEMM_MODE = 'bf16x6'")
+
+
 def prep_weight(w, min_n=33):
     """Weight preparation policy for the detector's nn.Linear weights."""
-    if GEMM_MODE == "bf16x6" and w.shape[0] >= min_n:
+    if GEMM_MODE in ("bf16x6", "f16x3") and w.shape[0] >= min_n:
         return split_weight(w.contiguous())
     return w
 
 
 def prep_conv_weight(w_ohwi):
-    if GEMM_MODE == "bf16x6" and w_ohwi.shape[0] >= 33:
+    if GEMM_MODE in ("bf16x6", "f16x3") and w_ohwi.shape[0] >= 33:
         Cout = w_ohwi.shape[0]
         return split_weight(w_ohwi.reshape(Cout, -1).contiguous(), conv_shape=tuple(w_ohwi.shape))
     return w_ohwi
@@ -116,12 +149,17 @@ def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = (r_cols if r_cols is not None else N) if R is not None else 0
-    check(_L().gom_gemm_f32_bf16x6(_p(A), _p(rows), lda, _p(pl), pl.stride(0), pl.stride(1), _p(scale),
-                                   _p(bias), _p(R), ldr, rc, 1 if relu else 0, _p(out), ldc, M, N, K, _stream()),
-          "gom_gemm_f32_bf16x6")
+    if W.kind == "f16x3":
+        check(_L().gom_gemm_f32_f16x3(_p(A), _p(rows), lda, _p(pl), pl.stride(0), pl.stride(1), _p(W.inv_scale),
+                                      _p(scale), _p(bias), _p(R), ldr, rc, 1 if relu else 0, _p(out), ldc, M, N, K,
+                                      _p(range_flag(A.device)), _stream()), "gom_gemm_f32_f16x3")
+    else:
+        check(_L().gom_gemm_f32_bf16x6(_p(A), _p(rows), lda, _p(pl), pl.stride(0), pl.stride(1), _p(scale),
+                                       _p(bias), _p(R), ldr, rc, 1 if relu else 0, _p(out), ldc, M, N, K, _stream()),
+              "gom_gemm_f32_bf16x6")
     if prof is not None:
         e1.record()
-        nbytes = 4.0 * M * K + 6.0 * N * pl.shape[2] + 4.0 * M * N + (4.0 * M * rc if R is not None else 0.0)
+        nbytes = 4.0 * M * K + 2.0 * pl.shape[0] * N * pl.shape[2] + 4.0 * M * N + (4.0 * M * rc if R is not None else 0.0)
         prof.append((e0, e1, 2.0 * M * N * K, nbytes))
     return out
 
@@ -169,7 +207,7 @@ def gemm_planes(A, W, bias=None, scale=None, R=None, relu=False, out=None, out_p
                 want="f32"):
     """C = act(A @ W^T * scale + bias + R) with A a `Planes` and W a `SplitWeight`; `want` in {"f32","planes","both"}
     selects fp32 rows and/or bf16 planes of the result (returned in that order)."""
-    assert isinstance(A, Planes) and isinstance(W, SplitWeight)
+    assert isinstance(A, Planes) and isinstance(W, SplitWeight) and W.kind == "bf16x6"
     M, K = A.shape
     N = W.N
     assert W.K == K and K % 32 == 0 and N % 4 == 0
@@ -297,6 +335,12 @@ def conv2d_nhwc(x, w_ohwi, scale=None, shift=None, R=None, relu=False, stride=1,
         if splits > 1:
             nbytes = 4 * splits * M * Cout
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        if w_ohwi.kind == "f16x3":
+            check(_L().gom_conv2d_nhwc_f32_f16x3(_p(x), _p(pl), pl.stride(0), pl.stride(1), _p(w_ohwi.inv_scale),
+                                                 _p(scale), _p(shift), _p(R), 1 if relu else 0, _p(y), B, H, Wd, Cin,
+                                                 Cout, KH, KW, stride, pad, _p(ws), nbytes, splits,
+                                                 _p(range_flag(x.device)), _stream()), "gom_conv2d_nhwc_f32_f16x3")
+            return y
         check(_L().gom_conv2d_nhwc_f32_bf16x6_splitk(_p(x), _p(pl), pl.stride(0), pl.stride(1), _p(scale), _p(shift),
                                                      _p(R), 1 if relu else 0, _p(y), B, H, Wd, Cin, Cout, KH, KW, stride,
                                                      pad, _p(ws), nbytes, splits, _stream()),

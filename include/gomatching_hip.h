@@ -108,6 +108,21 @@ int gom_conv2d_nhwc_f32_bf16x6(const float* X, const void* Wplanes, long w_plane
                                const float* shift, const float* R, int relu, float* Y, int B, int H, int Wd, int Cin,
                                int Cout, int KH, int KW, int stride, int pad, void* stream);
 
+/* "f16x3": the same products on the fp16 matrix cores from TWO fp16 planes per operand and three MFMA passes
+ * (a0b0 + a0b1 + a1b0; 22 significand bits, relative error ~7e-7 per product, half the MFMA work of bf16x6).
+ * Weights: gom_split_f16x2 scales each row by a power of two into fp16's upper normal range before the split and returns
+ * the inverse scales (`wscale`, applied to the accumulator).  Activations are split unscaled: |a| <= 65504, absolute
+ * accuracy 3e-8 below ~0.25; a non-finite result sets *flag (device int, may be NULL) -- checked by the host once per
+ * step.  Otherwise the arguments of the bf16x6 entry points; `splits` / workspace as gom_conv2d_nhwc_f32_bf16x6_splitk. */
+int gom_split_f16x2(const float* W, int ldw, int N, int K, void* planes_out, int Kpad, float* inv_scale, void* stream);
+int gom_gemm_f32_f16x3(const float* A, const int* a_rows, int lda, const void* Wplanes, long w_plane_stride, int ldw,
+                       const float* wscale, const float* scale, const float* shift, const float* R, int ldr, int r_cols,
+                       int relu, float* C, int ldc, int M, int N, int K, int* flag, void* stream);
+int gom_conv2d_nhwc_f32_f16x3(const float* X, const void* Wplanes, long w_plane_stride, int ldw, const float* wscale,
+                              const float* scale, const float* shift, const float* R, int relu, float* Y, int B, int H,
+                              int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
+                              long workspace_bytes, int splits, int* flag, void* stream);
+
 /* Split-K form for convolutions with few output tiles and a long K (input_proj[3]: 3x3 s2 2048 -> 256 on res5, M = 3584,
  * K = 18432): `splits` K-slices run as separate workgroups into workspace [splits][M][Cout] fp32, a second kernel sums
  * them in slice order (deterministic) and applies the epilogue.  gom_conv_bf16x6_splits: recommended slice count, 0 =

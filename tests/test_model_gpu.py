@@ -10,9 +10,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(params=["bf16x6", "fp32"])
+@pytest.fixture(params=["f16x3", "bf16x6", "fp32"])
 def gemm_mode(request):
-    """Both contraction back-ends: split-bf16 (default) and exact-fp32 MFMA, held to the same tolerances."""
+    """All contraction back-ends -- two-plane fp16 split (default), three-plane bf16 split, exact-fp32 MFMA -- held to the
+    same tolerances."""
     from gomatching_amd import ops
     old = ops.GEMM_MODE
     ops.GEMM_MODE = request.param

@@ -43,23 +43,26 @@ def test_gemm_shapes(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(1, 64, 256), (25, 38, 256), (300, 384, 256), (513, 129, 1024), (100, 1024, 6400),
                                    (4097, 256, 256), (130, 64, 64), (777, 1536, 256), (64, 100, 36)])
-def test_gemm_bf16x6_shapes(M, N, K):
-    """Split-bf16 path: same tolerance as the exact-fp32 MFMA kernel (reference in float64)."""
+@pytest.mark.parametrize("kind", ["f16x3", "bf16x6"])
+def test_gemm_split_shapes(M, N, K, kind):
+    """Split-precision paths (two fp16 planes x 3 passes, three bf16 planes x 6 passes): same tolerance as the exact-fp32
+    MFMA kernel (reference in float64)."""
     ops = _ops()
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g) * 3
     W = torch.randn(N, K, generator=g) / math.sqrt(K)
     b = torch.randn(N, generator=g)
-    sw = ops.split_weight(W.to(DEV))
+    sw = ops.split_weight(W.to(DEV), kind=kind)
     out = ops.gemm(A.to(DEV), sw, bias=b.to(DEV))
     ref = (A.double() @ W.double().t() + b.double()).float()
-    _close(out, ref, 2e-5, 1e-5, "gemm bf16x6 %s" % ((M, N, K),))
+    _close(out, ref, 2e-5, 1e-5, "gemm %s %s" % (kind, (M, N, K)))
     if N > 40:                                       # row slices of the planes (in_proj q/k/v style)
         out2 = ops.gemm(A.to(DEV), sw[8:40], bias=b[8:40].to(DEV))
         _close(out2, ref[:, 8:40], 2e-5, 1e-5, "sliced planes")
 
 
-def test_gemm_bf16x6_epilogue_gather_and_extremes():
+@pytest.mark.parametrize("kind", ["f16x3", "bf16x6"])
+def test_gemm_split_epilogue_gather_and_extremes(kind):
     ops = _ops()
     g = torch.Generator().manual_seed(13)
     M, N, K = 333, 256, 512
@@ -67,20 +70,36 @@ def test_gemm_bf16x6_epilogue_gather_and_extremes():
     W = torch.randn(N, K, generator=g) / math.sqrt(K)
     b, sc = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
     R = torch.randn(M, N, generator=g)
-    sw = ops.split_weight(W.to(DEV))
+    sw = ops.split_weight(W.to(DEV), kind=kind)
     out = ops.gemm(A.to(DEV), sw, bias=b.to(DEV), scale=sc.to(DEV), A2=A2.to(DEV), R=R.to(DEV), relu=True)
     ref = F.relu(((A + A2).double() @ W.double().t()).float() * sc + b + R)
     _close(out, ref, 3e-5, 1e-5, "epilogue")
     rows = torch.randint(0, M, (77,), generator=g, dtype=torch.int64)
     out = ops.gemm(A.to(DEV), sw, bias=b.to(DEV), rows=rows.to(torch.int32).to(DEV))
     _close(out, (A[rows].double() @ W.double().t()).float() + b, 3e-5, 1e-5, "row gather")
-    # wide dynamic range: tiny and huge magnitudes in one dot product keep fp32-level RELATIVE accuracy
-    A3 = torch.randn(64, K, generator=g) * torch.logspace(-6, 6, K)
-    W3 = torch.randn(128, K, generator=g) * torch.logspace(3, -3, K)
-    out = ops.gemm(A3.to(DEV), ops.split_weight(W3.to(DEV)))
-    ref = A3.double() @ W3.double().t()
-    scale = (A3.double().abs() @ W3.double().abs().t())
-    assert float(((out.cpu().double() - ref).abs() / scale).max()) < 2e-6
+    if kind == "bf16x6":
+        # wide dynamic range: tiny and huge magnitudes in one dot product keep fp32-level RELATIVE accuracy (bf16 planes
+        # carry fp32's exponent range; the fp16 planes do not, which is what the next block pins instead)
+        A3 = torch.randn(64, K, generator=g) * torch.logspace(-6, 6, K)
+        W3 = torch.randn(128, K, generator=g) * torch.logspace(3, -3, K)
+        out = ops.gemm(A3.to(DEV), ops.split_weight(W3.to(DEV), kind=kind))
+        ref = A3.double() @ W3.double().t()
+        scale = (A3.double().abs() @ W3.double().abs().t())
+        assert float(((out.cpu().double() - ref).abs() / scale).max()) < 2e-6
+        return
+    # f16x3 contract: weights of ANY magnitude (rows are power-of-two scaled before the split), activations up to 65504
+    # with 2^-22 relative accuracy above ~0.25 and 3e-8 absolute accuracy below; beyond the range the flag is raised
+    for w_mag, a_mag in ((1e-9, 1.0), (1e6, 1.0), (1.0, 1e4), (1.0, 1e-3)):
+        A3 = torch.randn(64, K, generator=g) * a_mag
+        W3 = torch.randn(128, K, generator=g) * w_mag * torch.logspace(-3, 3, 128).view(-1, 1)
+        out = ops.gemm(A3.to(DEV), ops.split_weight(W3.to(DEV), kind=kind))
+        ref = A3.double() @ W3.double().t()
+        bound = 2e-6 * (A3.double().abs() @ W3.double().abs().t()) + 1e-7 * W3.double().abs().sum(1).view(1, -1)
+        assert bool(((out.cpu().double() - ref).abs() <= bound).all()), (w_mag, a_mag)
+    ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))       # nothing so far left the range
+    ops.gemm(torch.full((8, K), 7e4).to(DEV), ops.split_weight(torch.ones(64, K).to(DEV), kind=kind))
+    with pytest.raises(Exception, match="fp16's range"):
+        ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 64, 256), (300, 384, 256), (513, 132, 1024), (2000, 640, 64), (129, 1024, 32)])
@@ -90,7 +109,7 @@ def test_gemm_planes_identical_to_bf16x6(M, N, K):
     from gomatching_amd import ops
     torch.manual_seed(M + N + K)
     A = torch.randn(M, K, device=DEV) * (torch.rand(M, 1, device=DEV) * 8)
-    W = ops.split_weight(torch.randn(N, K, device=DEV))
+    W = ops.split_weight(torch.randn(N, K, device=DEV), kind="bf16x6")
     b, sc = torch.randn(N, device=DEV), torch.rand(N, device=DEV) + 0.5
     R = torch.randn(M, N, device=DEV)
     Ap = ops.split_rows(A)
@@ -110,14 +129,16 @@ def test_gemm_planes_chain_and_bad_args():
     from gomatching_amd import ops, lib
     torch.manual_seed(5)
     A = torch.randn(777, 256, device=DEV)
-    W1, W2 = ops.split_weight(torch.randn(1024, 256, device=DEV) * 0.1), ops.split_weight(torch.randn(256, 1024, device=DEV) * 0.1)
+    W1 = ops.split_weight(torch.randn(1024, 256, device=DEV) * 0.1, kind="bf16x6")
+    W2 = ops.split_weight(torch.randn(256, 1024, device=DEV) * 0.1, kind="bf16x6")
     h_ref = ops.gemm(A, W1, relu=True)
     y_ref = ops.gemm(h_ref, W2, R=A)
     h = ops.gemm_planes(ops.split_rows(A), W1, relu=True, want="planes")
     y = ops.gemm_planes(h, W2, R=A)
     assert torch.equal(y, y_ref)
     with pytest.raises(AssertionError):
-        ops.gemm_planes(ops.split_rows(torch.randn(8, 40, device=DEV)), ops.split_weight(torch.randn(64, 40, device=DEV)))
+        ops.gemm_planes(ops.split_rows(torch.randn(8, 40, device=DEV)),
+                        ops.split_weight(torch.randn(64, 40, device=DEV), kind="bf16x6"))
     L = lib.load()
     assert L.gom_gemm_planes_bf16x6(None, 0, 0, None, 0, 0, None, None, None, 0, 0, 0, None, 0, None, 0, 0, 1, 4, 32,
                                     None) == 1
@@ -218,9 +239,10 @@ def test_conv_nhwc(Cin, Cout, k, stride, pad, H, W):
     Rd = R.permute(0, 2, 3, 1).contiguous().to(DEV)
     y = ops.conv2d_nhwc(xd, wd, scale=sc.to(DEV), shift=sh.to(DEV), R=Rd, relu=True, stride=stride, pad=pad)
     _close(y.permute(0, 3, 1, 2), ref, 3e-5, 1e-5, "conv")
-    sw = ops.split_weight(wd.reshape(Cout, -1), conv_shape=tuple(wd.shape))
-    y6 = ops.conv2d_nhwc(xd, sw, scale=sc.to(DEV), shift=sh.to(DEV), R=Rd, relu=True, stride=stride, pad=pad)
-    _close(y6.permute(0, 3, 1, 2), ref, 3e-5, 1e-5, "conv bf16x6")
+    for kind in ("f16x3", "bf16x6"):
+        sw = ops.split_weight(wd.reshape(Cout, -1), conv_shape=tuple(wd.shape), kind=kind)
+        y6 = ops.conv2d_nhwc(xd, sw, scale=sc.to(DEV), shift=sh.to(DEV), R=Rd, relu=True, stride=stride, pad=pad)
+        _close(y6.permute(0, 3, 1, 2), ref, 3e-5, 1e-5, "conv " + kind)
 
 
 def test_stem_preprocess_pool():

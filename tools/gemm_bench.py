@@ -46,7 +46,7 @@ def timeit(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--mode", default="bf16x6", choices=["bf16x6", "fp32"])
+    ap.add_argument("--mode", default="f16x3", choices=["f16x3", "bf16x6", "fp32"])
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     a = ap.parse_args()
     ops.GEMM_MODE = a.mode
