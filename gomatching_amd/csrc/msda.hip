@@ -141,35 +141,53 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < LP; ++i) { e[i] = expf(e[i] - mx); sum += e[i]; }
 
+    // The loop below is VALU-bound (47 vector instructions per corner load before this form), so:
+    //   * off / W and off / H (ms_deform_attn.py:141-147) are divisions by per-level constants: q = x * (1/W) followed by
+    //     one residual correction, r = fma(-q, W, x), q += r * (1/W) -- correctly rounded save for rare double-rounding
+    //     cases, 3 instructions instead of the ~10 of a full IEEE division;
+    //   * the softmax denominator is inverted once (e * (1/sum) differs from e / sum by at most one ulp);
+    //   * out-of-range corners are not branched around: the corner index is clamped into the map and its weight zeroed
+    //     (0 * finite = 0), which is what the reference's zero padding computes;
+    //   * corner offsets are 32-bit element offsets from the level's base (a level holds < 2^31 floats).
+    const float inv_sum = 1.f / sum;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int l = 0; l < LEVELS; ++l) {
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
         const float Hf = (float)H, Wf = (float)W;
+        const float rW = 1.f / Wf, rH = 1.f / Hf;
         const float* vl = vb + (size_t)lsi[l] * v_rs;
 #pragma unroll
         for (int p = 0; p < POINTS; ++p) {
             const int i = l * POINTS + p;
-            const float lx = rx + offv[i >> 1][(i & 1) * 2] / Wf;
-            const float ly = ry + offv[i >> 1][(i & 1) * 2 + 1] / Hf;
-            const float w = e[i] / sum;
+            const float ox = offv[i >> 1][(i & 1) * 2], oy = offv[i >> 1][(i & 1) * 2 + 1];
+            float qx = ox * rW, qy = oy * rH;
+            qx = fmaf(fmaf(-qx, Wf, ox), rW, qx);
+            qy = fmaf(fmaf(-qy, Hf, oy), rH, qy);
+            const float lx = rx + qx, ly = ry + qy;
+            const float w = e[i] * inv_sum;
             const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
-            if (h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf) {
-                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-                const float lh = h_im - h_low, lw = w_im - w_low;
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                const bool y0 = h_low >= 0, y1 = h_low + 1 <= H - 1;
-                const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
-                const float* base = vl + ((long)h_low * W + w_low) * (long)v_rs;
-                f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
-                if (y0 && x0) v1 = *reinterpret_cast<const f32x4*>(base);
-                if (y0 && x1) v2 = *reinterpret_cast<const f32x4*>(base + v_rs);
-                if (y1 && x0) v3 = *reinterpret_cast<const f32x4*>(base + (long)W * v_rs);
-                if (y1 && x1) v4 = *reinterpret_cast<const f32x4*>(base + (long)(W + 1) * v_rs);
-                const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-                const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-                acc += val * w;
-            }
+            const bool inside = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
+            const bool y0 = h_low >= 0, y1 = h_low + 1 <= H - 1;
+            const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
+            const int yc0 = y0 ? h_low : 0, yc1 = y1 ? h_low + 1 : H - 1;
+            const int xc0 = x0 ? w_low : 0, xc1 = x1 ? w_low + 1 : W - 1;
+            const int r0 = yc0 * W, r1 = yc1 * W;
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(vl + (r0 + xc0) * v_rs);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(vl + (r0 + xc1) * v_rs);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(vl + (r1 + xc0) * v_rs);
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(vl + (r1 + xc1) * v_rs);
+            float ww = inside ? w : 0.f;
+            float w1 = (y0 && x0) ? hh * hw : 0.f, w2 = (y0 && x1) ? hh * lw : 0.f;
+            float w3 = (y1 && x0) ? lh * hw : 0.f, w4 = (y1 && x1) ? lh * lw : 0.f;
+            // opaque to the optimiser: otherwise it re-creates a branch around every load whose weight may be zero
+            asm volatile("" : "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(ww));
+            const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+            acc += val * ww;
         }
     }
     *reinterpret_cast<f32x4*>(out + (size_t)q_global * (HEADS * CH) + m * CH + c4) = acc;
