@@ -29,7 +29,7 @@ SRC_HW = (720, 1280)
 # bf16x6 kernel issues 6 bf16 MFMA passes per fp32-equivalent product, so its ceiling in ALGORITHMIC flops is 2500/6.
 PEAKS = {"fp32": ("gemm_f32_kernel<128,128,64,64,0,0>", 157.3, 1),
          "bf16x6": ("gemm_bf16x6_kernel<128,128,0,0>", 2500.0 / 6.0, 6),
-         "f16x3": ("gemm_f16x3_kernel<128,128,0,0>", 2500.0 / 3.0, 3)}
+         "f16x3": ("gemm_f16x3_kernel<128,128,0,0,3>", 2500.0 / 3.0, 3)}
 DTYPES = {"fp32": "f32 (exact fp32 MFMA)",
           "bf16x6": "f32 (bf16x6 split MFMA: 24-bit significand products, fp32 accumulate)",
           "f16x3": "f32 (f16x3 split MFMA: 22-bit significand products, fp32 accumulate; parity tests at fp32 tolerances)"}

@@ -311,7 +311,7 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
                             1 if relu else 0, _p(out), ldc, M, N, K, _stream()), "gom_gemm_f32")
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K))
+        prof.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N + (M * N if R is not None else 0))))
     return out
 
 
