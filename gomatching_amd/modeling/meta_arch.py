@@ -56,6 +56,7 @@ class GoMatching:
         self.frames_per_step = frames_per_step
         self.use_graphs = use_graphs                             # hipGraph replay of the detector (see _detect_graphed)
         self._graphs = {}
+        self.max_graphs = 2
         self.training = False
 
         sd = normalize_state_dict(state_dict)
@@ -169,13 +170,22 @@ class GoMatching:
         first = batched_inputs[0]
         src = first["frame_u8"] if "frame_u8" in first else first["image"]
         key = (B, tuple(src.shape), str(src.dtype), tuple(first.get("resize_hw", ())), bool(first.get("flip_channels")))
-        state = self._graphs.get(key)
+        state = self._graphs.pop(key, None)
+        if state is not None:
+            self._graphs[key] = state                           # most recently used last
         if state is None:
             self._graphs[key] = "warm"                          # this call: eager
+            for k in [k for k, v in self._graphs.items() if v == "warm"][:-8]:
+                del self._graphs[k]
             return None
         if time_cost.get("_sync"):
             return None                                         # per-stage timing needs the eager path
         if state == "warm":
+            # a captured graph pins its whole activation pool (several GB at full size): keep the few most recently used
+            # step shapes only (a video has one resolution; the next video may bring another)
+            captured = [k for k, v in self._graphs.items() if isinstance(v, dict)]
+            for k in captured[:max(0, len(captured) - (self.max_graphs - 1))]:
+                self._graphs[k] = "warm"                        # dropped: re-captured if it comes back
             try:
                 raw, kind = self._raw_input(batched_inputs)
                 torch.cuda.synchronize()

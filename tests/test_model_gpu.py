@@ -290,6 +290,29 @@ def test_full_size_configs_run(builtin, hw, nframes):
         assert bool((s[:-1] >= s[1:]).all())                    # NMS order = descending score
 
 
+def test_detector_graph_replay_equals_eager_and_is_bounded():
+    """hipGraph replay of the detector returns the bits of the eager launches, survives interleaved step shapes, and
+    keeps at most `max_graphs` captured shapes alive."""
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.weights import synth_state_dict
+    cfg = mini_cfg("icdar15", device=DEV)
+    sd = synth_state_dict(cfg, seed=7, cls_bias={"detection_transformer.ctrl_point_class.0.bias": 0.5})
+    g = torch.Generator().manual_seed(4)
+    shapes = [(96, 128), (128, 96), (64, 160)]
+    clips = {hw: [{"image": (torch.rand(3, hw[0], hw[1], generator=g) * 255).to(DEV)} for _ in range(2)] for hw in shapes}
+    eager = GoMatching(cfg, sd, device=DEV, use_graphs=False)
+    ref = {hw: eager.inference(clips[hw], _time_cost()) for hw in shapes}
+    model = GoMatching(cfg, sd, device=DEV, use_graphs=True)
+    for rnd in range(4):                                             # eager, capture, replay, replay -- interleaved
+        for hw in shapes:
+            got = model.inference(clips[hw], _time_cost())
+            for a, b in zip(got, ref[hw]):
+                assert torch.equal(a.scores, b.scores) and torch.equal(a.bd, b.bd) and torch.equal(a.recs, b.recs)
+                assert torch.equal(a.reid_features, b.reid_features)
+    assert model.use_graphs                                          # capture did not fall back
+    assert sum(isinstance(v, dict) for v in model._graphs.values()) <= model.max_graphs
+
+
 def test_mixed_resolution_clip():
     """Frames of different sizes in one batch_inference call are split into per-size steps (config #5)."""
     from gomatching_amd.modeling import GoMatching
