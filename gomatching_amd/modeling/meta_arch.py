@@ -413,8 +413,8 @@ class GoMatching:
         col_of = np.searchsorted(uniq, ids)
         # "last box of a track": arg-max over onehot*arange, first index on ties (gom_lstmatcher.py:436-438)
         last = np.zeros((M,), np.int64)
-        for j in range(Np):
-            last[col_of[j]] = j if j > 0 else last[col_of[j]]
+        if Np > 1:
+            np.maximum.at(last, col_of[1:], np.arange(1, Np))   # index 0 never overrides the initial 0 (first on ties)
         meta = np.concatenate([nonk, col_of, last, k_inds]).astype(np.int32)
         offs = np.concatenate([[0], np.cumsum(n_t)]).astype(np.int32)
         dec = None
@@ -497,12 +497,12 @@ class GoMatching:
 
     def run_long_term_match(self, full_instances, k, id_count, cur_id):
         """gom_lstmatcher.py:467-564."""
-        cur = set(int(c) for c in np.asarray(cur_id).reshape(-1))
+        cur = np.asarray(cur_id).reshape(-1)
         sels = []
         for idx, p in enumerate(full_instances):
             ids = self._host(p)["ids"]
             if idx != len(full_instances) - 1:
-                sels.append(np.array([int(t) not in cur for t in ids], dtype=bool))
+                sels.append(~np.isin(ids, cur))
             else:
                 sels.append(ids == -1)
         traj, uniq = self._match(full_instances, sels, k, False, full_instances[k].image_size)
@@ -636,11 +636,11 @@ class GoMatching:
         cat + one index_select per field, the per-frame results being views of the selected rows."""
         ids = np.concatenate([self._host(x)["ids"] for x in instances]) if instances else np.zeros((0,), np.int64)
         uniq, counts = np.unique(ids, return_counts=True)
-        short = set(int(u) for u, c in zip(uniq, counts) if c < self.min_track_len)
+        short_arr = uniq[counts < self.min_track_len]
         todo, keeps, gidx, off = [], [], [], 0
         for k in range(len(instances)):
             hid = self._host(instances[k])["ids"]
-            keep = np.array([int(t) not in short for t in hid], dtype=bool)
+            keep = ~np.isin(hid, short_arr)
             if keep.all():                                       # nothing to drop in this frame
                 continue
             todo.append(k)

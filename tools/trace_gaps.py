@@ -47,8 +47,30 @@ def window(path, queue, start_frac=0.8, count=70):
         print("%9.1f  dur %7.1f  gap %7.1f  %s" % ((s - base) / 1e3, (e - s) / 1e3, (s - rows[i - 1][1]) / 1e3, n))
 
 
+def gaps_by_kernel(path, queue, top=14):
+    """Per kernel name: how long the queue sat idle before its launches started (dispatch wait + host cadence)."""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Queue_Id") == queue:
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60]))
+    rows.sort()
+    agg = collections.defaultdict(list)
+    for i in range(1, len(rows)):
+        g = rows[i][0] - rows[i - 1][1]
+        if g < 2000000:
+            agg[rows[i][2]].append(g)
+    for n, gs in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:top]:
+        gs.sort()
+        print("%-60s x%-5d gap before: mean %7.1f us  median %6.1f  p90 %7.1f  max %8.1f  total %7.2f ms"
+              % (n, len(gs), sum(gs) / len(gs) / 1e3, gs[len(gs) // 2] / 1e3, gs[int(len(gs) * 0.9)] / 1e3, gs[-1] / 1e3,
+                 sum(gs) / 1e6))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 3 and sys.argv[3] == "gaps":
+        gaps_by_kernel(sys.argv[1], sys.argv[2])
+    elif len(sys.argv) > 2:
         window(sys.argv[1], sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.8)
     else:
         main(sys.argv[1])
