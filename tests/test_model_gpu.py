@@ -138,6 +138,69 @@ def test_tracker_trace_golden(builtin, tag, matcher_runtime):
         assert kept[f].track_ids.cpu().tolist() == g["kept_ids_%d" % f].tolist(), f
 
 
+def _synthetic_trace(frames, dim, seed):
+    """Moving objects with births, drop-outs and re-appearances: per frame (reid [n, dim], boxes [n, 4])."""
+    g = np.random.default_rng(seed)
+    objs = [{"f": g.standard_normal(dim).astype(np.float32), "xy": g.uniform(10, 90, 2), "v": g.uniform(-0.4, 0.4, 2),
+             "on": True} for _ in range(5)]
+    out = []
+    for t in range(frames):
+        if g.random() < 0.06 and len(objs) < 9:
+            objs.append({"f": g.standard_normal(dim).astype(np.float32), "xy": g.uniform(10, 90, 2),
+                         "v": g.uniform(-0.4, 0.4, 2), "on": True})
+        feats, boxes = [], []
+        for o in objs:
+            o["xy"] = np.clip(o["xy"] + o["v"], 2, 100)
+            if g.random() < 0.08:
+                o["on"] = not o["on"]                                # drop-out / re-appearance
+            if o["on"] and not (t % 37 == 20):                      # and a few entirely empty frames
+                feats.append(o["f"] + 0.15 * g.standard_normal(dim).astype(np.float32))
+                boxes.append([o["xy"][0], o["xy"][1], o["xy"][0] + 14, o["xy"][1] + 8])
+        out.append((np.asarray(feats, np.float32).reshape(-1, dim), np.asarray(boxes, np.float32).reshape(-1, 4)))
+    return out
+
+
+@pytest.mark.parametrize("builtin", ["icdar15", "pp_dstext"])
+def test_tracker_across_100_frame_batches_vs_oracle(builtin, matcher_runtime):
+    """eval.py feeds a video in 100-frame batches and carries (instances, id_count) (eval.py:326-344,
+    gom_lstmatcher.py:366-403 with start_frame_id = batch_id * 100): ids of a 106-frame trace processed as 100 + 6
+    frames equal the oracle's, before and after short-track removal -- the window, the embedding pool and the id
+    counter all survive the batch boundary."""
+    from oracle import gom_oracle as O
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.structures import Instances, Boxes
+    from gomatching_amd.weights import synth_state_dict
+    cfg = mini_cfg(builtin, device=DEV)
+    sd = synth_state_dict(cfg, seed=7)
+    model = GoMatching(cfg, sd, device=DEV)
+    size = (96, 128)
+    trace = _synthetic_trace(106, model.roi_heads.feature_dim, seed=5)
+    ocfg = mini_cfg(builtin)
+    o_insts = [O.Inst(size, reid_features=torch.from_numpy(f).clone(), pred_boxes=torch.from_numpy(b).clone())
+               for f, b in trace]
+    with torch.no_grad():
+        o_res, o_count = O.track_clip(sd, ocfg, o_insts[:100], batch_id=0)
+        o_res, o_count = O.track_clip(sd, ocfg, o_insts[100:], batch_id=1, id_count=o_count, instances=o_res)
+    dets = []
+    for f, b in trace:
+        inst = Instances(size)
+        inst.reid_features = torch.from_numpy(f).to(DEV)
+        inst.pred_boxes = Boxes(torch.from_numpy(b).to(DEV))
+        dets.append(inst)
+    it = iter(dets)
+    model.detect_launch = lambda batched_inputs, time_cost: list(batched_inputs)
+    model.detect_finish = lambda h, time_cost: [next(it) for _ in h]
+    insts, id_count = model.batch_inference([{} for _ in range(100)], 0, 0, [], _time_cost())
+    insts, id_count = model.batch_inference([{} for _ in range(6)], 1, id_count, insts, _time_cost())
+    assert len(insts) == 106 and int(id_count) == int(o_count)
+    for f in range(106):
+        assert insts[f].track_ids.cpu().tolist() == o_res[f]["track_ids"].tolist(), f
+    kept, o_kept = model._remove_short_track(insts), O.remove_short_track(ocfg, o_res)
+    for f in range(106):
+        assert kept[f].track_ids.cpu().tolist() == o_kept[f]["track_ids"].tolist(), f
+    assert max(max(x.track_ids.cpu().tolist(), default=0) for x in kept) > 5       # births happened
+
+
 @pytest.mark.parametrize("builtin", ["icdar15", "pp_dstext"])
 @pytest.mark.parametrize("n_t,k", [([7, 0, 12, 5], 3), ([60, 70, 90], 2), ([1, 1], 1), ([3, 140], 1)])
 def test_native_match_runtime_equals_python_composition(builtin, n_t, k):
