@@ -392,35 +392,51 @@ class GoMatching:
         lo = self._pool.data_ptr()
         return lo <= f.data_ptr() < lo + self._pool.numel() * 4
 
+    def _rows_full(self, inst):
+        """Pool rows of every detection of a frame (homes foreign features first); cached on the host mirror."""
+        g = self._host(inst)
+        if g["row0"] is None or not self._in_pool(inst) or g.get("rows") is None or g["rows_row0"] != g["row0"]:
+            self._reid_rows(inst, np.ones((len(inst),), bool))
+            g["rows"], g["rows_row0"] = g["row0"] + np.arange(len(inst), dtype=np.int64), g["row0"]
+        return g["rows"]
+
     def _match(self, window, sels, k, short_term, hw):
-        """Shared arithmetic of run_short_term_match / run_long_term_match: returns (traj [n_k,M] numpy,
-        unique ids [M], ids of the non-k detections)."""
-        n_t = [int(s.sum()) for s in sels]
-        N, T = sum(n_t), len(n_t)
-        n_k = n_t[k]
-        ids = np.concatenate([self._host(w)["ids"][s] for t, (w, s) in enumerate(zip(window, sels)) if t != k]) \
-            if T > 1 else np.zeros((0,), np.int64)
+        """Shared arithmetic of run_short_term_match / run_long_term_match: returns (traj [n_k,M] numpy, unique ids
+        [M], ids of the non-k selected detections).  `sels`: per-frame boolean masks, or their concatenation.  The
+        bookkeeping runs on the window's concatenated host arrays (a handful of numpy calls whatever the window length)."""
+        T = len(window)
+        hosts = [self._host(w) for w in window]
+        lens = [len(w) for w in window]
+        sel_all = np.concatenate(sels) if isinstance(sels, (list, tuple)) else sels
+        sel_idx = np.nonzero(sel_all)[0]
+        f_sel = np.repeat(np.arange(T), lens)[sel_idx]           # frame of every selected detection (frame-major order)
+        n_arr = np.bincount(f_sel, minlength=T)
+        n_t = [int(v) for v in n_arr]
+        N, n_k = len(sel_idx), n_t[k]
+        not_k = f_sel != k
+        ids_sel = np.concatenate([h["ids"] if h["ids"] is not None else np.full((n,), -1, np.int64)   # frame k may be
+                                  for h, n in zip(hosts, lens)])[sel_idx] if N else np.zeros((0,), np.int64)  # unlabelled yet
+        ids = ids_sel[not_k]
         Np = N - n_k
         uniq = np.unique(ids)
         M = len(uniq)
         if n_k == 0 or M == 0:
-            return np.zeros((n_k, M), np.float32), uniq
-        rows = np.concatenate([self._reid_rows(w, s) for w, s in zip(window, sels)]).astype(np.int32)
-        boxes = np.concatenate([self._host(w)["boxes"][s] for w, s in zip(window, sels)]).astype(np.float32)
-        lo = sum(n_t[:k])
-        k_inds = np.arange(lo, lo + n_k)
-        nonk = np.concatenate([np.arange(0, lo), np.arange(lo + n_k, N)])
+            return np.zeros((n_k, M), np.float32), uniq, ids
+        rows = np.concatenate([self._rows_full(w) for w in window])[sel_idx].astype(np.int32)
+        boxes = np.concatenate([h["boxes"] for h in hosts])[sel_idx].astype(np.float32)
+        nonk = np.nonzero(not_k)[0]
+        k_inds = np.nonzero(~not_k)[0]
         col_of = np.searchsorted(uniq, ids)
         # "last box of a track": arg-max over onehot*arange, first index on ties (gom_lstmatcher.py:436-438)
         last = np.zeros((M,), np.int64)
         if Np > 1:
             np.maximum.at(last, col_of[1:], np.arange(1, Np))   # index 0 never overrides the initial 0 (first on ties)
         meta = np.concatenate([nonk, col_of, last, k_inds]).astype(np.int32)
-        offs = np.concatenate([[0], np.cumsum(n_t)]).astype(np.int32)
+        offs = np.zeros((T + 1,), np.int32)
+        np.cumsum(n_arr, out=offs[1:])
         dec = None
         if (not short_term) and self.decay_time > 0:
-            dts = np.concatenate([np.full((n,), T - t - 2, np.float32) for t, n in enumerate(n_t) if t != k])
-            dec = np.power(np.float32(self.decay_time), dts).astype(np.float32)
+            dec = np.power(np.float32(self.decay_time), (T - 2 - f_sel[not_k]).astype(np.float32)).astype(np.float32)
         # one packed host->device copy per match: rows | frame offsets | meta | boxes (f32 bits) | decay (f32 bits)
         parts = [rows, offs, meta, boxes.reshape(-1).view(np.int32)] + ([dec.view(np.int32)] if dec is not None else [])
         buf = self._h2d(np.concatenate(parts))
@@ -429,7 +445,7 @@ class GoMatching:
                                            buf[o3:].view(torch.float32) if dec is not None else None, n_t, k,
                                            short_term, hw, M, self.with_iou,
                                            self.max_center_dist if not short_term else 0.0)
-        return traj.cpu().numpy(), uniq
+        return traj.cpu().numpy(), uniq, ids
 
     def _assign(self, traj, uniq, ids_nonk, n_k):
         """LSA on -traj + thresholding (gom_lstmatcher.py:447-453 / 549-555)."""
@@ -483,7 +499,7 @@ class GoMatching:
                 traj = S[:, order]
         else:
             sels = [np.ones((len(prev),), bool), np.ones((len(cur),), bool)]
-            traj, uniq = self._match(instances, sels, 1, True, cur.image_size)
+            traj, uniq, _ = self._match(instances, sels, 1, True, cur.image_size)
         track_ids = self._assign(traj, uniq, self._host(prev)["ids"], len(cur))
         if id_count:
             for i in range(len(cur)):
@@ -496,26 +512,26 @@ class GoMatching:
         return instances, np.unique(track_ids)
 
     def run_long_term_match(self, full_instances, k, id_count, cur_id):
-        """gom_lstmatcher.py:467-564."""
+        """gom_lstmatcher.py:467-564: past frames contribute the detections of tracks that are NOT among the current
+        frame's matched ids, the current frame its unmatched (-1) detections."""
         cur = np.asarray(cur_id).reshape(-1)
-        sels = []
-        for idx, p in enumerate(full_instances):
-            ids = self._host(p)["ids"]
-            if idx != len(full_instances) - 1:
-                sels.append(~np.isin(ids, cur))
-            else:
-                sels.append(ids == -1)
-        traj, uniq = self._match(full_instances, sels, k, False, full_instances[k].image_size)
-        ids_nonk = np.concatenate([self._host(p)["ids"][s] for t, (p, s) in enumerate(zip(full_instances, sels))
-                                   if t != k]) if len(full_instances) > 1 else np.zeros((0,), np.int64)
-        n_k = int(sels[k].sum())
+        hosts = [self._host(p) for p in full_instances]
+        ids_all = np.concatenate([h["ids"] for h in hosts])
+        n_last = len(hosts[-1]["ids"])
+        sel_all = ~np.isin(ids_all, cur)
+        if n_last:
+            sel_all[-n_last:] = hosts[-1]["ids"] == -1
+        traj, uniq, ids_nonk = self._match(full_instances, sel_all, k, False, full_instances[k].image_size)
+        off_k = sum(len(h["ids"]) for h in hosts[:k])
+        sel_k = sel_all[off_k:off_k + len(hosts[k]["ids"])]
+        n_k = int(sel_k.sum())
         track_ids = self._assign(traj, uniq, ids_nonk, n_k)
         for i in range(n_k):
             if track_ids[i] < 0:
                 id_count = id_count + 1
                 track_ids[i] = id_count
-        full = self._host(full_instances[k])["ids"].copy()
-        full[sels[k]] = track_ids
+        full = hosts[k]["ids"].copy()
+        full[sel_k] = track_ids
         self._set_ids(full_instances[k], full)
         return full_instances, id_count
 
