@@ -96,3 +96,42 @@ def test_predictor_device_ingest_equals_host_path():
         assert x.image_size == y.image_size
         assert torch.equal(x.track_ids, y.track_ids) and torch.equal(x.recs, y.recs)
         assert torch.equal(x.scores, y.scores) and torch.equal(x.bd, y.bd)
+
+
+def test_video_to_result_files(tmp_path):
+    """The harness end to end on the GPU: uint8 BGR frames -> device ingest -> batch predictor (100-frame chunking) ->
+    result writers; the XML / JSON / TXT files carry exactly the tracks the model returned."""
+    import json
+    import xml.etree.ElementTree as ET
+    from gomatching_amd import results
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.predictor import GoMBatchPredictor, TextDecoder, new_time_cost
+    from gomatching_amd.synth import make_clip
+    from gomatching_amd.weights import synth_state_dict
+    cfg = mini_cfg("icdar15", device=DEV)
+    cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 128, 256
+    sd = synth_state_dict(cfg, seed=7, cls_bias={"detection_transformer.ctrl_point_class.0.bias": 0.5})
+    model = GoMatching(cfg, sd, device=DEV, frames_per_step=4)
+    spotter = GoMBatchPredictor(cfg, model, device_ingest=True)
+    frames = [np.ascontiguousarray(f[:, :, ::-1]) for f in make_clip(7, 72, 128, clip_id=3)]
+    tc = new_time_cost()
+    preds, seconds = results.spot_video(spotter, frames, tc)
+    assert len(preds) == 7 and seconds > 0 and tc["total_time"] == seconds
+    dec = TextDecoder(cfg.MODEL.TRANSFORMER.VOC_SIZE)
+    ann = results.write_video(preds, "Video_5_1_2", "ICDAR15", str(tmp_path), dec)
+    results.write_track_transcriptions(str(tmp_path / "preds"))
+    root = ET.parse(str(tmp_path / "preds" / "res_video_5.xml")).getroot()
+    js = json.loads((tmp_path / "jsons" / "Video_5_1_2.json").read_text(encoding="utf-8"))
+    assert [fr.attrib["ID"] for fr in root] == [str(i + 1) for i in range(7)] == list(js)
+    n_rows = 0
+    for i, fr in enumerate(root):
+        rows = ann[str(i + 1)]
+        kept_ids = set(int(t) for t in preds[i]["instances"].track_ids.cpu().tolist())
+        assert [int(o.attrib["ID"]) for o in fr] == [r[8] for r in rows] == [o["ID"] for o in js[str(i + 1)]]
+        assert set(r[8] for r in rows) <= kept_ids                      # writers may only drop (tiny boxes), never add
+        for o, r in zip(fr, rows):
+            assert [(int(p.attrib["x"]), int(p.attrib["y"])) for p in o] == list(zip(r[0:8:2], r[1:8:2]))
+        n_rows += len(rows)
+    assert n_rows > 0
+    txt = (tmp_path / "preds" / "res_video_5.txt").read_text().splitlines()
+    assert sorted(int(l.split(",")[0].strip('"')) for l in txt) == sorted(set(r[8] for rows in ann.values() for r in rows))
