@@ -40,6 +40,44 @@ def _resnet_keys(prefix="backbone.0.backbone."):
     return keys
 
 
+SWIN_TINY = {"embed": 96, "depths": (2, 2, 6, 2), "heads": (3, 6, 12, 24), "window": 7}
+
+
+def _swin_keys(prefix="backbone.0.backbone."):
+    """Swin-T, out_features stage3..5, patch_norm (swin_transformer.py:692-724)."""
+    S = SWIN_TINY
+    keys = {prefix + "patch_embed.proj.weight": (S["embed"], 3, 4, 4), prefix + "patch_embed.proj.bias": (S["embed"],)}
+    _ln(keys, prefix + "patch_embed.norm", S["embed"])
+    for i, (depth, heads) in enumerate(zip(S["depths"], S["heads"])):
+        C = S["embed"] * 2 ** i
+        for b in range(depth):
+            p = prefix + "layers.%d.blocks.%d." % (i, b)
+            _ln(keys, p + "norm1", C)
+            keys[p + "attn.relative_position_bias_table"] = ((2 * S["window"] - 1) ** 2, heads)
+            _lin(keys, p + "attn.qkv", 3 * C, C)
+            _lin(keys, p + "attn.proj", C, C)
+            _ln(keys, p + "norm2", C)
+            _lin(keys, p + "mlp.fc1", 4 * C, C)
+            _lin(keys, p + "mlp.fc2", C, 4 * C)
+        if i < len(S["depths"]) - 1:
+            p = prefix + "layers.%d.downsample." % i
+            keys[p + "reduction.weight"] = (2 * C, 4 * C)
+            _ln(keys, p + "norm", 4 * C)
+        if i >= 1:
+            _ln(keys, prefix + "norm%d" % i, C)
+    return keys
+
+
+def backbone_channels(cfg):
+    """Channel table of detection_transformer_wobackbone.py:59-70."""
+    name = cfg.MODEL.BACKBONE.NAME
+    if name == "build_swin_backbone":
+        return [192, 384, 768]
+    if name == "build_resnet_backbone":
+        return [512, 1024, 2048]
+    raise NotImplementedError("backbone %s is not built (SURVEY.md §8-f3)" % name)
+
+
 def _lin(keys, name, cout, cin):
     keys[name + ".weight"] = (cout, cin)
     keys[name + ".bias"] = (cout,)
@@ -74,12 +112,12 @@ def _deepsolo_keys(cfg, prefix="detection_transformer."):
     d, heads, L = T.HIDDEN_DIM, T.NHEADS, T.NUM_FEATURE_LEVELS
     ffn = T.DIM_FEEDFORWARD
     keys = {}
-    chans = [512, 1024, 2048]
+    chans = backbone_channels(cfg)
     for l in range(3):
         keys[prefix + "input_proj.%d.0.weight" % l] = (d, chans[l], 1, 1)
         keys[prefix + "input_proj.%d.0.bias" % l] = (d,)
         _ln(keys, prefix + "input_proj.%d.1" % l, d)
-    keys[prefix + "input_proj.3.0.weight"] = (d, 2048, 3, 3)
+    keys[prefix + "input_proj.3.0.weight"] = (d, chans[-1], 3, 3)
     keys[prefix + "input_proj.3.0.bias"] = (d,)
     _ln(keys, prefix + "input_proj.3.1", d)
     keys[prefix + "point_embed.weight"] = (T.NUM_QUERIES * T.NUM_POINTS, d)
@@ -158,7 +196,7 @@ def _roi_head_keys(cfg, prefix="roi_heads."):
 
 def canonical_keys(cfg):
     keys = {}
-    keys.update(_resnet_keys())
+    keys.update(_swin_keys() if cfg.MODEL.BACKBONE.NAME == "build_swin_backbone" else _resnet_keys())
     keys.update(_deepsolo_keys(cfg))
     keys.update(_roi_head_keys(cfg))
     return keys
