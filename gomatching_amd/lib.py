@@ -69,6 +69,13 @@ SIGNATURES = {
     "gom_track_score_f32": (I, [P, I, P, P, P, F, F, I, I, I, I, F, P, P]),
     "gom_short_term_pairs_f32": (I, [P, P, I, P, P, P, F, F, I, I, I, P, P]),
     "gom_mha_core_segments_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "gom_layernorm_any_f32": (I, [P, P, P, P, L, I, F, P]),
+    "gom_gelu_f32": (I, [P, L, P]),
+    "gom_swin_patchify_f32": (I, [P, P, I, I, I, P]),
+    "gom_swin_window_gather_f32": (I, [P, P, I, I, I, I, I, P]),
+    "gom_swin_window_scatter_add_f32": (I, [P, P, P, I, I, I, I, I, P]),
+    "gom_swin_patch_merge_f32": (I, [P, P, I, I, I, I, P]),
+    "gom_swin_window_attention_f32": (I, [P, P, P, P, L, I, I, I, P]),
     "gom_match_workspace_floats": (L, [I, I, I, I]),
     "gom_match_scores_f32": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
     "gom_linear_sum_assignment": (I, [ctypes.POINTER(ctypes.c_double), L, L, ctypes.POINTER(c_long),

@@ -615,6 +615,68 @@ def detect_post(cls, recls, ctrl, bd, recs, B, nq, P, img_h, img_w, det_thr, nms
     return out
 
 
+# ------------------------------------------------------------------------------------------ Swin glue
+def layernorm_any(x, gamma, beta, eps=1e-5):
+    _chk_f32(x, gamma, beta)
+    D = x.shape[-1]
+    out = torch.empty_like(x)
+    check(_L().gom_layernorm_any_f32(_p(x), _p(gamma), _p(beta), _p(out), x.numel() // D, D, eps, _stream()),
+          "gom_layernorm_any_f32")
+    return out
+
+
+def gelu_(x):
+    _chk_f32(x)
+    check(_L().gom_gelu_f32(_p(x), x.numel(), _stream()), "gom_gelu_f32")
+    return x
+
+
+def swin_patchify(img):
+    """[B,H,W,4] -> ([B*Hp*Wp, 64], Hp, Wp)."""
+    _chk_f32(img)
+    B, H, W, _ = img.shape
+    Hp, Wp = (H + 3) // 4, (W + 3) // 4
+    out = torch.empty((B * Hp * Wp, 64), dtype=_f32, device=img.device)
+    check(_L().gom_swin_patchify_f32(_p(img), _p(out), B, H, W, _stream()), "gom_swin_patchify_f32")
+    return out, Hp, Wp
+
+
+def swin_window_gather(x, B, H, W, shift):
+    _chk_f32(x)
+    C = x.shape[-1]
+    Hp, Wp = (H + 6) // 7 * 7, (W + 6) // 7 * 7
+    out = torch.empty((B * Hp * Wp, C), dtype=_f32, device=x.device)
+    check(_L().gom_swin_window_gather_f32(_p(x), _p(out), B, H, W, C, shift, _stream()), "gom_swin_window_gather_f32")
+    return out
+
+
+def swin_window_scatter_add(windows, shortcut, B, H, W, shift):
+    _chk_f32(windows, shortcut)
+    C = shortcut.shape[-1]
+    out = torch.empty_like(shortcut)
+    check(_L().gom_swin_window_scatter_add_f32(_p(windows), _p(shortcut), _p(out), B, H, W, C, shift, _stream()),
+          "gom_swin_window_scatter_add_f32")
+    return out
+
+
+def swin_patch_merge(x, B, H, W):
+    _chk_f32(x)
+    C = x.shape[-1]
+    H2, W2 = (H + 1) // 2, (W + 1) // 2
+    out = torch.empty((B * H2 * W2, 4 * C), dtype=_f32, device=x.device)
+    check(_L().gom_swin_patch_merge_f32(_p(x), _p(out), B, H, W, C, _stream()), "gom_swin_patch_merge_f32")
+    return out, H2, W2
+
+
+def swin_window_attention(qkv, bias, mask, windows_per_image, heads):
+    _chk_f32(qkv, bias, mask)
+    C = qkv.shape[1] // 3
+    out = torch.empty((qkv.shape[0], C), dtype=_f32, device=qkv.device)
+    check(_L().gom_swin_window_attention_f32(_p(qkv), _p(out), _p(bias), _p(mask), qkv.shape[0] // 49, windows_per_image,
+                                             heads, C, _stream()), "gom_swin_window_attention_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ tracker
 def gather_rows(src, rows):
     n, D = rows.numel(), src.shape[1]

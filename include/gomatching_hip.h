@@ -226,6 +226,25 @@ int gom_detect_post(const float* cls_logits, int ld_cls, const float* rescoring_
                     int* count, int* keep_idx, float* scores, float* boxes, float* ctrl_out, float* bd_out,
                     long long* recs_out, void* stream);
 
+/* ---- f3: Swin-T backbone glue (third_party/adet/modeling/swin/swin_transformer.py) ---------------------------------
+ * The linear layers use the GEMM entry points above.  Tokens are [B,H,W,C] channels-last.  Window rows are ordered
+ * (image, window row, window column, token 0..48), windows of 7x7 over the map zero-padded to multiples of 7. */
+int gom_layernorm_any_f32(const float* x, const float* gamma, const float* beta, float* out, long rows, int dim, float eps,
+                          void* stream);                                                /* dim % 4 == 0, <= 2048 */
+int gom_gelu_f32(float* x, long n, void* stream);                                         /* in place, exact erf form */
+/* PatchEmbed input (:473-479): image [B,H,W,4] -> rows [B*ceil(H/4)*ceil(W/4), 64] in (kh, kw, c) order, zero padded. */
+int gom_swin_patchify_f32(const float* img, float* out, int B, int H, int W, void* stream);
+/* pad + cyclic shift (-shift) + window_partition (:246-262) and its inverse fused with the residual add (:264-279). */
+int gom_swin_window_gather_f32(const float* x, float* out, int B, int H, int W, int C, int shift, void* stream);
+int gom_swin_window_scatter_add_f32(const float* windows, const float* shortcut, float* out, int B, int H, int W, int C,
+                                    int shift, void* stream);
+/* PatchMerging gather (:320-327): [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),4C]. */
+int gom_swin_patch_merge_f32(const float* x, float* out, int B, int H, int W, int C, void* stream);
+/* WindowAttention core (:139-165): qkv [num_windows*49, 3C] -> out [num_windows*49, C]; bias [heads,49,49]; mask
+ * [windows_per_image,49,49] (0 / -100) or NULL; head_dim 32. */
+int gom_swin_window_attention_f32(const float* qkv, float* out, const float* bias, const float* mask, long num_windows,
+                                  int windows_per_image, int heads, int C, void* stream);
+
 /* ---- A14/A15: tracker ---------------------------------------------------------------------------------*/
 int gom_gather_rows_f32(const float* src, const int* rows, float* out, int n, int dim, void* stream);
 /* per-frame softmax with an appended zero logit (lstmatcher.py:373-381); frame_offsets [num_frames+1] int32. */

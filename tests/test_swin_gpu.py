@@ -1,0 +1,97 @@
+"""Swin-T backbone on the GPU against the outputs of the reference's own SwinTransformer module
+(tests/golden/swin_tiny.npz): every stage output within fp32 accumulation noise, for sizes that need the internal window /
+patch padding too, under all three contraction back-ends; plus the glue kernels one by one against torch."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden
+from gomatching_amd.config import setup_cfg
+from gomatching_amd.weights import synth_state_dict
+from oracle import swin_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(params=["f16x3", "bf16x6", "fp32"])
+def gemm_mode(request):
+    from gomatching_amd import ops
+    old = ops.GEMM_MODE
+    ops.GEMM_MODE = request.param
+    yield request.param
+    ops.GEMM_MODE = old
+
+
+def _sd():
+    cfg = setup_cfg(builtin="icdar15")
+    cfg.MODEL.BACKBONE.NAME = "build_swin_backbone"
+    return synth_state_dict(cfg, seed=3)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_swin_tiny_matches_reference_module(tag, gemm_mode):
+    from gomatching_amd.modeling.swin import SwinTiny
+    g = golden("swin_tiny.npz")
+    net = SwinTiny(_sd(), torch.device(DEV))
+    x = torch.from_numpy(g["x_" + tag])
+    x4 = torch.cat([x.permute(0, 2, 3, 1), x.new_zeros(x.shape[0], x.shape[2], x.shape[3], 1)], -1).contiguous().to(DEV)
+    out = net.forward(x4)
+    for k in ("stage3", "stage4", "stage5"):
+        ref = torch.from_numpy(g["%s_%s" % (k, tag)])
+        got = out[k].permute(0, 3, 1, 2).cpu()
+        assert tuple(got.shape) == tuple(ref.shape)
+        err = float((got - ref).abs().max())
+        assert err <= 2e-4, (k, tag, err)
+
+
+def test_swin_glue_kernels_vs_torch():
+    from gomatching_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for D in (96, 192, 384, 768, 1536):
+        x = torch.randn(37, D, generator=g) * 3 + 0.7
+        gm, bt = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+        out = ops.layernorm_any(x.to(DEV), gm.to(DEV), bt.to(DEV)).cpu()
+        assert float((out - F.layer_norm(x, (D,), gm, bt)).abs().max()) <= 2e-5
+    x = torch.randn(1000, generator=g) * 3
+    assert float((ops.gelu_(x.clone().to(DEV)).cpu() - F.gelu(x)).abs().max()) <= 1e-6
+    B, H, W, C = 2, 12, 17, 96
+    t = torch.randn(B, H, W, C, generator=g)
+    for shift in (0, 3):
+        win = ops.swin_window_gather(t.view(-1, C).to(DEV), B, H, W, shift).cpu()
+        xp = F.pad(t, (0, 0, 0, (7 - W % 7) % 7, 0, (7 - H % 7) % 7))
+        Hp, Wp = xp.shape[1], xp.shape[2]
+        if shift:
+            xp = torch.roll(xp, shifts=(-shift, -shift), dims=(1, 2))
+        ref = xp.view(B, Hp // 7, 7, Wp // 7, 7, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, C)
+        assert torch.equal(win, ref)
+        back = ops.swin_window_scatter_add(win.to(DEV), t.view(-1, C).to(DEV), B, H, W, shift).cpu()
+        assert torch.equal(back.view(B, H, W, C), t + t)            # gather then scatter is the identity on the crop
+    m, H2, W2 = ops.swin_patch_merge(t.view(-1, C).to(DEV), B, H, W)
+    xp = F.pad(t, (0, 0, 0, W % 2, 0, H % 2))
+    ref = torch.cat([xp[:, 0::2, 0::2], xp[:, 1::2, 0::2], xp[:, 0::2, 1::2], xp[:, 1::2, 1::2]], -1)
+    assert (H2, W2) == (6, 9) and torch.equal(m.cpu().view(B, H2, W2, 4 * C), ref)
+    img = torch.randn(B, 10, 13, 4, generator=g)
+    rows, Hp, Wp = ops.swin_patchify(img.to(DEV))
+    ip = F.pad(img, (0, 0, 0, 3, 0, 2))
+    ref = ip.view(B, 3, 4, 4, 4, 4).permute(0, 1, 3, 2, 4, 5).reshape(-1, 64)
+    assert (Hp, Wp) == (3, 4) and torch.equal(rows.cpu(), ref)
+
+
+def test_window_attention_vs_torch():
+    from gomatching_amd import ops
+    g = torch.Generator().manual_seed(1)
+    heads, C, nW, B = 6, 192, 6, 2
+    qkv = torch.randn(B * nW * 49, 3 * C, generator=g)
+    bias = torch.randn(heads, 49, 49, generator=g)
+    mask = swin_oracle.shift_mask(12, 17)
+    for m in (None, mask):
+        out = ops.swin_window_attention(qkv.to(DEV), bias.to(DEV), None if m is None else m.contiguous().to(DEV), nW,
+                                        heads).cpu()
+        t = qkv.view(B * nW, 49, 3, heads, 32).permute(2, 0, 3, 1, 4)
+        a = (t[0] * 32 ** -0.5) @ t[1].transpose(-2, -1) + bias.unsqueeze(0)
+        if m is not None:
+            a = (a.view(B, nW, heads, 49, 49) + m.unsqueeze(1).unsqueeze(0)).view(-1, heads, 49, 49)
+        ref = (a.softmax(-1) @ t[2]).transpose(1, 2).reshape(B * nW * 49, C)
+        assert float((out - ref).abs().max()) <= 2e-5
