@@ -50,7 +50,12 @@ class DeepSolo:
             self.proj.append((ops.prep_weight(g("input_proj.%d.0.weight" % l).reshape(self.d, -1).contiguous()),
                               g("input_proj.%d.0.bias" % l), g("input_proj.%d.1.weight" % l),
                               g("input_proj.%d.1.bias" % l)))
-        self.proj3 = (ops.prep_conv_weight(_dev(sd[prefix + "input_proj.3.0.weight"].permute(0, 2, 3, 1), device)),
+        w3 = sd[prefix + "input_proj.3.0.weight"].float().permute(0, 2, 3, 1)          # OHWI
+        cin = w3.shape[-1]
+        self.proj3_cin = 1 << (cin - 1).bit_length()     # the implicit-GEMM conv wants a power-of-two Cin (Swin: 768 -> 1024)
+        if self.proj3_cin != cin:
+            w3 = torch.cat([w3, w3.new_zeros(w3.shape[:-1] + (self.proj3_cin - cin,))], -1)
+        self.proj3 = (ops.prep_conv_weight(_dev(w3, device)),
                       g("input_proj.3.0.bias"), g("input_proj.3.1.weight"), g("input_proj.3.1.bias"))
         self.point_embed = g("point_embed.weight")                           # [nq*P, 256]
         t = "transformer."
@@ -164,7 +169,12 @@ class DeepSolo:
         """A4 + A5: input_proj (conv + GroupNorm) of the 3 backbone levels + the stride-2 extra level,
         written level by level into the flattened token buffer."""
         shapes = [(f.shape[1], f.shape[2]) for f in feats]
-        x3 = ops.conv2d_nhwc(feats[-1], self.proj3[0], shift=self.proj3[1], stride=2, pad=1)
+        top = feats[-1]
+        if top.shape[3] != self.proj3_cin:               # zero channels up to the padded weight (tiny map: one small copy)
+            padded = torch.zeros(top.shape[:3] + (self.proj3_cin,), dtype=_f32, device=self.device)
+            padded[..., :top.shape[3]] = top
+            top = padded
+        x3 = ops.conv2d_nhwc(top, self.proj3[0], shift=self.proj3[1], stride=2, pad=1)
         shapes.append((x3.shape[1], x3.shape[2]))
         geo = self.geometry(shapes, B)
         S = geo["S"]

@@ -22,6 +22,7 @@ from .. import ops
 from ..structures import Boxes, Instances
 from ..weights import normalize_state_dict
 from .backbone import ResNet50
+from .swin import SwinTiny
 from .deepsolo import DeepSolo
 from .roi_heads import build_roi_heads
 
@@ -35,8 +36,9 @@ class GoMatching:
         if self.device.type != "cuda":
             raise RuntimeError("gomatching_amd runs on an MI355X only (MODEL.DEVICE=%s); there is no CPU path" %
                                cfg.MODEL.DEVICE)
-        if cfg.MODEL.BACKBONE.NAME != "build_resnet_backbone":
-            raise NotImplementedError("only the R-50 backbone of the shipped configs is built (SURVEY.md §8-f3)")
+        if cfg.MODEL.BACKBONE.NAME not in ("build_resnet_backbone", "build_swin_backbone"):
+            raise NotImplementedError("backbone %s is not built (R-50 and Swin-T are; SURVEY.md §8-f3)"
+                                      % cfg.MODEL.BACKBONE.NAME)
         V = cfg.VIDEO_TEST
         self.test_len = cfg.INPUT.VIDEO.TEST_LEN
         self.overlap_thresh = V.OVERLAP_THRESH
@@ -60,7 +62,13 @@ class GoMatching:
         self.training = False
 
         sd = normalize_state_dict(state_dict)
-        self.backbone = ResNet50(sd, self.device)
+        if cfg.MODEL.BACKBONE.NAME == "build_swin_backbone":
+            if cfg.MODEL.SWIN.TYPE != "tiny":
+                raise NotImplementedError("only Swin-T is built (detection_transformer_wobackbone.py:61-64)")
+            self.backbone = SwinTiny(sd, self.device)
+        else:
+            self.backbone = ResNet50(sd, self.device)
+        self.feature_names = self.backbone.out_features
         self.detection_transformer = DeepSolo(cfg, sd, self.device)
         self.roi_heads = build_roi_heads(cfg, sd, self.device)
         self._pool = None
@@ -142,10 +150,16 @@ class GoMatching:
         x = self._normalise(raw, kind)
         sync(); time_cost["pre_process"] += time.time() - t0
         t0 = time.time()
+        div = getattr(self.backbone, "size_divisibility", 0)
+        if div and (hw[0] % div or hw[1] % div):
+            # the reference pads such inputs to the backbone's size_divisibility (swin_transformer.py:678) and carries
+            # padding masks through DeepSolo; that masked path is not built
+            raise NotImplementedError("the %s backbone needs network inputs that are multiples of %d (got %dx%d): padding "
+                                      "masks are not implemented" % (type(self.backbone).__name__, div, hw[0], hw[1]))
         feats = self.backbone.forward(x)
         sync(); time_cost["backbone"] += time.time() - t0
         t0 = time.time()
-        out = self.detection_transformer.forward([feats["res3"], feats["res4"], feats["res5"]])
+        out = self.detection_transformer.forward([feats[k] for k in self.feature_names])
         sync(); time_cost["detector"] += time.time() - t0
         re = None
         if self.with_rescore:

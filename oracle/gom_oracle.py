@@ -699,8 +699,14 @@ def detect_frames(sd, cfg, images, taps=None):
     std = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
     x = torch.stack([(im - mean) / std for im in images])
     sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
-    feats = resnet50(x, sd)
-    feats = [feats[k] for k in ("res3", "res4", "res5")]
+    if cfg.MODEL.BACKBONE.NAME == "build_swin_backbone":
+        from oracle.swin_oracle import swin_tiny
+        assert all(h % 32 == 0 and w % 32 == 0 for h, w in sizes), "Swin needs padded batches + masks otherwise"
+        feats = swin_tiny(x, sd)
+        feats = [feats[k] for k in ("stage3", "stage4", "stage5")]
+    else:
+        feats = resnet50(x, sd)
+        feats = [feats[k] for k in ("res3", "res4", "res5")]
     masks = mask_out_padding([f.shape for f in feats], sizes)
     T = cfg.MODEL.TRANSFORMER
     pos = [pos_encoding_2d(m, T.HIDDEN_DIM // 2, T.TEMPERATURE) for m in masks]

@@ -95,3 +95,41 @@ def test_window_attention_vs_torch():
             a = (a.view(B, nW, heads, 49, 49) + m.unsqueeze(1).unsqueeze(0)).view(-1, heads, 49, 49)
         ref = (a.softmax(-1) @ t[2]).transpose(1, 2).reshape(B * nW * 49, C)
         assert float((out - ref).abs().max()) <= 2e-5
+
+
+def test_swin_end_to_end_clip_vs_oracle(gemm_mode):
+    """The whole path with the Swin-T backbone (build_swin_backbone) on a 6-frame 96x128 clip -- a size that needs no batch
+    padding -- against the CPU oracle: identical ids and characters, points within 1e-3 px."""
+    from helpers import mini_cfg
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.synth import make_clip
+    from oracle import gom_oracle as O
+    cfg = mini_cfg("icdar15", device=DEV)
+    cfg.MODEL.BACKBONE.NAME = "build_swin_backbone"
+    sd = synth_state_dict(cfg, seed=7, cls_bias={"detection_transformer.ctrl_point_class.0.bias": 0.8,
+                                                  "roi_heads.rescoring_head.bias": 0.8})
+    hw = (96, 128)
+    clip = make_clip(6, hw[0], hw[1], clip_id=2)
+    images = [torch.as_tensor(f.astype("float32").transpose(2, 0, 1)) for f in clip]
+    ocfg = mini_cfg("icdar15")
+    ocfg.MODEL.BACKBONE.NAME = "build_swin_backbone"
+    with torch.no_grad():
+        o_res, o_count = O.run_clip(sd, ocfg, images)
+    model = GoMatching(cfg, sd, device=DEV, frames_per_step=3)
+    tc = {k: 0.0 for k in ("pre_process", "backbone", "detector", "rescore", "tracker", "short_match", "long_match",
+                           "post_process", "total_time")}
+    insts, id_count = model.batch_inference([{"image": im, "height": hw[0], "width": hw[1]} for im in images], 0, 0, [], tc)
+    insts = model._remove_short_track(insts)
+    res = model.batch_postprocess(insts, [hw] * len(insts))
+    assert int(id_count) == int(o_count)
+    total = 0
+    for f in range(len(images)):
+        r, o = res[f]["instances"], o_res[f]["instances"]
+        assert r.track_ids.cpu().tolist() == o["track_ids"].tolist(), f
+        assert r.recs.cpu().tolist() == o["recs"].tolist(), f
+        assert float((r.bd.cpu() - o["bd"]).abs().max()) <= 1e-3 if len(r) else True
+        assert float((r.scores.cpu() - o["scores"]).abs().max()) <= 1e-4 if len(r) else True
+        total += len(r)
+    assert total > 0
+    with pytest.raises(NotImplementedError, match="multiples of 32"):
+        model.inference([{"image": torch.rand(3, 90, 130) * 255}], tc)
