@@ -61,7 +61,7 @@ def calibrate(model, inputs, frac=0.3):
     tc = new_time_cost()
     x, hw = model.preprocess_image(inputs[:1])
     feats = model.backbone.forward(x)
-    out = model.detection_transformer.forward([feats["res3"], feats["res4"], feats["res5"]])
+    out = model.detection_transformer.forward([feats[k] for k in model.feature_names])
     thr = model.test_score_threshold
     logit_thr = float(np.log(thr / (1 - thr)))
     T = model.cfg.MODEL.TRANSFORMER
@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backbone", default="r50", choices=["r50", "swin"],
+                    help="r50 = BASELINE.json's workload; swin = side measurement of the Swin-T backbone (§8-f3) on 1024x1792 "
+                         "frames (network inputs must be multiples of 32 for it; not the BASELINE workload)")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="N=1 diagnostic: run the replicated tracker over W copies of this GPU's records per step, i.e. "
                          "the tracker load of a W-GPU run, beside one GPU's detection (value still counts 8 frames/step)")
@@ -144,11 +147,16 @@ def main():
     ops.GEMM_MODE = args.gemm
     cfg = setup_cfg(builtin="icdar15")
     cfg.MODEL.DEVICE = "cuda"
+    src_hw = SRC_HW
+    if args.backbone == "swin":
+        cfg.MODEL.BACKBONE.NAME = "build_swin_backbone"
+        src_hw = (1024, 1792)                                  # already network size: the harness resize is a no-op
+        cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 1024, 2000
     model, sd = build_model(cfg, device)
     predictor = GoMBatchPredictor(cfg, model)
 
     # this rank's block of the clip: frames [rank*8, rank*8+8) of a world*8-frame synthetic video
-    clip = make_clip(FRAMES_PER_GPU * world, SRC_HW[0], SRC_HW[1], clip_id=0, num_rects=12)
+    clip = make_clip(FRAMES_PER_GPU * world, src_hw[0], src_hw[1], clip_id=0, num_rects=12)
     mine = [f[:, :, ::-1] for f in clip[rank * FRAMES_PER_GPU:(rank + 1) * FRAMES_PER_GPU]]   # harness takes BGR
     inputs, hw = predictor.prepare(mine)                       # host resize etc.: outside the timed window
     inputs = [dict(x, image=x["image"].to(device)) for x in inputs]      # resident in HBM before timing starts
@@ -240,9 +248,12 @@ def main():
         "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPES[args.gemm], "data": "synthetic",
-        "config": {"workload": "configs[1]: 1280x720 ICDAR15-video clip -> %dx%d net input, %d frames/GPU, "
-                               "100 queries, GoMatching_ICDAR15 (R-50 + DeepSolo + LSTMatcher, rescoring), "
-                               "random-init synthetic weights" % (net_hw[0], net_hw[1], FRAMES_PER_GPU),
+        "config": {"workload": ("configs[1]: 1280x720 ICDAR15-video clip -> %dx%d net input, %d frames/GPU, "
+                                "100 queries, GoMatching_ICDAR15 (R-50 + DeepSolo + LSTMatcher, rescoring), "
+                                "random-init synthetic weights" % (net_hw[0], net_hw[1], FRAMES_PER_GPU))
+                   if args.backbone == "r50" else
+                   ("NOT the BASELINE workload: Swin-T backbone side measurement, %dx%d net input, %d frames/GPU, 100 "
+                    "queries, DeepSolo + LSTMatcher, random-init synthetic weights" % (net_hw[0], net_hw[1], FRAMES_PER_GPU)),
                    "frames_per_step": FRAMES_PER_GPU * world, "emulated_world": args.emulate_world, "pipelining": "detector(step i+1) overlaps tracker(step i)", "detector_hipgraph": graphed,
                    "parallelism": "frame-sharded dp%d + 1 all-gather/step"
                    % world if world > 1 else "single GPU",
@@ -262,7 +273,7 @@ def main():
                      if graphed else "%d eager steps after the timed region" % PROFILE_STEPS},
         "stage_ms_per_step": {k: v / args.steps * 1e3 for k, v in tc.items() if isinstance(v, float) and v > 0},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.backbone == "r50":
         cpu_cfg = setup_cfg(builtin="icdar15")
         cpu_cfg.MODEL.DEVICE = "cpu"
         gpu0 = model.inference(inputs[:1], new_time_cost())[0]

@@ -8,40 +8,51 @@ namespace {
 
 constexpr int WS = 7, WT = WS * WS;
 
-// ---- LayerNorm over the last dimension, any D <= 2048 with D % 4 == 0 (96 ... 1536): one wave per row, the row in
-// registers, centred variance (two reductions) as nn.LayerNorm.
+// ---- LayerNorm over the last dimension, any D <= 2048 with D % 4 == 0 (96 ... 1536): the row in registers, centred
+// variance (two reductions) as nn.LayerNorm.  One wave per row; for D <= 128 (Swin stage 0: 96 channels over 900k
+// tokens) one HALF-wave per row, so that 24 of 32 lanes work instead of 24 of 64.
+template <int LANES>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int LANES>                                          // lanes per row: 64 or 32
 __global__ __launch_bounds__(256) void layernorm_any_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ out,
                                                             long rows, int D, float eps) {
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int lane = threadIdx.x & 63;
-    const float* xr = x + row * D;
-    f32x4 v[8];
+    constexpr int RPB = 256 / LANES, NV = LANES == 64 ? 8 : 1;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / LANES;
+    const bool live = row < rows;
+    const int lane = threadIdx.x % LANES;
+    const float* xr = x + (live ? row : 0) * D;
+    f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = (lane + 64 * i) * 4;
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + LANES * i) * 4;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < D) {
             v[i] = *reinterpret_cast<const f32x4*>(xr + c);
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
     }
-    const float mean = wave_sum(s) / (float)D;
+    const float mean = group_sum<LANES>(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = (lane + 64 * i) * 4;
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + LANES * i) * 4;
         if (c < D) {
             const f32x4 d = v[i] - mean;
             q += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    const float rstd = rsqrtf(group_sum<LANES>(q) / (float)D + eps);
+    if (!live) return;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = (lane + 64 * i) * 4;
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + LANES * i) * 4;
         if (c < D) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
             *reinterpret_cast<f32x4*>(out + row * D + c) = (v[i] - mean) * rstd * g + b;
@@ -217,8 +228,12 @@ extern "C" int gom_layernorm_any_f32(const float* x, const float* gamma, const f
                                      float eps, void* stream) {
     GOM_CHECK_ARG(x && gamma && beta && out && rows >= 0 && dim > 0 && dim <= 2048 && (dim % 4) == 0);
     if (rows == 0) return GOM_OK;
-    hipLaunchKernelGGL(layernorm_any_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                       out, rows, dim, eps);
+    if (dim <= 128)
+        hipLaunchKernelGGL(layernorm_any_kernel<32>, dim3((unsigned)cdiv(rows, 8)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                           beta, out, rows, dim, eps);
+    else
+        hipLaunchKernelGGL(layernorm_any_kernel<64>, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                           beta, out, rows, dim, eps);
     return gom_launch_status();
 }
 

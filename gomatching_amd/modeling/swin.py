@@ -100,7 +100,7 @@ class SwinTiny:
                 att = ops.swin_window_attention(qkv, blk["bias"], self._mask(Hc, Wc) if blk["shift"] else None, nW, heads)
                 att = ops.gemm(att, blk["proj"][0], bias=blk["proj"][1])
                 t = ops.swin_window_scatter_add(att, t, B, Hc, Wc, blk["shift"])
-                h = ops.gelu_(ops.gemm(ops.layernorm_any(t, *blk["norm2"]), blk["fc1"][0], bias=blk["fc1"][1]))
+                h = ops.gemm_gelu(ops.layernorm_any(t, *blk["norm2"]), blk["fc1"][0], bias=blk["fc1"][1])
                 t = ops.gemm(h, blk["fc2"][0], bias=blk["fc2"][1], R=t)
             if "norm" in st:
                 outs["stage%d" % (i + 2)] = ops.layernorm_any(t, *st["norm"]).view(B, Hc, Wc, C)

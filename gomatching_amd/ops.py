@@ -151,9 +151,11 @@ def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols=None):
     rc = (r_cols if r_cols is not None else N) if R is not None else 0
     if W.kind == "f16x3":
         check(_L().gom_gemm_f32_f16x3(_p(A), _p(rows), lda, _p(pl), pl.stride(0), pl.stride(1), _p(W.inv_scale),
-                                      _p(scale), _p(bias), _p(R), ldr, rc, 1 if relu else 0, _p(out), ldc, M, N, K,
+                                      _p(scale), _p(bias), _p(R), ldr, rc, 2 if relu == "gelu" else (1 if relu else 0),
+                                      _p(out), ldc, M, N, K,
                                       _p(range_flag(A.device)), _stream()), "gom_gemm_f32_f16x3")
     else:
+        assert relu in (False, True, 0, 1), "only the f16x3 kernel has a GELU epilogue (use gemm_gelu)"
         check(_L().gom_gemm_f32_bf16x6(_p(A), _p(rows), lda, _p(pl), pl.stride(0), pl.stride(1), _p(scale),
                                        _p(bias), _p(R), ldr, rc, 1 if relu else 0, _p(out), ldc, M, N, K, _stream()),
               "gom_gemm_f32_bf16x6")
@@ -616,6 +618,13 @@ def detect_post(cls, recls, ctrl, bd, recs, B, nq, P, img_h, img_w, det_thr, nms
 
 
 # ------------------------------------------------------------------------------------------ Swin glue
+def gemm_gelu(A, W, bias=None):
+    """GELU(A @ W^T + bias): fused into the f16x3 epilogue, a separate in-place pass on the other back-ends."""
+    if isinstance(W, SplitWeight) and W.kind == "f16x3":
+        return gemm(A, W, bias=bias, relu="gelu")
+    return gelu_(gemm(A, W, bias=bias))
+
+
 def layernorm_any(x, gamma, beta, eps=1e-5):
     _chk_f32(x, gamma, beta)
     D = x.shape[-1]
