@@ -115,8 +115,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backbone", default="r50", choices=["r50", "swin"],
-                    help="r50 = BASELINE.json's workload; swin = side measurement of the Swin-T backbone (§8-f3) on 1024x1792 "
-                         "frames (network inputs must be multiples of 32 for it; not the BASELINE workload)")
+                    help="r50 = BASELINE.json's workload; swin = side measurement of the Swin-T backbone (§8-f3) on the "
+                         "same frames (not the BASELINE workload)")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="N=1 diagnostic: run the replicated tracker over W copies of this GPU's records per step, i.e. "
                          "the tracker load of a W-GPU run, beside one GPU's detection (value still counts 8 frames/step)")
@@ -149,9 +149,7 @@ def main():
     cfg.MODEL.DEVICE = "cuda"
     src_hw = SRC_HW
     if args.backbone == "swin":
-        cfg.MODEL.BACKBONE.NAME = "build_swin_backbone"
-        src_hw = (1024, 1792)                                  # already network size: the harness resize is a no-op
-        cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 1024, 2000
+        cfg.MODEL.BACKBONE.NAME = "build_swin_backbone"        # same frames and resize as the R-50 workload
     model, sd = build_model(cfg, device)
     predictor = GoMBatchPredictor(cfg, model)
 

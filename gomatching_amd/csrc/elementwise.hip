@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
 // deformable_transformer.py:161-163.  dim_t[128] is supplied by the host (same pow as the reference).
 __global__ __launch_bounds__(256) void pos2d_kernel(const float* __restrict__ dim_t,
                                                     const float* __restrict__ level_embed, float* __restrict__ out,
-                                                    int H, int W, float scale) {
+                                                    int H, int W, int Hv, int Wv, float scale) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over HW*256
     if (i >= (long)H * W * 256) return;
     const int ch = (int)(i & 255);
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void pos2d_kernel(const float* __restrict__ di
     const bool is_y = ch < 128;
     const int j = is_y ? ch : ch - 128;
     const float e = is_y ? (float)(r + 1) : (float)(c + 1);
-    const float last = is_y ? (float)H : (float)W;
+    // padded batches: the cumulative sums stop at the valid extent (pos_encoding.py:67-72); tokens beyond it are never read
+    const float last = is_y ? (float)Hv : (float)Wv;
     const float emb = (e - 0.5f) / (last + 1e-6f) * scale;
     const float a = emb / dim_t[j];
     out[i] = ((j & 1) ? cosf(a) : sinf(a)) + level_embed[ch];
@@ -104,14 +105,18 @@ __global__ __launch_bounds__(256) void ref_sigmoid_kernel(const float* __restric
 // valid[s] = all of ((col+0.5)/W, (row+0.5)/H) in (0.01, 0.99).
 __global__ __launch_bounds__(256) void proposal_valid_kernel(const int64_t* __restrict__ shapes,
                                                              const int64_t* __restrict__ lsi, int L,
-                                                             unsigned char* __restrict__ valid, long S) {
+                                                             unsigned char* __restrict__ valid, long S,
+                                                             const int64_t* __restrict__ vshapes) {
     const long s = (long)blockIdx.x * 256 + threadIdx.x;
     if (s >= S) return;
     int l = 0;
     for (int i = 1; i < L; ++i) if (s >= lsi[i]) l = i;
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const long t = s - lsi[l];
-    const float x = ((float)(t % W) + 0.5f) / (float)W, y = ((float)(t / W) + 0.5f) / (float)H;
+    // the grid is normalised by the VALID extent of the level (deformable_transformer.py:117-124): padded tokens land
+    // beyond 0.99 and are invalid by the same test that drops the border proposals
+    const float Hn = (float)(vshapes ? vshapes[2 * l] : H), Wn = (float)(vshapes ? vshapes[2 * l + 1] : W);
+    const float x = ((float)(t % W) + 0.5f) / Wn, y = ((float)(t / W) + 0.5f) / Hn;
     valid[s] = (x > 0.01f && x < 0.99f && y > 0.01f && y < 0.99f) ? 1 : 0;
 }
 
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(256) void bezier_refs_kernel(const float* __restric
                                                           const int64_t* __restrict__ shapes,
                                                           const int64_t* __restrict__ lsi, int L,
                                                           const float* __restrict__ bern, float* __restrict__ refs,
-                                                          int B, long S, int nq, int P, int compact) {
+                                                          int B, long S, int nq, int P, int compact,
+                                                          const int64_t* __restrict__ vshapes) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*nq*P
     if (i >= (long)B * nq * P) return;
     const int p = (int)(i % P);
@@ -133,7 +139,8 @@ __global__ __launch_bounds__(256) void bezier_refs_kernel(const float* __restric
     for (int k = 1; k < L; ++k) if (s >= lsi[k]) l = k;
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const long t = s - lsi[l];
-    const float gx = ((float)(t % W) + 0.5f) / (float)W, gy = ((float)(t / W) + 0.5f) / (float)H;
+    const float Hn = (float)(vshapes ? vshapes[2 * l] : H), Wn = (float)(vshapes ? vshapes[2 * l + 1] : W);
+    const float gx = ((float)(t % W) + 0.5f) / Wn, gy = ((float)(t / W) + 0.5f) / Hn;
     const bool ok = gx > 0.01f && gx < 0.99f && gy > 0.01f && gy < 0.99f;
     const float px = ok ? logf(gx / (1.f - gx)) : INFINITY;
     const float py = ok ? logf(gy / (1.f - gy)) : INFINITY;
@@ -153,15 +160,40 @@ __global__ __launch_bounds__(256) void bezier_refs_kernel(const float* __restric
 // ref[s] = ((col+0.5)/W, (row+0.5)/H) following the reference's linspace / divide order.
 __global__ __launch_bounds__(256) void enc_ref_kernel(const int64_t* __restrict__ shapes,
                                                       const int64_t* __restrict__ lsi, int L, float* __restrict__ ref,
-                                                      long S) {
+                                                      long S, const int64_t* __restrict__ vshapes) {
     const long s = (long)blockIdx.x * 256 + threadIdx.x;
     if (s >= S) return;
     int l = 0;
     for (int i = 1; i < L; ++i) if (s >= lsi[i]) l = i;
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const long t = s - lsi[l];
+    if (vshapes) {                                           // / (valid_ratio * size), the reference's order (:294-295)
+        const float vx = (float)vshapes[2 * l + 1] / (float)W, vy = (float)vshapes[2 * l] / (float)H;
+        ref[s * 2] = ((float)(t % W) + 0.5f) / (vx * (float)W);
+        ref[s * 2 + 1] = ((float)(t / W) + 0.5f) / (vy * (float)H);
+        return;
+    }
     ref[s * 2] = ((float)(t % W) + 0.5f) / (float)W;
     ref[s * 2 + 1] = ((float)(t / W) + 0.5f) / (float)H;
+}
+
+// padded batches: value rows of tokens outside the valid extent are zero (ms_deform_attn.py:134-135); buf [B*S, ld],
+// columns [col0, col0 + ncols).
+__global__ __launch_bounds__(256) void zero_padded_kernel(float* __restrict__ buf, int ld, int col0, int ncols4,
+                                                          const int64_t* __restrict__ shapes,
+                                                          const int64_t* __restrict__ lsi,
+                                                          const int64_t* __restrict__ vshapes, int L, long S, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*S*ncols4
+    if (i >= total) return;
+    const int c = (int)(i % ncols4);
+    const long tok = i / ncols4;
+    const long s = tok % S;
+    int l = 0;
+    for (int k = 1; k < L; ++k) if (s >= lsi[k]) l = k;
+    const int W = (int)shapes[2 * l + 1];
+    const long t = s - lsi[l];
+    if ((t / W) >= vshapes[2 * l] || (t % W) >= vshapes[2 * l + 1])
+        *reinterpret_cast<f32x4*>(buf + tok * ld + col0 + c * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -218,7 +250,16 @@ extern "C" int gom_maxpool3x3s2_nhwc_f32(const float* x, float* y, int B, int H,
 extern "C" int gom_pos_encoding_2d_f32(const float* dim_t128, const float* level_embed256, float* out, int H, int W,
                                        void* stream) {
     GOM_CHECK_ARG(dim_t128 && level_embed256 && out && H > 0 && W > 0);
-    hipLaunchKernelGGL(pos2d_kernel, GOM_GRID((long)H * W * 256), dim_t128, level_embed256, out, H, W,
+    hipLaunchKernelGGL(pos2d_kernel, GOM_GRID((long)H * W * 256), dim_t128, level_embed256, out, H, W, H, W,
+                       6.283185307179586f);
+    return gom_launch_status();
+}
+
+extern "C" int gom_pos_encoding_2d_valid_f32(const float* dim_t128, const float* level_embed256, float* out, int H, int W,
+                                             int valid_h, int valid_w, void* stream) {
+    GOM_CHECK_ARG(dim_t128 && level_embed256 && out && H > 0 && W > 0 && valid_h > 0 && valid_h <= H && valid_w > 0 &&
+                  valid_w <= W);
+    hipLaunchKernelGGL(pos2d_kernel, GOM_GRID((long)H * W * 256), dim_t128, level_embed256, out, H, W, valid_h, valid_w,
                        6.283185307179586f);
     return gom_launch_status();
 }
@@ -243,7 +284,16 @@ extern "C" int gom_ref_sigmoid_f32(const float* delta, int ld_delta, const float
 extern "C" int gom_proposal_valid(const int64_t* spatial_shapes, const int64_t* level_start_index, int num_levels,
                                   unsigned char* valid, long S, void* stream) {
     GOM_CHECK_ARG(spatial_shapes && level_start_index && valid && num_levels > 0 && S > 0);
-    hipLaunchKernelGGL(proposal_valid_kernel, GOM_GRID(S), spatial_shapes, level_start_index, num_levels, valid, S);
+    hipLaunchKernelGGL(proposal_valid_kernel, GOM_GRID(S), spatial_shapes, level_start_index, num_levels, valid, S,
+                       (const int64_t*)nullptr);
+    return gom_launch_status();
+}
+
+extern "C" int gom_proposal_valid_masked(const int64_t* spatial_shapes, const int64_t* level_start_index, int num_levels,
+                                         const int64_t* valid_shapes, unsigned char* valid, long S, void* stream) {
+    GOM_CHECK_ARG(spatial_shapes && level_start_index && valid_shapes && valid && num_levels > 0 && S > 0);
+    hipLaunchKernelGGL(proposal_valid_kernel, GOM_GRID(S), spatial_shapes, level_start_index, num_levels, valid, S,
+                       valid_shapes);
     return gom_launch_status();
 }
 
@@ -255,14 +305,46 @@ extern "C" int gom_bezier_reference_points(const float* coord_raw, const int* to
     GOM_CHECK_ARG(B > 0 && S > 0 && num_queries > 0 && num_points > 0);
     hipLaunchKernelGGL(bezier_refs_kernel, GOM_GRID((long)B * num_queries * num_points), coord_raw, topk_idx,
                        spatial_shapes, level_start_index, num_levels, bernstein, refs, B, S, num_queries, num_points,
-                       compact);
+                       compact, (const int64_t*)nullptr);
+    return gom_launch_status();
+}
+
+extern "C" int gom_bezier_reference_points_masked(const float* coord_raw, const int* topk_idx, const int64_t* spatial_shapes,
+                                                  const int64_t* level_start_index, const int64_t* valid_shapes,
+                                                  int num_levels, const float* bernstein, float* refs, int B, long S,
+                                                  int num_queries, int num_points, int compact, void* stream) {
+    GOM_CHECK_ARG(coord_raw && topk_idx && spatial_shapes && level_start_index && valid_shapes && bernstein && refs);
+    GOM_CHECK_ARG(B > 0 && S > 0 && num_queries > 0 && num_points > 0);
+    hipLaunchKernelGGL(bezier_refs_kernel, GOM_GRID((long)B * num_queries * num_points), coord_raw, topk_idx,
+                       spatial_shapes, level_start_index, num_levels, bernstein, refs, B, S, num_queries, num_points,
+                       compact, valid_shapes);
     return gom_launch_status();
 }
 
 extern "C" int gom_encoder_reference_points(const int64_t* spatial_shapes, const int64_t* level_start_index,
                                             int num_levels, float* ref, long S, void* stream) {
     GOM_CHECK_ARG(spatial_shapes && level_start_index && ref && num_levels > 0 && S > 0);
-    hipLaunchKernelGGL(enc_ref_kernel, GOM_GRID(S), spatial_shapes, level_start_index, num_levels, ref, S);
+    hipLaunchKernelGGL(enc_ref_kernel, GOM_GRID(S), spatial_shapes, level_start_index, num_levels, ref, S,
+                       (const int64_t*)nullptr);
+    return gom_launch_status();
+}
+
+extern "C" int gom_encoder_reference_points_masked(const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                                   const int64_t* valid_shapes, int num_levels, float* ref, long S,
+                                                   void* stream) {
+    GOM_CHECK_ARG(spatial_shapes && level_start_index && valid_shapes && ref && num_levels > 0 && S > 0);
+    hipLaunchKernelGGL(enc_ref_kernel, GOM_GRID(S), spatial_shapes, level_start_index, num_levels, ref, S, valid_shapes);
+    return gom_launch_status();
+}
+
+extern "C" int gom_zero_padded_tokens_f32(float* buf, int ld, int col0, int ncols, const int64_t* spatial_shapes,
+                                          const int64_t* level_start_index, const int64_t* valid_shapes, int num_levels,
+                                          int B, long S, void* stream) {
+    GOM_CHECK_ARG(buf && spatial_shapes && level_start_index && valid_shapes && num_levels > 0 && B > 0 && S > 0);
+    GOM_CHECK_ARG(ncols > 0 && (ncols % 4) == 0 && (col0 % 4) == 0 && (ld % 4) == 0 && col0 + ncols <= ld);
+    const long total = (long)B * S * (ncols / 4);
+    hipLaunchKernelGGL(zero_padded_kernel, GOM_GRID(total), buf, ld, col0, ncols / 4, spatial_shapes, level_start_index,
+                       valid_shapes, num_levels, S, total);
     return gom_launch_status();
 }
 

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float* __restrict
                                                          const int64_t* __restrict__ lsi,
                                                          const float* __restrict__ raw, int ld_raw,
                                                          const float* __restrict__ ref, float* __restrict__ out,
-                                                         int B, int Lq, long v_bs, int v_rs) {
+                                                         int B, int Lq, long v_bs, int v_rs,
+                                                         const float* __restrict__ vr) {
     constexpr int LP = LEVELS * POINTS;
     const long q_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q_global >= (long)B * Lq) return;
@@ -164,7 +165,9 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float* __restrict
             float qx = ox * rW, qy = oy * rH;
             qx = fmaf(fmaf(-qx, Wf, ox), rW, qx);
             qy = fmaf(fmaf(-qy, Hf, oy), rH, qy);
-            const float lx = rx + qx, ly = ry + qy;
+            // padded batches: the reference point is scaled by the level's valid ratio first (deformable_transformer.py:
+            // 262-263 / 470-472); vr == nullptr is the unpadded case (ratios 1)
+            const float lx = (vr ? rx * vr[2 * l] : rx) + qx, ly = (vr ? ry * vr[2 * l + 1] : ry) + qy;
             const float w = e[i] * inv_sum;
             const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
             const bool inside = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
@@ -206,7 +209,21 @@ extern "C" int gom_msda_fused_forward(const float* raw, int ld_raw, const float*
     const long nq = (long)batch * num_query;
     hipLaunchKernelGGL((msda_fused_kernel<4>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
                        spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
-                       value_batch_stride, value_row_stride);
+                       value_batch_stride, value_row_stride, (const float*)nullptr);
+    return gom_launch_status();
+}
+
+extern "C" int gom_msda_fused_forward_vr(const float* raw, int ld_raw, const float* ref, const float* value,
+                                         long value_batch_stride, int value_row_stride, const int64_t* spatial_shapes,
+                                         const int64_t* level_start_index, const float* valid_ratios, float* output,
+                                         int batch, int num_query, void* stream) {
+    GOM_CHECK_ARG(raw && ref && value && spatial_shapes && level_start_index && valid_ratios && output);
+    GOM_CHECK_ARG(batch > 0 && num_query > 0 && ld_raw >= HEADS * LEVELS * 4 * 3 && (ld_raw % 4) == 0);
+    GOM_CHECK_ARG(value_row_stride >= HEADS * CH && (value_row_stride % 4) == 0 && (value_batch_stride % 4) == 0);
+    const long nq = (long)batch * num_query;
+    hipLaunchKernelGGL((msda_fused_kernel<4>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
+                       spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
+                       value_batch_stride, value_row_stride, valid_ratios);
     return gom_launch_status();
 }
 

@@ -69,6 +69,12 @@ SIGNATURES = {
     "gom_track_score_f32": (I, [P, I, P, P, P, F, F, I, I, I, I, F, P, P]),
     "gom_short_term_pairs_f32": (I, [P, P, I, P, P, P, F, F, I, I, I, P, P]),
     "gom_mha_core_segments_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "gom_pos_encoding_2d_valid_f32": (I, [P, P, P, I, I, I, I, P]),
+    "gom_proposal_valid_masked": (I, [P, P, I, P, P, L, P]),
+    "gom_encoder_reference_points_masked": (I, [P, P, P, I, P, L, P]),
+    "gom_bezier_reference_points_masked": (I, [P, P, P, P, P, I, P, P, I, L, I, I, I, P]),
+    "gom_msda_fused_forward_vr": (I, [P, I, P, P, L, I, P, P, P, P, I, I, P]),
+    "gom_zero_padded_tokens_f32": (I, [P, I, I, I, P, P, P, I, I, L, P]),
     "gom_layernorm_any_f32": (I, [P, P, P, P, L, I, F, P]),
     "gom_gelu_f32": (I, [P, L, P]),
     "gom_swin_patchify_f32": (I, [P, P, I, I, I, P]),

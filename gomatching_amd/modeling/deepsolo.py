@@ -132,8 +132,27 @@ class DeepSolo:
         shapes.append((c(h2, 3, 2, 1), c(w2, 3, 2, 1)))
         return shapes
 
-    def geometry(self, shapes, B):
-        key = (tuple(shapes), B)
+    @staticmethod
+    def valid_shapes(shapes, image_hw, strides=(8, 16, 32)):
+        """Valid (unpadded) extent of every level for an image of `image_hw` inside a padded batch: ceil(size / stride)
+        for the backbone levels (gom_lstmatcher.py:63-76); the extra level takes the nearest-neighbour resampling of the
+        FIRST level's mask (detection_transformer_wobackbone.py:177-178) with torch's float source-index rule."""
+        import numpy as np
+        v = [(min(-(-image_hw[0] // s), H), min(-(-image_hw[1] // s), W)) for s, (H, W) in zip(strides, shapes[:3])]
+
+        def resample(n_in, n_out, n_valid):
+            scale = np.float32(n_in) / np.float32(n_out)
+            src = np.minimum(np.floor(np.arange(n_out, dtype=np.float32) * scale).astype(np.int64), n_in - 1)
+            return int((src < n_valid).sum())
+
+        v.append((resample(shapes[0][0], shapes[3][0], v[0][0]), resample(shapes[0][1], shapes[3][1], v[0][1])))
+        return v
+
+    def geometry(self, shapes, B, vshapes=None):
+        """Per-resolution tables.  `vshapes`: valid extents per level for a padded batch (None: nothing is padded)."""
+        if vshapes is not None and all(tuple(v) == tuple(s) for v, s in zip(vshapes, shapes)):
+            vshapes = None
+        key = (tuple(shapes), B, None if vshapes is None else tuple(map(tuple, vshapes)))
         if key in self._geom:
             return self._geom[key]
         dev = self.device
@@ -141,17 +160,28 @@ class DeepSolo:
         lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
         S = int(ss.prod(1).sum())
         ss_d, lsi_d = ss.to(dev), lsi.to(dev)
+        vs_d = vr_d = None
+        if vshapes is not None:
+            import numpy as np
+            if any(v[0] <= 0 or v[1] <= 0 for v in vshapes):
+                raise ValueError("a level has no valid token: image %s too small for the padded batch" % (vshapes,))
+            vs_d = torch.as_tensor(vshapes, dtype=torch.long).to(dev)
+            vr = np.array([[np.float32(v[1]) / np.float32(s[1]), np.float32(v[0]) / np.float32(s[0])]
+                           for v, s in zip(vshapes, shapes)], np.float32)              # (Wv/W, Hv/H), get_valid_ratio
+            vr_d = torch.from_numpy(vr).to(dev)
         lvl_pos = torch.empty((S, 256), dtype=_f32, device=dev)
         for l, (H, W) in enumerate(shapes):
-            ops.pos_encoding_into(self.dim_t, self.level_embed[l], lvl_pos[int(lsi[l]):], H, W)
+            ops.pos_encoding_into(self.dim_t, self.level_embed[l], lvl_pos[int(lsi[l]):], H, W,
+                                  None if vshapes is None else vshapes[l])
         # (src + pos) @ W = src @ W + pos @ W, and pos is a per-resolution constant: the position term of every encoder
         # layer's offsets/logits GEMM is a cached residual table instead of a second operand stream
         pos_w = [ops.broadcast_rows(ops.gemm(lvl_pos, L["attn"]["raw"][0]), B).view(B * S, 384) for L in self.enc]
         geo = {
             "S": S, "shapes": ss_d, "lsi": lsi_d, "lsi_host": [int(v) for v in lsi], "pos_w": pos_w,
             "lvl_pos": ops.broadcast_rows(lvl_pos, B).view(B * S, 256),
-            "enc_ref": ops.broadcast_rows(ops.encoder_reference_points(ss_d, lsi_d, S), B).view(B * S, 1, 2),
-            "valid": ops.proposal_valid(ss_d, lsi_d, S),
+            "enc_ref": ops.broadcast_rows(ops.encoder_reference_points(ss_d, lsi_d, S, vs_d), B).view(B * S, 1, 2),
+            "valid": ops.proposal_valid(ss_d, lsi_d, S, vs_d),
+            "vshapes": vs_d, "vr": vr_d, "vr0": None if vr_d is None else (float(vr[0, 0]), float(vr[0, 1])),
         }
         self._geom[key] = geo
         return geo
@@ -165,7 +195,7 @@ class DeepSolo:
         return self._invalid_logit
 
     # --------------------------------------------------------------------------------- pieces
-    def input_tokens(self, feats, B):
+    def input_tokens(self, feats, B, image_hw=None):
         """A4 + A5: input_proj (conv + GroupNorm) of the 3 backbone levels + the stride-2 extra level,
         written level by level into the flattened token buffer."""
         shapes = [(f.shape[1], f.shape[2]) for f in feats]
@@ -176,7 +206,7 @@ class DeepSolo:
             top = padded
         x3 = ops.conv2d_nhwc(top, self.proj3[0], shift=self.proj3[1], stride=2, pad=1)
         shapes.append((x3.shape[1], x3.shape[2]))
-        geo = self.geometry(shapes, B)
+        geo = self.geometry(shapes, B, None if image_hw is None else self.valid_shapes(shapes, image_hw))
         S = geo["S"]
         src = torch.empty((B, S, 256), dtype=_f32, device=self.device)
         for l, f in enumerate(feats):
@@ -192,7 +222,9 @@ class DeepSolo:
         for li, L in enumerate(self.enc):
             w, b = L["attn"]["raw_value"]
             rv = ops.gemm(src, w, bias=b, R=geo["pos_w"][li], r_cols=384)             # [B*S, 384 | 256]
-            samp = ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S)
+            if geo["vr"] is not None:                      # padded batch: value.masked_fill(padding_mask, 0)
+                ops.zero_padded_tokens_(rv, 384, 256, geo["shapes"], geo["lsi"], geo["vshapes"], B, S)
+            samp = ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, geo["vr"])
             x = ops.gemm(samp, L["attn"]["out"][0], bias=L["attn"]["out"][1], R=src)
             src = ops.layernorm(x, *L["norm1"])
             h = ops.gemm(src, L["lin1"][0], bias=L["lin1"][1], relu=True)
@@ -212,7 +244,7 @@ class DeepSolo:
         h = ops.gemm(h, self.bezier_coord[1][0], bias=self.bezier_coord[1][1], relu=True)
         coord_sel = ops.gemm(h, self.bezier_coord[2][0], bias=self.bezier_coord[2][1])          # [B*nq, 8]
         refs = ops.bezier_reference_points(coord_sel, topk, geo["shapes"], geo["lsi"], self.bernstein, B, S, self.nq,
-                                           self.P, compact=True)
+                                           self.P, compact=True, vshapes=geo["vshapes"])
         return refs, topk, enc_class
 
     def decoder(self, memory, refs, geo, B):
@@ -221,11 +253,16 @@ class DeepSolo:
         Q = B * nq * P
         tgt = ops.broadcast_rows(self.point_embed, B).view(Q, 256)
         values = ops.gemm(memory, self.dec_value_w, bias=self.dec_value_b)                    # [B*S, 1536]
+        vr = geo["vr"]
+        if vr is not None:
+            ops.zero_padded_tokens_(values, 0, values.shape[1], geo["shapes"], geo["lsi"], geo["vshapes"], B, S)
         refs = refs.view(Q, 2)
         inter_refs = []
         E = 256
         for lid, L in enumerate(self.dec):
-            qpos = ops.point_pos_embed(refs, self.dim_t)
+            # reference_points_input = reference_points * valid_ratios; the query position comes from level 0's (:470-473)
+            qref = refs if vr is None else ops.scale_xy_(refs.clone(), *geo["vr0"])
+            qpos = ops.point_pos_embed(qref, self.dim_t)
             qpos = ops.gemm(qpos, self.ref_point_head[0][0], bias=self.ref_point_head[0][1], relu=True)
             qpos = ops.gemm(qpos, self.ref_point_head[1][0], bias=self.ref_point_head[1][1])
             # intra-instance attention over the 25 points of each query (deformable_transformer.py:386-394)
@@ -250,7 +287,7 @@ class DeepSolo:
             # deformable cross attention into the encoder memory (:406-422)
             value = values[:, lid * E:(lid + 1) * E]
             samp = self._msda_strided(L["cross"], tgt, qpos, refs.view(Q, 1, 2), value, values.stride(0), geo, B,
-                                      nq * P)
+                                      nq * P, vr)
             x = ops.gemm(samp, L["cross"]["out"][0], bias=L["cross"]["out"][1], R=tgt)
             tgt = ops.layernorm(x, *L["norm_cross"])
             h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True)
@@ -262,10 +299,10 @@ class DeepSolo:
             inter_refs.append(refs)
         return tgt, inter_refs
 
-    def _msda_strided(self, W, query, query_pos, ref, value_view, ld_value, geo, B, Lq):
+    def _msda_strided(self, W, query, query_pos, ref, value_view, ld_value, geo, B, Lq, vr=None):
         """Cross-attention sampling straight out of the fused [B*S, 1536] value buffer (no compaction copy)."""
         raw = ops.gemm(query, W["raw"][0], bias=W["raw"][1], A2=query_pos)
-        return ops.msda_fused(raw, ref, value_view, geo["S"] * ld_value, geo["shapes"], geo["lsi"], B, Lq)
+        return ops.msda_fused(raw, ref, value_view, geo["S"] * ld_value, geo["shapes"], geo["lsi"], B, Lq, vr)
 
     def _mlp3(self, x, layers):
         h = ops.gemm(x, layers[0][0], bias=layers[0][1], relu=True)
@@ -283,12 +320,12 @@ class DeepSolo:
                 "query_features": hs}
 
     # --------------------------------------------------------------------------------- whole forward
-    def forward(self, feats, taps=None):
+    def forward(self, feats, taps=None, image_hw=None):
         """feats: [res3, res4, res5] NHWC tensors of one batch of same-size frames.  Returns the reference's
         output dict with tensors flattened over (B, nq, P): pred_logits [B*nq*P,1], pred_text_logits [.,voc+1],
         pred_ctrl_points [.,2], pred_bd_points [.,4], query_features [.,256]."""
         B = feats[0].shape[0]
-        src, geo = self.input_tokens(feats, B)
+        src, geo = self.input_tokens(feats, B, image_hw)
         memory = self.encoder(src, geo, B)
         refs, topk, enc_class = self.proposals(memory, geo, B)
         hs, inter_refs = self.decoder(memory, refs, geo, B)

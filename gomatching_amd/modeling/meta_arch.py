@@ -150,12 +150,9 @@ class GoMatching:
         x = self._normalise(raw, kind)
         sync(); time_cost["pre_process"] += time.time() - t0
         t0 = time.time()
-        div = getattr(self.backbone, "size_divisibility", 0)
-        if div and (hw[0] % div or hw[1] % div):
-            # the reference pads such inputs to the backbone's size_divisibility (swin_transformer.py:678) and carries
-            # padding masks through DeepSolo; that masked path is not built
-            raise NotImplementedError("the %s backbone needs network inputs that are multiples of %d (got %dx%d): padding "
-                                      "masks are not implemented" % (type(self.backbone).__name__, div, hw[0], hw[1]))
+        # no batch padding: the reference hands `ImageList.from_tensors(images)` (gom_lstmatcher.py:169, no
+        # size_divisibility) to the backbone, and Swin pads inside its own blocks (swin_transformer.py:251-253, :320,
+        # :477-479) -- so do csrc/swin.hip's patchify / window / merge kernels
         feats = self.backbone.forward(x)
         sync(); time_cost["backbone"] += time.time() - t0
         t0 = time.time()

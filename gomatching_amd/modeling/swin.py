@@ -43,7 +43,7 @@ class SwinTiny:
     out_features = ("stage3", "stage4", "stage5")
     strides = {"stage3": 8, "stage4": 16, "stage5": 32}
     channels = {"stage3": 192, "stage4": 384, "stage5": 768}
-    size_divisibility = 32
+    size_divisibility = 32          # what the reference's module reports (:651); GoMatching never pads to it
 
     def __init__(self, sd, device, prefix="backbone.0.backbone."):
         self.device = device

@@ -402,11 +402,17 @@ def ms_deform_attn_forward_strided(value2d, batch_stride, shapes, lsi, loc, w, B
     return out
 
 
-def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq):
-    """raw [B*Lq, >=384] (offsets | logits, stride(1)==1), ref [B*Lq, 2], value2d [B*S, 256] column slice."""
+def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq, valid_ratios=None):
+    """raw [B*Lq, >=384] (offsets | logits, stride(1)==1), ref [B*Lq, 2], value2d [B*S, 256] column slice;
+    valid_ratios [4,2] fp32 (Wv/W, Hv/H) for padded batches."""
     assert raw.stride(1) == 1 and value2d.stride(1) == 1
-    _chk_f32(ref)
+    _chk_f32(ref, valid_ratios)
     out = torch.empty((B * Lq, 256), dtype=_f32, device=raw.device)
+    if valid_ratios is not None:
+        check(_L().gom_msda_fused_forward_vr(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride,
+                                             value2d.stride(0), _p(shapes), _p(lsi), _p(valid_ratios), _p(out), B, Lq,
+                                             _stream()), "gom_msda_fused_forward_vr")
+        return out
     check(_L().gom_msda_fused_forward(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride, value2d.stride(0),
                                       _p(shapes), _p(lsi), _p(out), B, Lq, _stream()), "gom_msda_fused_forward")
     return out
@@ -510,7 +516,11 @@ def maxpool3x3s2(x):
     return y
 
 
-def pos_encoding_into(dim_t, level_embed_row, out_view, H, W):
+def pos_encoding_into(dim_t, level_embed_row, out_view, H, W, valid_hw=None):
+    if valid_hw is not None:
+        check(_L().gom_pos_encoding_2d_valid_f32(_p(dim_t), _p(level_embed_row), _p(out_view), H, W, int(valid_hw[0]),
+                                                 int(valid_hw[1]), _stream()), "gom_pos_encoding_2d_valid_f32")
+        return
     check(_L().gom_pos_encoding_2d_f32(_p(dim_t), _p(level_embed_row), _p(out_view), H, W, _stream()),
           "gom_pos_encoding_2d_f32")
 
@@ -532,23 +542,44 @@ def ref_sigmoid(delta, ref, C):
     return out
 
 
-def proposal_valid(shapes, lsi, S):
+def proposal_valid(shapes, lsi, S, vshapes=None):
     out = torch.empty((S,), dtype=torch.uint8, device=shapes.device)
+    if vshapes is not None:
+        check(_L().gom_proposal_valid_masked(_p(shapes), _p(lsi), shapes.shape[0], _p(vshapes), _p(out), S, _stream()),
+              "gom_proposal_valid_masked")
+        return out
     check(_L().gom_proposal_valid(_p(shapes), _p(lsi), shapes.shape[0], _p(out), S, _stream()), "gom_proposal_valid")
     return out
 
 
-def encoder_reference_points(shapes, lsi, S):
+def zero_padded_tokens_(buf, col0, ncols, shapes, lsi, vshapes, B, S):
+    """buf [B*S, ld]: zero columns [col0, col0+ncols) of the tokens outside their level's valid region."""
+    _chk_f32(buf)
+    check(_L().gom_zero_padded_tokens_f32(_p(buf), buf.stride(0), col0, ncols, _p(shapes), _p(lsi), _p(vshapes),
+                                          shapes.shape[0], B, S, _stream()), "gom_zero_padded_tokens_f32")
+    return buf
+
+
+def encoder_reference_points(shapes, lsi, S, vshapes=None):
     out = torch.empty((S, 2), dtype=_f32, device=shapes.device)
+    if vshapes is not None:
+        check(_L().gom_encoder_reference_points_masked(_p(shapes), _p(lsi), _p(vshapes), shapes.shape[0], _p(out), S,
+                                                       _stream()), "gom_encoder_reference_points_masked")
+        return out
     check(_L().gom_encoder_reference_points(_p(shapes), _p(lsi), shapes.shape[0], _p(out), S, _stream()),
           "gom_encoder_reference_points")
     return out
 
 
-def bezier_reference_points(coord_raw, topk_idx, shapes, lsi, bern, B, S, nq, P, compact=False):
+def bezier_reference_points(coord_raw, topk_idx, shapes, lsi, bern, B, S, nq, P, compact=False, vshapes=None):
     """coord_raw: [B,S,8] (compact=False) or the selected tokens' rows [B*nq,8] (compact=True)."""
     _chk_f32(coord_raw, bern)
     out = torch.empty((B, nq, P, 2), dtype=_f32, device=coord_raw.device)
+    if vshapes is not None:
+        check(_L().gom_bezier_reference_points_masked(_p(coord_raw), _p(topk_idx), _p(shapes), _p(lsi), _p(vshapes),
+                                                      shapes.shape[0], _p(bern), _p(out), B, S, nq, P,
+                                                      1 if compact else 0, _stream()), "gom_bezier_reference_points_masked")
+        return out
     check(_L().gom_bezier_reference_points(_p(coord_raw), _p(topk_idx), _p(shapes), _p(lsi), shapes.shape[0],
                                            _p(bern), _p(out), B, S, nq, P, 1 if compact else 0, _stream()),
           "gom_bezier_reference_points")

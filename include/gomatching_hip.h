@@ -226,6 +226,28 @@ int gom_detect_post(const float* cls_logits, int ld_cls, const float* rescoring_
                     int* count, int* keep_idx, float* scores, float* boxes, float* ctrl_out, float* bd_out,
                     long long* recs_out, void* stream);
 
+/* ---- padded batches (gom_lstmatcher.py:63-76; deformable_transformer.py:141-148): every level's valid region is a
+ * top-left rectangle valid_shapes [L][2] = (Hv, Wv) of its (H, W).  Mask-aware forms of the geometry tables, the fused
+ * MSDA (reference points scaled by the level's valid ratio [L][2] = (Wv/W, Hv/H)) and the value zero-fill. */
+int gom_pos_encoding_2d_valid_f32(const float* dim_t128, const float* level_embed256, float* out, int H, int W, int valid_h,
+                                  int valid_w, void* stream);
+int gom_proposal_valid_masked(const int64_t* spatial_shapes, const int64_t* level_start_index, int num_levels,
+                              const int64_t* valid_shapes, unsigned char* valid, long S, void* stream);
+int gom_encoder_reference_points_masked(const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                        const int64_t* valid_shapes, int num_levels, float* ref, long S, void* stream);
+int gom_bezier_reference_points_masked(const float* coord_raw, const int* topk_idx, const int64_t* spatial_shapes,
+                                       const int64_t* level_start_index, const int64_t* valid_shapes, int num_levels,
+                                       const float* bernstein, float* refs, int B, long S, int num_queries, int num_points,
+                                       int compact, void* stream);
+int gom_msda_fused_forward_vr(const float* raw, int ld_raw, const float* ref, const float* value, long value_batch_stride,
+                              int value_row_stride, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                              const float* valid_ratios, float* output, int batch, int num_query, void* stream);
+/* zero columns [col0, col0+ncols) of the rows of buf [B*S, ld] whose token lies outside its level's valid region
+ * (value.masked_fill(padding_mask, 0), ms_deform_attn.py:134-135). */
+int gom_zero_padded_tokens_f32(float* buf, int ld, int col0, int ncols, const int64_t* spatial_shapes,
+                               const int64_t* level_start_index, const int64_t* valid_shapes, int num_levels, int B, long S,
+                               void* stream);
+
 /* ---- f3: Swin-T backbone glue (third_party/adet/modeling/swin/swin_transformer.py) ---------------------------------
  * The linear layers use the GEMM entry points above.  Tokens are [B,H,W,C] channels-last.  Window rows are ordered
  * (image, window row, window column, token 0..48), windows of 7x7 over the map zero-padded to multiples of 7. */

@@ -156,8 +156,9 @@ def case_msda():
     np.savez_compressed(os.path.join(GOLD, "msda.npz"), **out)
 
 
-def case_deepsolo(builtin, tag, voc=None):
-    """(ii) DeepSolo-without-backbone at a mini geometry, random features in place of R-50 outputs."""
+def case_deepsolo(builtin, tag, voc=None, image_hw=None):
+    """(ii) DeepSolo-without-backbone at a mini geometry, random features in place of R-50 outputs.  `image_hw`: the
+    unpadded image size of a batch padded to 64x96 -> non-trivial padding masks (gom_lstmatcher.py:63-76)."""
     cfg = mini_cfg(builtin, voc=voc)
     sd = synth_state_dict(cfg, seed=7)
     ref = build_ref_deepsolo(cfg, sd)
@@ -168,6 +169,10 @@ def case_deepsolo(builtin, tag, voc=None):
     dims = [(512, 8, 12), (1024, 4, 6), (2048, 2, 3)]
     feats = [torch.randn(B, c, h, w, generator=g) * 0.5 for c, h, w in dims]
     masks = [torch.zeros(B, h, w, dtype=torch.bool) for _, h, w in dims]
+    if image_hw is not None:
+        for m, stride in zip(masks, (8, 16, 32)):
+            m[:] = True
+            m[:, :int(np.ceil(image_hw[0] / stride)), :int(np.ceil(image_hw[1] / stride))] = False
     T = cfg.MODEL.TRANSFORMER
     posenc = pe.PositionalEncoding2D(T.HIDDEN_DIM // 2, T.TEMPERATURE, normalize=True)
     nts = [misc.NestedTensor(f, m) for f, m in zip(feats, masks)]
@@ -188,6 +193,10 @@ def case_deepsolo(builtin, tag, voc=None):
     # intermediate taps come from the (just validated) oracle; final outputs above are the reference's
     for k in ("memory", "enc_class", "topk", "init_ref", "enc0", "dec0"):
         out["tap_" + k] = _np(taps[k])
+    for i, m in enumerate(masks):
+        out["mask%d" % i] = _np(m)
+    if image_hw is not None:
+        out["image_hw"] = np.asarray(image_hw)
     np.savez_compressed(os.path.join(GOLD, "deepsolo_%s.npz" % tag), **out)
 
 
@@ -382,6 +391,7 @@ def main():
     case_msda()
     case_deepsolo("icdar15", "ic15")
     case_deepsolo("bovtext", "voc96", voc=96)
+    case_deepsolo("icdar15", "padded", image_hw=(41, 70))
     case_matcher("icdar15", "lst")
     case_matcher("pp_dstext", "pp")
     case_tracker("icdar15", "lst")
@@ -391,4 +401,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "padded":           # regenerate only the padded-batch DeepSolo fixture
+        os.makedirs(GOLD, exist_ok=True)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        case_deepsolo("icdar15", "padded", image_hw=(41, 70))
+    else:
+        main()

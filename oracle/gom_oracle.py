@@ -701,7 +701,6 @@ def detect_frames(sd, cfg, images, taps=None):
     sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
     if cfg.MODEL.BACKBONE.NAME == "build_swin_backbone":
         from oracle.swin_oracle import swin_tiny
-        assert all(h % 32 == 0 and w % 32 == 0 for h, w in sizes), "Swin needs padded batches + masks otherwise"
         feats = swin_tiny(x, sd)
         feats = [feats[k] for k in ("stage3", "stage4", "stage5")]
     else:

@@ -75,6 +75,34 @@ def test_deepsolo_mini_golden(builtin, tag, voc, gemm_mode):
         _close(out[k].view(*shape), g[k], 2e-4, k)
 
 
+def test_deepsolo_padded_batch_golden(gemm_mode):
+    """Padded batch (41x70 images inside 64x96): the mask-aware kernels against the reference's own outputs."""
+    from gomatching_amd.weights import synth_state_dict
+    from gomatching_amd.modeling import DeepSolo
+    g = golden("deepsolo_padded.npz")
+    cfg = mini_cfg("icdar15")
+    sd = synth_state_dict(cfg, seed=7)
+    net = DeepSolo(cfg, sd, DEV)
+    feats = [t(g["feat%d" % i]).permute(0, 2, 3, 1).contiguous().to(DEV) for i in range(3)]
+    taps = {}
+    out = net.forward(feats, taps=taps, image_hw=tuple(int(v) for v in g["image_hw"]))
+    B, nq, P = 2, cfg.MODEL.TRANSFORMER.NUM_QUERIES, 25
+    # padded tokens of the memory are garbage-in/garbage-out in both implementations only through masked paths;
+    # compare the valid ones, then everything downstream
+    shapes = [(8, 12), (4, 6), (2, 3), (1, 2)]
+    vs = DeepSolo.valid_shapes(shapes, tuple(int(v) for v in g["image_hw"]))
+    keep = torch.cat([((torch.arange(H)[:, None] < v[0]) & (torch.arange(W)[None, :] < v[1])).flatten()
+                      for (H, W), v in zip(shapes, vs)])
+    mem = taps["memory"].view(B, -1, 256).cpu()
+    _close(mem[:, keep], t(g["tap_memory"])[:, keep], 1e-4, "memory (valid tokens)")
+    assert torch.equal(taps["topk"].cpu().long(), t(g["tap_topk"])), "top-k proposals differ"
+    _close(taps["init_ref"].view(B, nq, P, 2), g["tap_init_ref"], 1e-5, "init_ref")
+    for k, shape in (("pred_logits", (B, nq, P, 1)), ("pred_text_logits", (B, nq, P, -1)),
+                     ("pred_ctrl_points", (B, nq, P, 2)), ("pred_bd_points", (B, nq, P, 4)),
+                     ("query_features", (B, nq, P, 256))):
+        _close(out[k].view(*shape), g[k], 2e-4, k)
+
+
 @pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
 def test_matcher_heads_golden(builtin, tag):
     from gomatching_amd.weights import synth_state_dict

@@ -37,6 +37,44 @@ def test_deepsolo_mini(builtin, tag, voc):
         np.testing.assert_allclose(out[k].numpy(), g[k], atol=TOL, rtol=0, err_msg=k)
 
 
+def test_deepsolo_padded_batch():
+    """A batch padded to 64x96 around 41x70 images: padding masks reach the position tables, the encoder value
+    rows, the valid ratios and the proposal validity (gom_lstmatcher.py:63-76)."""
+    g = golden("deepsolo_padded.npz")
+    cfg = mini_cfg("icdar15")
+    sd = synth_state_dict(cfg, seed=7)
+    feats = [t(g["feat%d" % i]) for i in range(3)]
+    masks = [t(g["mask%d" % i]).bool() for i in range(3)]
+    assert bool(masks[0].any()) and bool(masks[1].any())
+    T = cfg.MODEL.TRANSFORMER
+    pos = [O.pos_encoding_2d(m, T.HIDDEN_DIM // 2, T.TEMPERATURE) for m in masks]
+    for i in range(3):
+        np.testing.assert_allclose(pos[i].numpy(), g["pos%d" % i], atol=1e-6, rtol=0)
+    with torch.no_grad():
+        out = O.deepsolo_forward(sd, cfg, feats, masks, pos)
+    for k in ("pred_logits", "pred_text_logits", "pred_ctrl_points", "pred_bd_points", "query_features"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], atol=TOL, rtol=0, err_msg=k)
+
+
+def test_valid_shapes_follow_the_masks():
+    """Host logic: DeepSolo.valid_shapes == the valid extents of the reference's masks, incl. the resampled 4th level."""
+    from gomatching_amd.modeling.deepsolo import DeepSolo
+    import torch.nn.functional as F
+    for hw, pad in (((41, 70), (64, 96)), ((720, 1280), (736, 1280)), ((1000, 1777), (1024, 1792)), ((33, 33), (64, 64))):
+        shapes, masks = [], []
+        for s in (8, 16, 32):
+            m = torch.ones(1, pad[0] // s, pad[1] // s, dtype=torch.bool)
+            m[:, :-(-hw[0] // s), :-(-hw[1] // s)] = False
+            masks.append(m)
+            shapes.append(tuple(m.shape[1:]))
+        h3, w3 = (shapes[2][0] - 1) // 2 + 1, (shapes[2][1] - 1) // 2 + 1
+        shapes.append((h3, w3))
+        masks.append(F.interpolate(masks[0][None].float(), size=(h3, w3)).to(torch.bool)[0])
+        got = DeepSolo.valid_shapes(shapes, hw)
+        want = [(int((~m[0, :, 0]).sum()), int((~m[0, 0, :]).sum())) for m in masks]
+        assert [tuple(v) for v in got] == want, (hw, got, want)
+
+
 @pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
 def test_matcher_heads(builtin, tag):
     g = golden("matcher_%s.npz" % tag)
