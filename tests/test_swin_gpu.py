@@ -122,13 +122,59 @@ def test_swin_end_to_end_clip_vs_oracle(gemm_mode, hw):
     insts, id_count = model.batch_inference([{"image": im, "height": hw[0], "width": hw[1]} for im in images], 0, 0, [], tc)
     insts = model._remove_short_track(insts)
     res = model.batch_postprocess(insts, [hw] * len(insts))
-    assert int(id_count) == int(o_count)
+    dump = [(f, res[f]["instances"].track_ids.cpu().tolist(), o_res[f]["instances"]["track_ids"].tolist(),
+             res[f]["instances"].scores.cpu().tolist(), o_res[f]["instances"]["scores"].tolist())
+            for f in range(len(images))]
+    assert int(id_count) == int(o_count), dump
     total = 0
     for f in range(len(images)):
         r, o = res[f]["instances"], o_res[f]["instances"]
-        assert r.track_ids.cpu().tolist() == o["track_ids"].tolist(), f
+        assert r.track_ids.cpu().tolist() == o["track_ids"].tolist(), dump
         assert r.recs.cpu().tolist() == o["recs"].tolist(), f
         assert float((r.bd.cpu() - o["bd"]).abs().max()) <= 1e-3 if len(r) else True
         assert float((r.scores.cpu() - o["scores"]).abs().max()) <= 1e-4 if len(r) else True
         total += len(r)
     assert total > 0
+
+
+@pytest.mark.parametrize("backbone", ["build_resnet_backbone", "build_swin_backbone"])
+def test_no_kernel_reads_uninitialised_memory(backbone, monkeypatch):
+    """Every scratch / output buffer of the path comes from `torch.empty`.  Poison those allocations with NaN (floats) and
+    a large sentinel (integers): the results must stay bit-identical to the unpoisoned run, at a frame size that leaves
+    ragged tiles, padded windows and odd maps everywhere."""
+    from helpers import mini_cfg
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.synth import make_clip
+    cfg = mini_cfg("icdar15", device=DEV)
+    cfg.MODEL.BACKBONE.NAME = backbone
+    sd = synth_state_dict(cfg, seed=7, cls_bias={"detection_transformer.ctrl_point_class.0.bias": 0.8,
+                                                  "roi_heads.rescoring_head.bias": 0.8})
+    hw = (90, 130)
+    clip = make_clip(6, hw[0], hw[1], clip_id=2)
+    images = [torch.as_tensor(f.astype("float32").transpose(2, 0, 1)) for f in clip]
+
+    def run():
+        model = GoMatching(cfg, sd, device=DEV, frames_per_step=3)
+        model.use_graphs = False
+        tc = {k: 0.0 for k in ("pre_process", "backbone", "detector", "rescore", "tracker", "short_match", "long_match",
+                               "post_process", "total_time")}
+        insts, idc = model.batch_inference([{"image": im, "height": hw[0], "width": hw[1]} for im in images], 0, 0, [], tc)
+        return [(i.track_ids.cpu(), i.bd.cpu(), i.scores.cpu(), i.recs.cpu()) for i in insts], int(idc)
+
+    clean, clean_count = run()
+    real_empty, real_like = torch.empty, torch.empty_like
+
+    def poison(x):
+        if x.is_cuda:
+            x.fill_(float("nan") if x.is_floating_point() else (1 << 30 if x.dtype in (torch.int32, torch.int64) else 1))
+        return x
+
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: poison(real_empty(*a, **k)))
+    monkeypatch.setattr(torch, "empty_like", lambda *a, **k: poison(real_like(*a, **k)))
+    dirty, dirty_count = run()
+    monkeypatch.undo()
+    assert dirty_count == clean_count
+    assert sum(len(c[0]) for c in clean) > 0
+    for f, (c, d) in enumerate(zip(clean, dirty)):
+        for a, b, name in zip(c, d, ("track_ids", "bd", "scores", "recs")):
+            assert torch.equal(a, b), (f, name)
