@@ -51,6 +51,7 @@ _DEFAULTS = {
         "PIXEL_STD": [58.395, 57.120, 57.375],
         "BACKBONE": {"NAME": "build_resnet_backbone"},
         "SWIN": {"TYPE": "tiny", "DROP_PATH_RATE": 0.2},
+        "ViTAEv2": {"TYPE": "vitaev2_s", "DROP_PATH_RATE": 0.2},
         "RESNETS": {"DEPTH": 50, "STRIDE_IN_1X1": False, "OUT_FEATURES": ["res3", "res4", "res5"]},
         "TRANSFORMER": {
             "ENABLED": True, "INFERENCE_TH_TEST": 0.4, "AUX_LOSS": True,

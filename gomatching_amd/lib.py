@@ -82,6 +82,14 @@ SIGNATURES = {
     "gom_swin_window_scatter_add_f32": (I, [P, P, P, I, I, I, I, I, P]),
     "gom_swin_patch_merge_f32": (I, [P, P, I, I, I, I, P]),
     "gom_swin_window_attention_f32": (I, [P, P, P, P, L, I, I, I, P]),
+    "gom_im2col_nhwc_f32": (I, [P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "gom_grouped_conv3x3_nhwc_f32": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
+    "gom_silu_f32": (I, [P, L, P]),
+    "gom_vitae_window_gather_f32": (I, [P, P, I, I, I, I, P]),
+    "gom_vitae_window_crop_f32": (I, [P, P, P, P, I, I, I, I, P]),
+    "gom_vitae_window_attention_f32": (I, [P, P, L, I, I, P]),
+    "gom_softmax_rows_scaled_f32": (I, [P, L, I, L, F, P]),
+    "gom_transpose_f32": (I, [P, P, I, I, L, L, P]),
     "gom_match_workspace_floats": (L, [I, I, I, I]),
     "gom_match_scores_f32": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
     "gom_linear_sum_assignment": (I, [ctypes.POINTER(ctypes.c_double), L, L, ctypes.POINTER(c_long),

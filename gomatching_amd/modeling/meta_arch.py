@@ -23,6 +23,7 @@ from ..structures import Boxes, Instances
 from ..weights import normalize_state_dict
 from .backbone import ResNet50
 from .swin import SwinTiny
+from .vitae import ViTAEv2S
 from .deepsolo import DeepSolo
 from .roi_heads import build_roi_heads
 
@@ -36,8 +37,8 @@ class GoMatching:
         if self.device.type != "cuda":
             raise RuntimeError("gomatching_amd runs on an MI355X only (MODEL.DEVICE=%s); there is no CPU path" %
                                cfg.MODEL.DEVICE)
-        if cfg.MODEL.BACKBONE.NAME not in ("build_resnet_backbone", "build_swin_backbone"):
-            raise NotImplementedError("backbone %s is not built (R-50 and Swin-T are; SURVEY.md §8-f3)"
+        if cfg.MODEL.BACKBONE.NAME not in ("build_resnet_backbone", "build_swin_backbone", "build_vitaev2_backbone"):
+            raise NotImplementedError("backbone %s is not built (R-50, Swin-T and ViTAEv2-S are; SURVEY.md §8-f3)"
                                       % cfg.MODEL.BACKBONE.NAME)
         V = cfg.VIDEO_TEST
         self.test_len = cfg.INPUT.VIDEO.TEST_LEN
@@ -53,6 +54,8 @@ class GoMatching:
         self.test_score_threshold = cfg.MODEL.TRANSFORMER.INFERENCE_TH_TEST
         self.min_size_test = None          # only set for the ViTAE backbone in the reference (:144-146)
         self.max_size_test = None
+        if cfg.MODEL.BACKBONE.NAME == "build_vitaev2_backbone":
+            self.min_size_test, self.max_size_test = cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST
         self.pixel_mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
         self.pixel_std = [float(v) for v in cfg.MODEL.PIXEL_STD]
         self.frames_per_step = frames_per_step
@@ -66,6 +69,10 @@ class GoMatching:
             if cfg.MODEL.SWIN.TYPE != "tiny":
                 raise NotImplementedError("only Swin-T is built (detection_transformer_wobackbone.py:61-64)")
             self.backbone = SwinTiny(sd, self.device)
+        elif cfg.MODEL.BACKBONE.NAME == "build_vitaev2_backbone":
+            if cfg.MODEL.ViTAEv2.TYPE != "vitaev2_s":
+                raise NotImplementedError("only vitaev2_s exists (detection_transformer_wobackbone.py:64-68)")
+            self.backbone = ViTAEv2S(sd, self.device)
         else:
             self.backbone = ResNet50(sd, self.device)
         self.feature_names = self.backbone.out_features
@@ -707,13 +714,24 @@ class GoMatching:
         return instances
 
     def batch_postprocess(self, instances, image_sizes):
-        """gom_lstmatcher.py:353-364 + detector_postprocess :78-111 (non-ViTAE branch): scale ctrl_points and
+        """gom_lstmatcher.py:353-364 + detector_postprocess :78-111 (both branches): scale ctrl_points and
         bd to the original frame size; pred_boxes stay in network-input pixels.  Frames that share the scale factors
         (a whole video normally) are scaled by ONE kernel per field over their concatenated rows."""
         groups = {}
         for i, (r, image_size) in enumerate(zip(instances, image_sizes)):
-            key = (image_size[1] / r.image_size[1], image_size[0] / r.image_size[0], r.has("ctrl_points"),
-                   r.has("pred_boxes") and not isinstance(r.bd, list))
+            sx, sy = image_size[1] / r.image_size[1], image_size[0] / r.image_size[0]
+            if self.min_size_test and self.max_size_test:
+                # ViTAE branch (:82-96): the network input was padded, so the scale comes from the resize rule
+                # (ResizeShortestEdge re-derived from the output size), not from the padded tensor's shape
+                oh, ow = image_size
+                size = self.min_size_test * 1.0
+                k = self.min_size_test / min(ow, oh)
+                newh, neww = (size, k * ow) if oh < ow else (k * oh, size)
+                if max(newh, neww) > self.max_size_test:
+                    k = self.max_size_test * 1.0 / max(newh, neww)
+                    newh, neww = newh * k, neww * k
+                sx, sy = ow / int(neww + 0.5), oh / int(newh + 0.5)
+            key = (sx, sy, r.has("ctrl_points"), r.has("pred_boxes") and not isinstance(r.bd, list))
             groups.setdefault(key, []).append(i)
         for (sx, sy, has_ctrl, has_bd), idxs in groups.items():
             for field, on in (("ctrl_points", has_ctrl), ("bd", has_bd)):

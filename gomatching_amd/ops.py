@@ -717,6 +717,85 @@ def swin_window_attention(qkv, bias, mask, windows_per_image, heads):
     return out
 
 
+# ------------------------------------------------------------------------------------------ ViTAEv2 glue
+def im2col(x, KH, KW, stride, pad, dilation, ldo):
+    """[B,H,W,C] -> ([B*OH*OW, ldo], OH, OW): columns (kh, kw, c), zeros beyond KH*KW*C."""
+    _chk_f32(x)
+    B, H, W, C = x.shape
+    OH = (H + 2 * pad - dilation * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dilation * (KW - 1) - 1) // stride + 1
+    out = torch.empty((B * OH * OW, ldo), dtype=_f32, device=x.device)
+    check(_L().gom_im2col_nhwc_f32(_p(x), _p(out), B, H, W, C, KH, KW, stride, pad, dilation, ldo, _stream()),
+          "gom_im2col_nhwc_f32")
+    return out, OH, OW
+
+
+def grouped_conv3x3(x, w, scale, shift, groups, stride=1, silu=False, R=None):
+    """x [B,H,W,Cin], w [Cout,3,3,Cin/groups] -> [B,OH,OW,Cout] = act(conv*scale + shift) + R (padding 1)."""
+    _chk_f32(x, w, scale, shift, R)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    assert w.shape[1:] == (3, 3, Cin // groups)
+    y = torch.empty((B, (H - 1) // stride + 1, (W - 1) // stride + 1, Cout), dtype=_f32, device=x.device)
+    if R is not None:
+        assert R.numel() == y.numel()
+    check(_L().gom_grouped_conv3x3_nhwc_f32(_p(x), _p(w), _p(scale), _p(shift), _p(R), 3 if silu else 0, _p(y), B, H, W,
+                                            Cin, Cout, groups, stride, _stream()), "gom_grouped_conv3x3_nhwc_f32")
+    return y
+
+
+def silu_(x):
+    _chk_f32(x)
+    check(_L().gom_silu_f32(_p(x), x.numel(), _stream()), "gom_silu_f32")
+    return x
+
+
+def vitae_window_gather(x, B, H, W):
+    """tokens [B*H*W, C] -> window rows [B*nW*49, C] over the centred zero-padded grid."""
+    _chk_f32(x)
+    C = x.shape[-1]
+    Hp, Wp = -(-H // 7) * 7, -(-W // 7) * 7
+    out = torch.empty((B * Hp * Wp, C), dtype=_f32, device=x.device)
+    check(_L().gom_vitae_window_gather_f32(_p(x), _p(out), B, H, W, C, _stream()), "gom_vitae_window_gather_f32")
+    return out
+
+
+def vitae_window_crop(windows, B, H, W, R1=None, R2=None):
+    """window rows -> tokens [B*H*W, C] (+ R1 + R2)."""
+    _chk_f32(windows, R1, R2)
+    C = windows.shape[-1]
+    out = torch.empty((B * H * W, C), dtype=_f32, device=windows.device)
+    check(_L().gom_vitae_window_crop_f32(_p(windows), _p(R1), _p(R2), _p(out), B, H, W, C, _stream()),
+          "gom_vitae_window_crop_f32")
+    return out
+
+
+def vitae_window_attention(qkv, heads):
+    _chk_f32(qkv)
+    C = qkv.shape[1] // 3
+    out = torch.empty((qkv.shape[0], C), dtype=_f32, device=qkv.device)
+    check(_L().gom_vitae_window_attention_f32(_p(qkv), _p(out), qkv.shape[0] // 49, heads, C, _stream()),
+          "gom_vitae_window_attention_f32")
+    return out
+
+
+def softmax_rows_scaled_(x, cols, scale):
+    """In place over the first `cols` columns of a 2-D row-strided view."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == _f32
+    check(_L().gom_softmax_rows_scaled_f32(_p(x), x.shape[0], cols, x.stride(0), float(scale), _stream()),
+          "gom_softmax_rows_scaled_f32")
+    return x
+
+
+def transpose_into(x, out):
+    """out[c, r] = x[r, c] for 2-D row-strided views (out may be wider than x has rows)."""
+    assert x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1
+    assert out.shape[0] == x.shape[1] and out.shape[1] >= x.shape[0]
+    check(_L().gom_transpose_f32(_p(x), _p(out), x.shape[0], x.shape[1], x.stride(0), out.stride(0), _stream()),
+          "gom_transpose_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ tracker
 def gather_rows(src, rows):
     n, D = rows.numel(), src.shape[1]

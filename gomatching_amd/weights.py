@@ -68,6 +68,64 @@ def _swin_keys(prefix="backbone.0.backbone."):
     return keys
 
 
+VITAEV2_S = {"embed": (64, 64, 128, 256), "token": (64, 128, 256, 512), "ratios": (4, 2, 2, 2), "kernel": (7, 3, 3, 3),
+             "dilations": ((1, 2, 3, 4), (1, 2, 3), (1, 2), (1, 2)), "rc_heads": (1, 1, 2, 4), "nc_heads": (1, 2, 4, 8),
+             "rc_group": (1, 16, 32, 64), "nc_group": (1, 32, 64, 128), "nc_depth": (2, 2, 8, 2),
+             "tokens_type": ("window", "window", "transformer", "transformer"), "window": 7, "mlp_ratio": 4}
+
+
+def _bn(keys, name, c):
+    for leaf in ("weight", "bias", "running_mean", "running_var"):
+        keys[name + "." + leaf] = (c,)
+
+
+def _gconv(keys, name, cout, cin, groups, k=3):
+    keys[name + ".weight"] = (cout, cin // groups, k, k)
+    keys[name + ".bias"] = (cout,)
+
+
+def _vitae_keys(prefix="backbone.0.backbone."):
+    """ViTAEv2-S as `build_vitaev2_backbone` builds it (vitae_v2.py:228-249): per stage one ReductionCell
+    (ReductionCell.py:66-131) and NC_depth NormalCells (NormalCell.py:113-153)."""
+    V = VITAEV2_S
+    keys = {}
+    cin = 3
+    for i in range(4):
+        E, T = V["embed"][i], V["token"][i]
+        p = prefix + "layers.%d.RC." % i
+        for j in range(len(V["dilations"][i])):
+            keys[p + "PRM.convs.%d.0.weight" % j] = (E, cin, V["kernel"][i], V["kernel"][i])
+            keys[p + "PRM.convs.%d.0.bias" % j] = (E,)
+        g = V["rc_group"][i]
+        _gconv(keys, p + "PCM.0", E, cin, g); _bn(keys, p + "PCM.1", E)
+        _gconv(keys, p + "PCM.3", E, E, g); _bn(keys, p + "PCM.4", E)
+        _gconv(keys, p + "PCM.6", T, E, g)
+        D = E * len(V["dilations"][i])                      # op='cat'
+        _ln(keys, p + "attn.norm1", D)
+        _lin(keys, p + "attn.attn.qkv", 3 * T, D)
+        if V["tokens_type"][i] == "transformer":            # Token_transformer's Attention: qkv_bias=False (:12)
+            del keys[p + "attn.attn.qkv.bias"]
+        _lin(keys, p + "attn.attn.proj", T, T)
+        _ln(keys, p + "attn.norm2", T)
+        _lin(keys, p + "attn.mlp.fc1", T, T)                # ReductionCell's mlp_ratio is its default 1.0
+        _lin(keys, p + "attn.mlp.fc2", T, T)
+        g = V["nc_group"][i]
+        Hd = T * V["mlp_ratio"]
+        for b in range(V["nc_depth"][i]):
+            p = prefix + "layers.%d.NC.%d." % (i, b)
+            _ln(keys, p + "norm1", T)
+            _lin(keys, p + "attn.qkv", 3 * T, T)
+            _lin(keys, p + "attn.proj", T, T)
+            _ln(keys, p + "norm2", T)
+            _lin(keys, p + "mlp.fc1", Hd, T)
+            _lin(keys, p + "mlp.fc2", T, Hd)
+            _gconv(keys, p + "PCM.0", Hd, T, g); _bn(keys, p + "PCM.1", Hd)
+            _gconv(keys, p + "PCM.3", T, Hd, g); _bn(keys, p + "PCM.4", T)
+            _gconv(keys, p + "PCM.6", T, T, g)
+        cin = T
+    return keys
+
+
 def backbone_channels(cfg):
     """Channel table of detection_transformer_wobackbone.py:59-70."""
     name = cfg.MODEL.BACKBONE.NAME
@@ -75,6 +133,10 @@ def backbone_channels(cfg):
         return [192, 384, 768]
     if name == "build_resnet_backbone":
         return [512, 1024, 2048]
+    if name == "build_vitaev2_backbone":
+        if cfg.MODEL.ViTAEv2.TYPE != "vitaev2_s":
+            raise NotImplementedError("only vitaev2_s exists (detection_transformer_wobackbone.py:64-68)")
+        return [128, 256, 512]
     raise NotImplementedError("backbone %s is not built (SURVEY.md §8-f3)" % name)
 
 
@@ -196,7 +258,9 @@ def _roi_head_keys(cfg, prefix="roi_heads."):
 
 def canonical_keys(cfg):
     keys = {}
-    keys.update(_swin_keys() if cfg.MODEL.BACKBONE.NAME == "build_swin_backbone" else _resnet_keys())
+    name = cfg.MODEL.BACKBONE.NAME
+    keys.update(_swin_keys() if name == "build_swin_backbone" else _vitae_keys() if name == "build_vitaev2_backbone"
+                else _resnet_keys())
     keys.update(_deepsolo_keys(cfg))
     keys.update(_roi_head_keys(cfg))
     return keys
@@ -216,6 +280,7 @@ def synth_state_dict(cfg, seed=0, cls_bias=None, as_torch=True):
     are degenerate for inference (zero-initialised last layers, prior-probability biases), which
     get small random values so that every stage of the path does observable work."""
     heads = cfg.MODEL.TRANSFORMER.NHEADS
+    vitae = cfg.MODEL.BACKBONE.NAME == "build_vitaev2_backbone"
     sd = {}
     for name, shape in canonical_keys(cfg).items():
         leaf = name.rsplit(".", 1)[-1]
@@ -226,6 +291,14 @@ def synth_state_dict(cfg, seed=0, cls_bias=None, as_torch=True):
                 v = 1.0 + _uniform(name, seed, shape, 0.2)
             else:
                 v = _uniform(name, seed, shape, 0.05)
+        elif leaf == "running_var":                          # BatchNorm2d buffers outside the FrozenBN naming (ViTAE PCM)
+            v = 1.0 + _uniform(name, seed, shape, 0.2)
+        elif vitae and name.startswith("backbone.") and len(shape) == 4:
+            # nn.Conv2d's own default (kaiming_uniform(a=sqrt(5)) = U(+-1/sqrt(fan_in))): ViTAE has no output norms, the
+            # hotter initialiser used for the FrozenBN R-50 would grow its activations by 100x per stage
+            v = _uniform(name, seed, shape, 1.0 / math.sqrt(shape[1] * shape[2] * shape[3]))
+        elif vitae and name.startswith("backbone.") and len(shape) == 2:
+            v = _uniform(name, seed, shape, 0.02 * math.sqrt(3.0))      # trunc_normal_(std=.02), vitae_v2.py:196
         elif len(shape) == 4:  # conv: kaiming-uniform over fan_in (keeps post-ReLU scale ~stationary)
             fan_in = shape[1] * shape[2] * shape[3]
             v = _uniform(name, seed, shape, math.sqrt(6.0 / fan_in))

@@ -267,6 +267,31 @@ int gom_swin_patch_merge_f32(const float* x, float* out, int B, int H, int W, in
 int gom_swin_window_attention_f32(const float* qkv, float* out, const float* bias, const float* mask, long num_windows,
                                   int windows_per_image, int heads, int C, void* stream);
 
+/* ---- f3: ViTAEv2-S backbone glue (third_party/adet/modeling/vitae_v2/) ----------------------------------------------
+ * Linear layers, dense convolutions and the two products of the full attention use the GEMM entry points above. */
+/* x [B,H,W,C] -> rows [B*OH*OW, ldo], columns (kh, kw, c) then zeros up to ldo: feeds the dilated strided convolutions
+ * of the pyramid reduction module (PRM, ReductionCell.py:27-34,55-62) to a GEMM.  C % 4 == 0, ldo % 4 == 0. */
+int gom_im2col_nhwc_f32(const float* x, float* out, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
+                        int dilation, int ldo, void* stream);
+/* grouped 3x3 convolution, padding 1 (PCM, ReductionCell.py:97-105 / NormalCell.py:137-145): w [Cout,3,3,Cin/groups]
+ * with Cin/groups in {4,16}; y = act(conv*scale + shift) + R; scale / R may be NULL; act 0 none, 3 SiLU. */
+int gom_grouped_conv3x3_nhwc_f32(const float* x, const float* w, const float* scale, const float* shift, const float* R,
+                                 int act, float* y, int B, int H, int W, int Cin, int Cout, int groups, int stride,
+                                 void* stream);
+int gom_silu_f32(float* x, long n, void* stream);                                         /* in place, n % 4 == 0 */
+/* centred zero padding to multiples of 7 + window_partition, and window_reverse + crop (+ up to two addends of the token
+ * shape, NULL to skip) (ReductionCell.py:147-163, NormalCell.py:160-211). */
+int gom_vitae_window_gather_f32(const float* x, float* out, int B, int H, int W, int C, void* stream);
+int gom_vitae_window_crop_f32(const float* windows, const float* R1, const float* R2, float* out, int B, int H, int W, int C,
+                              void* stream);
+/* WindowAttention core without position bias / mask (window.py:92-124): qkv [num_windows*49, 3C] -> out
+ * [num_windows*49, C]; head_dim C/heads in {64,128}. */
+int gom_vitae_window_attention_f32(const float* qkv, float* out, long num_windows, int heads, int C, void* stream);
+/* in place x[r, :cols] = softmax(x[r, :cols] * scale), cols <= 8192 (full attention, NormalCell.py:52-54). */
+int gom_softmax_rows_scaled_f32(float* x, long rows, int cols, long ld, float scale, void* stream);
+/* out[c*ldo + r] = x[r*ld + c]. */
+int gom_transpose_f32(const float* x, float* out, int rows, int cols, long ld, long ldo, void* stream);
+
 /* ---- A14/A15: tracker ---------------------------------------------------------------------------------*/
 int gom_gather_rows_f32(const float* src, const int* rows, float* out, int n, int dim, void* stream);
 /* per-frame softmax with an appended zero logit (lstmatcher.py:373-381); frame_offsets [num_frames+1] int32. */

@@ -676,11 +676,21 @@ def remove_short_track(cfg, instances):
     return [inst.select(ids[k] >= 0) for k, inst in enumerate(instances)]
 
 
-def batch_postprocess(instances, image_sizes):
-    """gom_lstmatcher.py:353-364 + :78-111 (non-ViTAE branch): scale ctrl_points and bd, not pred_boxes."""
+def batch_postprocess(instances, image_sizes, min_size=None, max_size=None):
+    """gom_lstmatcher.py:353-364 + :78-111: scale ctrl_points and bd, not pred_boxes.  min_size / max_size are only set
+    for the ViTAE backbone (:144-146): the scale then comes from the resize rule, not from the (padded) tensor shape."""
     out = []
     for r, (height, width) in zip(instances, image_sizes):
-        sx, sy = width / r.image_size[1], height / r.image_size[0]
+        if min_size and max_size:
+            size = min_size * 1.0
+            k = min_size / min(width, height)
+            newh, neww = (size, k * width) if height < width else (k * height, size)
+            if max(newh, neww) > max_size:
+                k = max_size * 1.0 / max(newh, neww)
+                newh, neww = newh * k, neww * k
+            sx, sy = width / int(neww + 0.5), height / int(newh + 0.5)
+        else:
+            sx, sy = width / r.image_size[1], height / r.image_size[0]
         r["ctrl_points"][:, 0::2] *= sx
         r["ctrl_points"][:, 1::2] *= sy
         r["bd"][..., 0::2] *= sx
@@ -702,6 +712,10 @@ def detect_frames(sd, cfg, images, taps=None):
     if cfg.MODEL.BACKBONE.NAME == "build_swin_backbone":
         from oracle.swin_oracle import swin_tiny
         feats = swin_tiny(x, sd)
+        feats = [feats[k] for k in ("stage3", "stage4", "stage5")]
+    elif cfg.MODEL.BACKBONE.NAME == "build_vitaev2_backbone":
+        from oracle.vitae_oracle import vitae_v2_s
+        feats = vitae_v2_s(x, sd)
         feats = [feats[k] for k in ("stage3", "stage4", "stage5")]
     else:
         feats = resnet50(x, sd)
@@ -732,4 +746,6 @@ def run_clip(sd, cfg, images, orig_hw=None):
         if cfg.VIDEO_TEST.MIN_TRACK_LEN > 0:
             instances = remove_short_track(cfg, instances)
         hw = orig_hw if orig_hw is not None else (images[0].shape[-2], images[0].shape[-1])
-        return batch_postprocess(instances, [hw] * len(instances)), id_count
+        vitae = cfg.MODEL.BACKBONE.NAME == "build_vitaev2_backbone"
+        return batch_postprocess(instances, [hw] * len(instances), cfg.INPUT.MIN_SIZE_TEST if vitae else None,
+                                 cfg.INPUT.MAX_SIZE_TEST if vitae else None), id_count
