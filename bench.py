@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backbone", default="r50", choices=["r50", "swin"],
+    ap.add_argument("--backbone", default="r50", choices=["r50", "swin", "vitae"],
                     help="r50 = BASELINE.json's workload; swin = side measurement of the Swin-T backbone (§8-f3) on the "
                          "same frames (not the BASELINE workload)")
     ap.add_argument("--emulate-world", type=int, default=1,
@@ -150,6 +150,10 @@ def main():
     src_hw = SRC_HW
     if args.backbone == "swin":
         cfg.MODEL.BACKBONE.NAME = "build_swin_backbone"        # same frames and resize as the R-50 workload
+    if args.backbone == "vitae":
+        cfg.MODEL.BACKBONE.NAME = "build_vitaev2_backbone"
+        src_hw = (1024, 1792)                                  # ViTAE needs multiples of 32 (the reference asserts): frames
+        cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 1024, 2000     # arrive at network size, the resize is a no-op
     model, sd = build_model(cfg, device)
     predictor = GoMBatchPredictor(cfg, model)
 
@@ -250,8 +254,9 @@ def main():
                                 "100 queries, GoMatching_ICDAR15 (R-50 + DeepSolo + LSTMatcher, rescoring), "
                                 "random-init synthetic weights" % (net_hw[0], net_hw[1], FRAMES_PER_GPU))
                    if args.backbone == "r50" else
-                   ("NOT the BASELINE workload: Swin-T backbone side measurement, %dx%d net input, %d frames/GPU, 100 "
-                    "queries, DeepSolo + LSTMatcher, random-init synthetic weights" % (net_hw[0], net_hw[1], FRAMES_PER_GPU)),
+                   ("NOT the BASELINE workload: %s backbone side measurement, %dx%d net input, %d frames/GPU, 100 "
+                    "queries, DeepSolo + LSTMatcher, random-init synthetic weights"
+                    % ({"swin": "Swin-T", "vitae": "ViTAEv2-S"}[args.backbone], net_hw[0], net_hw[1], FRAMES_PER_GPU)),
                    "frames_per_step": FRAMES_PER_GPU * world, "emulated_world": args.emulate_world, "pipelining": "detector(step i+1) overlaps tracker(step i)", "detector_hipgraph": graphed,
                    "parallelism": "frame-sharded dp%d + 1 all-gather/step"
                    % world if world > 1 else "single GPU",

@@ -125,16 +125,18 @@ class ViTAEv2S:
         S = self._zeros(("S", N), (N, Np))
         vt = self._zeros(("vt", N, hd), (hd, Np))
         out = torch.empty((B * N, C), dtype=_f32, device=self.device)
+        split = ops.GEMM_MODE in ("f16x3", "bf16x6") and N >= 33
         for b in range(B):
             rows = qkv[b * N:(b + 1) * N]
             for h in range(heads):
                 q = rows[:, h * hd:(h + 1) * hd]
                 k = rows[:, C + h * hd:C + (h + 1) * hd]
                 v = rows[:, 2 * C + h * hd:2 * C + (h + 1) * hd]
-                ops.gemm(q, k, out=S[:, :N])
+                # K and V^T are the "weight" operands of the two products: split at run time for the split back-ends
+                ops.gemm(q, ops.split_weight(k) if split else k, out=S[:, :N])
                 ops.softmax_rows_scaled_(S, N, hd ** -0.5)
                 ops.transpose_into(v, vt)
-                ops.gemm(S, vt, out=out[b * N:(b + 1) * N, h * hd:(h + 1) * hd])
+                ops.gemm(S, ops.split_weight(vt) if split else vt, out=out[b * N:(b + 1) * N, h * hd:(h + 1) * hd])
         return out
 
     def _window_attention(self, xn, B, H, W, qkv, heads):

@@ -78,18 +78,20 @@ class SplitWeight:
 
 
 def split_weight(w, conv_shape=None, kind=None):
-    """w: fp32 [N, K] (contiguous) on the GPU -> SplitWeight of the current GEMM_MODE's kind."""
-    _chk_f32(w)
+    """w: fp32 [N, K] on the GPU (rows may be strided: a column slice of a wider buffer, as the K / V operands of an
+    attention product are) -> SplitWeight of the current GEMM_MODE's kind."""
+    assert w.dim() == 2 and w.stride(1) == 1 and w.dtype == _f32 and w.is_cuda
     kind = kind or (GEMM_MODE if GEMM_MODE in ("bf16x6", "f16x3") else "bf16x6")
     N, K = w.shape
+    ldw = w.stride(0) if N > 1 else K
     Kpad = (K + 31) // 32 * 32
     if kind == "f16x3":
         planes = torch.empty((2, N, Kpad), dtype=torch.float16, device=w.device)
         inv = torch.empty((N,), dtype=_f32, device=w.device)
-        check(_L().gom_split_f16x2(_p(w), K, N, K, _p(planes), Kpad, _p(inv), _stream()), "gom_split_f16x2")
+        check(_L().gom_split_f16x2(_p(w), ldw, N, K, _p(planes), Kpad, _p(inv), _stream()), "gom_split_f16x2")
         return SplitWeight(planes, N, K, conv_shape, "f16x3", inv)
     planes = torch.empty((3, N, Kpad), dtype=torch.bfloat16, device=w.device)
-    check(_L().gom_split_bf16x3(_p(w), K, N, K, _p(planes), Kpad, _stream()), "gom_split_bf16x3")
+    check(_L().gom_split_bf16x3(_p(w), ldw, N, K, _p(planes), Kpad, _stream()), "gom_split_bf16x3")
     return SplitWeight(planes, N, K, conv_shape)
 
 

@@ -68,7 +68,7 @@ def test_dilated_convolution_through_im2col():
             Kp = -(-K // 32) * 32
             cols, oh, ow = ops.im2col(x.permute(0, 2, 3, 1).contiguous().to(DEV), k, k, s, pad, d, Kp)
             assert (oh, ow) == tuple(ref.shape[-2:])
-            assert float(cols[:, K:].abs().max()) == 0.0
+            assert Kp == K or float(cols[:, K:].abs().max()) == 0.0
             got = cols[:, :K].cpu() @ w.permute(0, 2, 3, 1).reshape(8, K).t()
             assert float((got.view(2, oh, ow, 8).permute(0, 3, 1, 2) - ref).abs().max()) <= 1e-4
 
