@@ -348,6 +348,23 @@ extern "C" int gom_zero_padded_tokens_f32(float* buf, int ld, int col0, int ncol
     return gom_launch_status();
 }
 
+// 32-bit word copy as a KERNEL: the tracker's per-match descriptor upload reads the pinned (device-mapped) staging buffer
+// with this instead of an async DMA, so that its ordering against the next kernel of the stream is plain kernel order.
+namespace {
+__global__ __launch_bounds__(256) void copy_words_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" int gom_copy_words(const void* src, void* dst, long n_words, void* stream) {
+    GOM_CHECK_ARG(src && dst && n_words >= 0);
+    if (n_words == 0) return GOM_OK;
+    hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)cdiv(n_words, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned*)src, (unsigned*)dst, n_words);
+    return gom_launch_status();
+}
+
 extern "C" int gom_add_f32(const float* a, const float* b, float* out, long n, void* stream) {
     GOM_CHECK_ARG(a && b && out && n >= 0 && (n % 4) == 0);
     if (n == 0) return GOM_OK;

@@ -59,6 +59,7 @@ SIGNATURES = {
     "gom_bezier_reference_points": (I, [P, P, P, P, I, P, P, I, L, I, I, I, P]),
     "gom_scale_xy_f32": (I, [P, L, F, F, P]),
     "gom_add_f32": (I, [P, P, P, L, P]),
+    "gom_copy_words": (I, [P, P, L, P]),
     "gom_broadcast_rows_f32": (I, [P, P, L, I, P]),
     "gom_topk_workspace_bytes": (L, [I, L, I]),
     "gom_topk_tokens": (I, [P, I, P, P, I, L, I, P, P, P, P]),

@@ -62,6 +62,9 @@ class GoMatching:
         self.use_graphs = use_graphs                             # hipGraph replay of the detector (see _detect_graphed)
         self._graphs = {}
         self.max_graphs = 2
+        # tracker descriptor uploads (see _h2d): "kernel" = a copy kernel reads the device-mapped pinned staging buffer, so
+        # the upload is ordered against the match kernels by plain kernel order; "dma" = async hipMemcpy; "sync" = dma + wait
+        self.h2d_mode = "kernel"
         self.training = False
 
         sd = normalize_state_dict(state_dict)
@@ -347,7 +350,11 @@ class GoMatching:
 
     def _h2d(self, arr):
         """numpy -> device through a pinned staging ring (a pageable copy costs ~40 us and stalls the stream; the
-        tracker issues one per match).  A slot is rewritten only after the event recorded behind its last copy."""
+        tracker issues one per match).  A slot is rewritten only after the event recorded behind its last copy.
+        The default moves the words with a kernel rather than the DMA engine: with the async-DMA form a rare (~3 % of
+        fresh processes, one build) run-to-run difference of the track ids was observed while the detector's hipGraph
+        replayed on the other stream -- detector outputs bit-identical, any change of timing made it disappear, root
+        cause not established ("tracker determinism").  The kernel form has no DMA-to-kernel hand-over."""
         arr = np.ascontiguousarray(arr)
         t = torch.from_numpy(arr)
         nbytes = arr.nbytes
@@ -364,7 +371,12 @@ class GoMatching:
             slot[1].synchronize()
         host = slot[0][:nbytes].view(t.dtype).view(t.shape)
         host.copy_(t)
-        dev = host.to(self.device, non_blocking=True)
+        if self.h2d_mode == "kernel" and nbytes % 4 == 0:
+            dev = ops.copy_words(host, torch.empty(t.shape, dtype=t.dtype, device=self.device))
+        else:
+            dev = host.to(self.device, non_blocking=True)
+            if self.h2d_mode == "sync":
+                torch.cuda.current_stream().synchronize()
         ev = torch.cuda.Event()
         ev.record()
         slot[1] = ev

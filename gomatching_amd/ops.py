@@ -595,6 +595,14 @@ def scale_xy_(x, sx, sy):
     return x
 
 
+def copy_words(src, dst):
+    """dst <- src over 32-bit words by a kernel (src: pinned host tensor or device tensor of the same byte size)."""
+    nbytes = src.numel() * src.element_size()
+    assert nbytes == dst.numel() * dst.element_size() and nbytes % 4 == 0 and src.is_contiguous() and dst.is_contiguous()
+    check(_L().gom_copy_words(src.data_ptr(), dst.data_ptr(), nbytes // 4, _stream()), "gom_copy_words")
+    return dst
+
+
 def add(a, b):
     _chk_f32(a, b)
     out = torch.empty_like(a)

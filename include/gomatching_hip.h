@@ -207,6 +207,8 @@ int gom_bezier_reference_points(const float* coord_raw, const int* topk_idx, con
 /* A18: in-place (x, y) pair scaling, detector_postprocess gom_lstmatcher.py:100-109. */
 int gom_scale_xy_f32(float* x, long n_pairs, float sx, float sy, void* stream);
 int gom_add_f32(const float* a, const float* b, float* out, long n, void* stream);
+/* dst[i] = src[i] over 32-bit words, as a kernel; src may be pinned host memory (device-mapped). */
+int gom_copy_words(const void* src, void* dst, long n_words, void* stream);
 int gom_broadcast_rows_f32(const float* src, float* out, long n, int B, void* stream);
 
 /* top-k token indices per batch element (deformable_transformer.py:188-190); idx_out [B,k] int32, sorted by

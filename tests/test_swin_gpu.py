@@ -137,11 +137,14 @@ def test_swin_end_to_end_clip_vs_oracle(gemm_mode, hw):
     assert total > 0
 
 
+@pytest.mark.parametrize("graphs", [False, True])
+@pytest.mark.parametrize("poison_value", [float("nan"), 1e30, -1e30])
 @pytest.mark.parametrize("backbone", ["build_resnet_backbone", "build_swin_backbone"])
-def test_no_kernel_reads_uninitialised_memory(backbone, monkeypatch):
+def test_no_kernel_reads_uninitialised_memory(backbone, poison_value, graphs, monkeypatch):
     """Every scratch / output buffer of the path comes from `torch.empty`.  Poison those allocations with NaN (floats) and
     a large sentinel (integers): the results must stay bit-identical to the unpoisoned run, at a frame size that leaves
-    ragged tiles, padded windows and odd maps everywhere."""
+    ragged tiles, padded windows and odd maps everywhere.  NaN catches arithmetic on stale memory, +-1e30 catches
+    comparisons (fmaxf drops a NaN)."""
     from helpers import mini_cfg
     from gomatching_amd.modeling import GoMatching
     from gomatching_amd.synth import make_clip
@@ -155,7 +158,7 @@ def test_no_kernel_reads_uninitialised_memory(backbone, monkeypatch):
 
     def run():
         model = GoMatching(cfg, sd, device=DEV, frames_per_step=3)
-        model.use_graphs = False
+        model.use_graphs = graphs                                # (a fill inside a capture becomes a memset node)
         tc = {k: 0.0 for k in ("pre_process", "backbone", "detector", "rescore", "tracker", "short_match", "long_match",
                                "post_process", "total_time")}
         insts, idc = model.batch_inference([{"image": im, "height": hw[0], "width": hw[1]} for im in images], 0, 0, [], tc)
@@ -166,7 +169,8 @@ def test_no_kernel_reads_uninitialised_memory(backbone, monkeypatch):
 
     def poison(x):
         if x.is_cuda:
-            x.fill_(float("nan") if x.is_floating_point() else (1 << 30 if x.dtype in (torch.int32, torch.int64) else 1))
+            big = poison_value if x.dtype in (torch.float32, torch.float64) else max(-6e4, min(6e4, poison_value))
+            x.fill_(big if x.is_floating_point() else (1 << 30 if x.dtype in (torch.int32, torch.int64) else 1))
         return x
 
     monkeypatch.setattr(torch, "empty", lambda *a, **k: poison(real_empty(*a, **k)))
