@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--backbone", default="r50", choices=["r50", "swin", "vitae"],
                     help="r50 = BASELINE.json's workload; swin = side measurement of the Swin-T backbone (§8-f3) on the "
                          "same frames (not the BASELINE workload)")
+    ap.add_argument("--h2d", default=None, choices=["kernel", "dma", "sync"],
+                    help="diagnostic: how the tracker uploads its per-match descriptors (GoMatching.h2d_mode)")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="N=1 diagnostic: run the replicated tracker over W copies of this GPU's records per step, i.e. "
                          "the tracker load of a W-GPU run, beside one GPU's detection (value still counts 8 frames/step)")
@@ -155,6 +157,8 @@ def main():
         src_hw = (1024, 1792)                                  # ViTAE needs multiples of 32 (the reference asserts): frames
         cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 1024, 2000     # arrive at network size, the resize is a no-op
     model, sd = build_model(cfg, device)
+    if args.h2d:
+        model.h2d_mode = args.h2d
     predictor = GoMBatchPredictor(cfg, model)
 
     # this rank's block of the clip: frames [rank*8, rank*8+8) of a world*8-frame synthetic video

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void msda_prep_kernel(const float* __restrict_
 // sampling-location arithmetic and the bilinear gather in ONE pass over the [Q, 384] offsets|logits rows, so
 // the [Q,8,4,4,2] locations and [Q,8,4,4] weights never exist in HBM (saves 3 x 457 MB of traffic per
 // encoder call at 8 x 37 171 tokens and one launch).  Same lane mapping as msda_fwd_kernel.
-template <int POINTS>
+template <int POINTS, bool HAS_VR>
 __global__ __launch_bounds__(256) void msda_fused_kernel(const float* __restrict__ value,
                                                          const int64_t* __restrict__ shapes,
                                                          const int64_t* __restrict__ lsi,
@@ -166,8 +166,9 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float* __restrict
             qx = fmaf(fmaf(-qx, Wf, ox), rW, qx);
             qy = fmaf(fmaf(-qy, Hf, oy), rH, qy);
             // padded batches: the reference point is scaled by the level's valid ratio first (deformable_transformer.py:
-            // 262-263 / 470-472); vr == nullptr is the unpadded case (ratios 1)
-            const float lx = (vr ? rx * vr[2 * l] : rx) + qx, ly = (vr ? ry * vr[2 * l + 1] : ry) + qy;
+            // 262-263 / 470-472); HAS_VR = false is the unpadded case (ratios 1): a
+            // compile-time switch, the run-time form of it cost the unpadded kernel 80 % (503 -> 919 us)
+            const float lx = (HAS_VR ? rx * vr[2 * l] : rx) + qx, ly = (HAS_VR ? ry * vr[2 * l + 1] : ry) + qy;
             const float w = e[i] * inv_sum;
             const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
             const bool inside = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
@@ -207,7 +208,7 @@ extern "C" int gom_msda_fused_forward(const float* raw, int ld_raw, const float*
     GOM_CHECK_ARG(value_row_stride >= HEADS * CH && (value_row_stride % 4) == 0 && (value_batch_stride % 4) == 0);
     GOM_CHECK_ARG(((uintptr_t)raw % 16) == 0 && ((uintptr_t)value % 16) == 0);
     const long nq = (long)batch * num_query;
-    hipLaunchKernelGGL((msda_fused_kernel<4>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
+    hipLaunchKernelGGL((msda_fused_kernel<4, false>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
                        spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
                        value_batch_stride, value_row_stride, (const float*)nullptr);
     return gom_launch_status();
@@ -221,7 +222,7 @@ extern "C" int gom_msda_fused_forward_vr(const float* raw, int ld_raw, const flo
     GOM_CHECK_ARG(batch > 0 && num_query > 0 && ld_raw >= HEADS * LEVELS * 4 * 3 && (ld_raw % 4) == 0);
     GOM_CHECK_ARG(value_row_stride >= HEADS * CH && (value_row_stride % 4) == 0 && (value_batch_stride % 4) == 0);
     const long nq = (long)batch * num_query;
-    hipLaunchKernelGGL((msda_fused_kernel<4>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
+    hipLaunchKernelGGL((msda_fused_kernel<4, true>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
                        spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
                        value_batch_stride, value_row_stride, valid_ratios);
     return gom_launch_status();
