@@ -91,6 +91,7 @@ SIGNATURES = {
     "gom_vitae_window_attention_f32": (I, [P, P, L, I, I, P]),
     "gom_softmax_rows_scaled_f32": (I, [P, L, I, L, F, P]),
     "gom_transpose_f32": (I, [P, P, I, I, L, L, P]),
+    "gom_flash_attention_f32": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
     "gom_match_workspace_floats": (L, [I, I, I, I]),
     "gom_match_scores_f32": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
     "gom_linear_sum_assignment": (I, [ctypes.POINTER(ctypes.c_double), L, L, ctypes.POINTER(c_long),

@@ -91,6 +91,7 @@ class ViTAEv2S:
                                 "nc_heads": V["nc_heads"][i]})
             cin = T
         self._scratch = {}
+        self.flash = True      # full attention through the fused kernel under the f16x3 back-end (else: GEMM pair + softmax)
 
     # ------------------------------------------------------------------------------------------------------------
     def _pcm(self, x, layers, groups, strides, R=None):
@@ -117,10 +118,13 @@ class ViTAEv2S:
         return buf
 
     def _full_attention(self, qkv, B, N, heads):
-        """softmax(q k^T / sqrt(hd)) v per (image, head): two GEMM launches around a row softmax.  The score matrix is
-        [N, ceil4(N)] fp32 (205 MB at 64x112 tokens) and is reused across heads."""
+        """softmax(q k^T / sqrt(hd)) v per (image, head).  Default (f16x3 back-end): one fused launch for all images and
+        heads.  Otherwise two GEMM launches around a row softmax per (image, head); the score matrix is then
+        [N, ceil4(N)] fp32 (205 MB at 64x112 tokens), reused across heads."""
         C = qkv.shape[1] // 3
         hd = C // heads
+        if ops.GEMM_MODE == "f16x3" and self.flash:
+            return ops.flash_attention(qkv, B, N, heads)         # scores stay on the CU (attn_flash.hip)
         Np = -(-N // 4) * 4
         S = self._zeros(("S", N), (N, Np))
         vt = self._zeros(("vt", N, hd), (hd, Np))

@@ -806,6 +806,19 @@ def transpose_into(x, out):
     return out
 
 
+def flash_attention(qkv, B, N, heads):
+    """qkv [B*N, 3C] (q | k | v, heads contiguous inside each) -> [B*N, C]: full attention per (image, head), the score
+    matrix never leaves the CU (attn_flash.hip; f16x3 products)."""
+    _chk_f32(qkv)
+    assert qkv.dim() == 2 and qkv.is_contiguous() and qkv.shape[0] == B * N
+    C = qkv.shape[1] // 3
+    out = torch.empty((B * N, C), dtype=_f32, device=qkv.device)
+    f = qkv.view(-1)
+    check(_L().gom_flash_attention_f32(_p(f), _p(f[C:]), _p(f[2 * C:]), _p(out), B, N, heads, C // heads, 3 * C, C,
+                                       _p(range_flag(qkv.device)), _stream()), "gom_flash_attention_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ tracker
 def gather_rows(src, rows):
     n, D = rows.numel(), src.shape[1]

@@ -293,6 +293,13 @@ int gom_vitae_window_attention_f32(const float* qkv, float* out, long num_window
 int gom_softmax_rows_scaled_f32(float* x, long rows, int cols, long ld, float scale, void* stream);
 /* out[c*ldo + r] = x[r*ld + c]. */
 int gom_transpose_f32(const float* x, float* out, int rows, int cols, long ld, long ldo, void* stream);
+/* Full self-attention with the scores kept on the CU (NormalCell.py:46-58 / token_transformer.py:27-44):
+ * out[b*N + i, h*hd : (h+1)*hd] = softmax_j(q_i . k_j / sqrt(hd)) v_j over the N tokens of image b, for every head h.
+ * q, k, v point at column 0 of their first head inside row-strided fp32 buffers (row stride ld, e.g. a fused qkv buffer
+ * with q = qkv, k = qkv + C, v = qkv + 2C); hd in {64, 128}; products on the fp16 matrix cores with the f16x3 split
+ * (operands within +-65504; a non-finite output sets *flag, which may be NULL). */
+int gom_flash_attention_f32(const float* q, const float* k, const float* v, float* out, int batch, int N, int heads,
+                            int head_dim, int ld, int ldo, int* flag, void* stream);
 
 /* ---- A14/A15: tracker ---------------------------------------------------------------------------------*/
 int gom_gather_rows_f32(const float* src, const int* rows, float* out, int n, int dim, void* stream);

@@ -141,6 +141,37 @@ def test_row_softmax_and_transpose():
     assert torch.equal(out[:, :50].cpu(), x[:, 64:128].t().cpu()) and float(out[:, 50:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("heads,hd", [(2, 64), (4, 64), (2, 128)])
+@pytest.mark.parametrize("N", [15, 48, 64, 200, 1000])
+def test_flash_attention_vs_torch(heads, hd, N):
+    """softmax(q k^T / sqrt(hd)) v with the scores kept on the CU against torch fp64 -> fp32, ragged N (tail key tiles,
+    tail query blocks), two images."""
+    from gomatching_amd import ops
+    g = torch.Generator().manual_seed(N + hd)
+    B, C = 2, heads * hd
+    qkv = torch.randn(B * N, 3 * C, generator=g)
+    qkv[:, :C] *= 2.0                                            # scores with a real spread
+    q, k, v = qkv.double().view(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(B * N, C).float()
+    got = ops.flash_attention(qkv.to(DEV), B, N, heads).cpu()
+    assert float((got - ref).abs().max()) <= 2e-5, float((got - ref).abs().max())
+    ops.check_range_flag(DEV)
+
+
+def test_flash_and_gemm_pair_attention_agree():
+    from gomatching_amd.modeling.vitae import ViTAEv2S
+    g = golden("vitae_s.npz")
+    net = ViTAEv2S(_sd(), torch.device(DEV))
+    x = torch.from_numpy(g["x_a"])
+    x4 = torch.cat([x.permute(0, 2, 3, 1), x.new_zeros(x.shape[0], x.shape[2], x.shape[3], 1)], -1).contiguous().to(DEV)
+    a = net.forward(x4)
+    net.flash = False
+    b = net.forward(x4)
+    for k in a:
+        assert float((a[k] - b[k]).abs().max()) <= 1e-4, k
+
+
 def test_vitae_end_to_end_clip_vs_oracle(gemm_mode):
     """The whole path with the ViTAEv2-S backbone on a 6-frame 96x128 clip against the CPU oracle: identical ids and
     characters, points within 1e-3 px; the ViTAE-specific post-process scale (gom_lstmatcher.py:82-96) included."""
