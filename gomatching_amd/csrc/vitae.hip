@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
     *reinterpret_cast<f32x4*>(out + i * 4) = v;
 }
 
-// ---- grouped 3x3 convolution, padding 1, NHWC, weights [Cout][3][3][CG] (CG = Cin / groups input channels per group);
+// ---- grouped 3x3 convolution, padding 1, NHWC, weights [3][3][Cout][CG] (CG = Cin / groups input channels per group);
 // y = act(conv * scale + shift) [+ R].  One thread per (pixel, output channel): neighbouring threads share the group's
 // input pixels (broadcast in the vector cache) and write coalesced.
 template <int CG>
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_kernel(const float* __res
     const int oy = (int)(r % OH);
     const long b = r / OH;
     const int g = co / cout_g;
-    const float* wr = w + (long)co * 9 * CG;
+    const float* wr = w + (long)co * CG;                      // [3][3][Cout][CG]: a wave's lanes read contiguous weights
     float acc = 0.f;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_kernel(const float* __res
             const int ix = ox * stride - 1 + kw;
             if (ix < 0 || ix >= W) continue;
             const float* xp = x + ((b * H + iy) * W + ix) * Cin + g * CG;
-            const float* wp = wr + (kh * 3 + kw) * CG;
+            const float* wp = wr + (long)(kh * 3 + kw) * Cout * CG;
 #pragma unroll
             for (int c = 0; c < CG; c += 4) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(xp + c), q = *reinterpret_cast<const f32x4*>(wp + c);

@@ -52,7 +52,7 @@ class ViTAEv2S:
                         w = torch.cat([w, w.new_zeros(w.shape[:-1] + (cin_pad - w.shape[-1],))], -1)
                     wd = ops.prep_conv_weight(w.contiguous().to(device))
                 else:
-                    wd = w.contiguous().to(device)
+                    wd = w.permute(1, 2, 0, 3).contiguous().to(device)                          # [3,3,Cout,Cin/groups]
                 layers.append((wd, None if scale is None else scale.contiguous().to(device), shift.contiguous().to(device)))
                 cin_pad = None
             return layers

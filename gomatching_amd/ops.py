@@ -741,11 +741,12 @@ def im2col(x, KH, KW, stride, pad, dilation, ldo):
 
 
 def grouped_conv3x3(x, w, scale, shift, groups, stride=1, silu=False, R=None):
-    """x [B,H,W,Cin], w [Cout,3,3,Cin/groups] -> [B,OH,OW,Cout] = act(conv*scale + shift) + R (padding 1)."""
+    """x [B,H,W,Cin], w [3,3,Cout,Cin/groups] (tap-major: a wave's lanes read contiguous weights) -> [B,OH,OW,Cout] =
+    act(conv*scale + shift) + R (padding 1)."""
     _chk_f32(x, w, scale, shift, R)
     B, H, W, Cin = x.shape
-    Cout = w.shape[0]
-    assert w.shape[1:] == (3, 3, Cin // groups)
+    Cout = w.shape[2]
+    assert w.shape == (3, 3, Cout, Cin // groups)
     y = torch.empty((B, (H - 1) // stride + 1, (W - 1) // stride + 1, Cout), dtype=_f32, device=x.device)
     if R is not None:
         assert R.numel() == y.numel()

@@ -275,7 +275,7 @@ int gom_swin_window_attention_f32(const float* qkv, float* out, const float* bia
  * of the pyramid reduction module (PRM, ReductionCell.py:27-34,55-62) to a GEMM.  C % 4 == 0, ldo % 4 == 0. */
 int gom_im2col_nhwc_f32(const float* x, float* out, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
                         int dilation, int ldo, void* stream);
-/* grouped 3x3 convolution, padding 1 (PCM, ReductionCell.py:97-105 / NormalCell.py:137-145): w [Cout,3,3,Cin/groups]
+/* grouped 3x3 convolution, padding 1 (PCM, ReductionCell.py:97-105 / NormalCell.py:137-145): w [3,3,Cout,Cin/groups]
  * with Cin/groups in {4,16}; y = act(conv*scale + shift) + R; scale / R may be NULL; act 0 none, 3 SiLU. */
 int gom_grouped_conv3x3_nhwc_f32(const float* x, const float* w, const float* scale, const float* shift, const float* R,
                                  int act, float* y, int B, int H, int W, int Cin, int Cout, int groups, int stride,

@@ -84,7 +84,7 @@ def test_grouped_conv_bn_silu_vs_torch():
         conv = F.conv2d(x, w, None, stride, 1, 1, groups)
         ref = F.silu(conv * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
         xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
-        wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+        wd = w.permute(2, 3, 0, 1).contiguous().to(DEV)                       # [3,3,Cout,Cin/groups]
         got = ops.grouped_conv3x3(xd, wd, scale.to(DEV), shift.to(DEV), groups, stride=stride, silu=True)
         assert float((got.permute(0, 3, 1, 2).cpu() - ref).abs().max()) <= 1e-5
         R = torch.randn(ref.shape, generator=g)
