@@ -434,6 +434,8 @@ class GoMatching:
         """Shared arithmetic of run_short_term_match / run_long_term_match: returns (traj [n_k,M] numpy, unique ids
         [M], ids of the non-k selected detections).  `sels`: per-frame boolean masks, or their concatenation.  The
         bookkeeping runs on the window's concatenated host arrays (a handful of numpy calls whatever the window length)."""
+        prof = getattr(self, "_match_prof", None)                # diagnostic (tools/match_breakdown.py): seconds per phase
+        t_in = time.perf_counter() if prof is not None else 0.0
         T = len(window)
         hosts = [self._host(w) for w in window]
         lens = [len(w) for w in window]
@@ -469,13 +471,24 @@ class GoMatching:
             dec = np.power(np.float32(self.decay_time), (T - 2 - f_sel[not_k]).astype(np.float32)).astype(np.float32)
         # one packed host->device copy per match: rows | frame offsets | meta | boxes (f32 bits) | decay (f32 bits)
         parts = [rows, offs, meta, boxes.reshape(-1).view(np.int32)] + ([dec.view(np.int32)] if dec is not None else [])
+        t_host = time.perf_counter() if prof is not None else 0.0
         buf = self._h2d(np.concatenate(parts))
         o0 = len(rows); o1 = o0 + len(offs); o2 = o1 + len(meta); o3 = o2 + 4 * N
         traj = self.roi_heads.match_scores(self._pool, buf[:o0], buf[o0:o1], buf[o1:o2], buf[o2:o3].view(torch.float32),
                                            buf[o3:].view(torch.float32) if dec is not None else None, n_t, k,
                                            short_term, hw, M, self.with_iou,
                                            self.max_center_dist if not short_term else 0.0)
-        return traj.cpu().numpy(), uniq, ids
+        if prof is None:
+            return traj.cpu().numpy(), uniq, ids
+        t_issue = time.perf_counter()
+        out = traj.cpu().numpy()
+        t_done = time.perf_counter()
+        prof["host_prep"] += t_host - t_in
+        prof["issue"] += t_issue - t_host
+        prof["wait"] += t_done - t_issue
+        prof["matches"] += 1
+        prof["rows"] += N
+        return out, uniq, ids
 
     def _assign(self, traj, uniq, ids_nonk, n_k):
         """LSA on -traj + thresholding (gom_lstmatcher.py:447-453 / 549-555)."""

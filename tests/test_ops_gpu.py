@@ -62,6 +62,32 @@ def test_gemm_split_shapes(M, N, K, kind):
 
 
 @pytest.mark.parametrize("kind", ["f16x3", "bf16x6"])
+def test_gemm_split_operands_on_rounding_ties(kind):
+    """Operand values that sit EXACTLY on a rounding tie of the first plane (and whose residual is then exactly half a
+    unit, incl. the smallest normal fp16): the split must still be exact -- a scalar-convert version of the split lost the
+    low plane of such an element in the attention kernel (tools/flash_diag3.py).  Identity weights read the split back."""
+    ops = _ops()
+    import numpy as np
+    K = 256
+    g = np.random.default_rng(5)
+    rows = []
+    for e in range(-13, 6):                                       # binades 2^e .. 2^(e+1): fp16 ulp = 2^(e-10), bf16 2^(e-7)
+        ulp = 2.0 ** (e - (10 if kind == "f16x3" else 7))
+        m = g.integers(0, 1 << (10 if kind == "f16x3" else 7), size=K)
+        x = (2.0 ** e + m * ulp + 0.5 * ulp) * g.choice([-1.0, 1.0], size=K)      # half-way between two plane-0 values
+        rows.append(x.astype(np.float32))
+    A = torch.from_numpy(np.stack(rows))
+    assert torch.equal(A.double(), torch.from_numpy(np.stack(rows).astype(np.float64)))      # exactly representable
+    eye = torch.eye(K)
+    out = ops.gemm(A.to(DEV), ops.split_weight(eye.to(DEV), kind=kind)).cpu()
+    rel = ((out - A).abs() / A.abs()).max()
+    assert float(rel) <= 2.0 ** -21, float(rel)
+    out_w = ops.gemm(eye.to(DEV), ops.split_weight(A[:, :K].contiguous().to(DEV), kind=kind)).cpu()     # ties as WEIGHTS
+    rel_w = ((out_w.t() - A).abs() / A.abs()).max()
+    assert float(rel_w) <= 2.0 ** -21, float(rel_w)
+
+
+@pytest.mark.parametrize("kind", ["f16x3", "bf16x6"])
 def test_gemm_split_epilogue_gather_and_extremes(kind):
     ops = _ops()
     g = torch.Generator().manual_seed(13)

@@ -159,6 +159,26 @@ def test_flash_attention_vs_torch(heads, hd, N):
     ops.check_range_flag(DEV)
 
 
+def test_flash_attention_operands_on_rounding_ties():
+    """q, k, v values exactly half-way between two fp16 numbers (the case that cost a scalar split its low plane)."""
+    import numpy as np
+    from gomatching_amd import ops
+    rng = np.random.default_rng(11)
+    B, N, heads, hd = 1, 96, 2, 128
+    C = heads * hd
+
+    def ties(shape, e_lo, e_hi):
+        e = rng.integers(e_lo, e_hi, size=shape).astype(np.float64)
+        ulp = 2.0 ** (e - 10)
+        return ((2.0 ** e + rng.integers(0, 1024, size=shape) * ulp + 0.5 * ulp) * rng.choice([-1.0, 1.0], size=shape)).astype(np.float32)
+
+    qkv = torch.from_numpy(np.concatenate([ties((B * N, C), -4, -1), ties((B * N, C), -3, 1), ties((B * N, C), -6, 2)], 1))
+    q, k, v = qkv.double().view(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = (((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1) @ v).transpose(1, 2).reshape(B * N, C).float()
+    got = ops.flash_attention(qkv.to(DEV), B, N, heads).cpu()
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), float((got - ref).abs().max())
+
+
 def test_flash_and_gemm_pair_attention_agree():
     from gomatching_amd.modeling.vitae import ViTAEv2S
     g = golden("vitae_s.npz")
