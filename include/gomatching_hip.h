@@ -343,6 +343,18 @@ int gom_match_scores_f32(const float* pool, int ld_pool, const int* rows, const 
                          const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec, int n_dec, int d,
                          int heads, int ffn, float img_w, float img_h, int with_iou, float max_center_dist,
                          float* workspace, long workspace_floats, float* traj, void* stream);
+/* The same match as ONE persistent kernel (match_fused.hip): phases separated by grid-wide barriers instead of kernel
+ * boundaries -- a match then costs one launch instead of ~18 dependent ones.  Same arguments and workspace as
+ * gom_match_scores_f32 (the last 64 workspace floats hold the barrier word).  gom_match_fused_supported() tells whether a
+ * problem is inside its range (N <= 256 rows, head_dim 128, at most one encoder layer); outside it returns
+ * GOM_ERR_UNSUPPORTED and the caller uses gom_match_scores_f32. */
+int gom_match_fused_supported(int N, int n_k, int d, int heads, int n_enc, int n_dec);
+int gom_match_fused_set_grid(int workgroups);           /* [host] size of the persistent grid (default 16), 1..256 */
+int gom_match_scores_fused_f32(const float* pool, int ld_pool, const int* rows, const int* frame_offsets, const int* meta,
+                               const float* boxes, const float* decay, int N, int T, int lo, int hi, int num_tracks,
+                               const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec, int n_dec, int d,
+                               int heads, int ffn, float img_w, float img_h, int with_iou, float max_center_dist,
+                               float* workspace, long workspace_floats, float* traj, void* stream);
 /* [host] rectangular assignment, SciPy-compatible tie-breaking (gom_lstmatcher.py:447,549).  Returns the number
  * of assigned pairs (min(nr,nc)) or a negative error. */
 int gom_linear_sum_assignment(const double* cost, long nr, long nc, long* row_ind, long* col_ind);

@@ -126,14 +126,15 @@ def test_matcher_heads_golden(builtin, tag):
         _close(rh._activate_asso(logits, n_t), g["asso%d_out" % ci], 1e-4, "asso act")
 
 
-@pytest.fixture(params=["native", "python"])
+@pytest.fixture(params=["fused", "native", "python"])
 def matcher_runtime(request):
-    """The per-match device chain issued by the native runtime (one FFI call) or composed kernel by kernel in Python."""
+    """The per-match device chain as ONE persistent kernel (optional), issued kernel by kernel by the native runtime (one
+    FFI call; default), or composed kernel by kernel in Python."""
     from gomatching_amd import ops
-    old = ops.NATIVE_MATCHER
-    ops.NATIVE_MATCHER = request.param == "native"
+    old = ops.NATIVE_MATCHER, ops.FUSED_MATCHER
+    ops.NATIVE_MATCHER, ops.FUSED_MATCHER = request.param != "python", request.param == "fused"
     yield request.param
-    ops.NATIVE_MATCHER = old
+    ops.NATIVE_MATCHER, ops.FUSED_MATCHER = old
 
 
 @pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
@@ -256,15 +257,19 @@ def test_native_match_runtime_equals_python_composition(builtin, n_t, k):
     decay = (0.9 ** torch.arange(Np).float()).to(DEV)
     out = {}
     for short_term in (False, True):
-        for native in (True, False):
-            ops.NATIVE_MATCHER = native
+        for mode in ("fused", "native", "python"):
+            ops.NATIVE_MATCHER, ops.FUSED_MATCHER = mode != "python", mode == "fused"
             try:
-                out[native] = heads.match_scores(pool, rows, offs, meta, boxes, None if short_term else decay, n_t, k,
-                                                 short_term, (96, 128), M, True, 0.0 if short_term else 50.0)
+                out[mode] = heads.match_scores(pool, rows, offs, meta, boxes, None if short_term else decay, n_t, k,
+                                               short_term, (96, 128), M, True, 0.0 if short_term else 50.0)
             finally:
-                ops.NATIVE_MATCHER = True
-        assert out[True].shape == (n_k, M) and torch.isfinite(out[True]).all()
-        assert torch.equal(out[True], out[False])
+                ops.NATIVE_MATCHER, ops.FUSED_MATCHER = True, False
+        assert out["native"].shape == (n_k, M) and torch.isfinite(out["native"]).all()
+        assert torch.equal(out["native"], out["python"])
+        # the persistent one-kernel form (match_fused.hip, <= 256 rows) runs every linear layer on the fp32 FMA scheme:
+        # same values up to the summation order of the MFMA split-K kernel the chain uses for its larger products
+        assert out["fused"].shape == (n_k, M)
+        assert float((out["fused"] - out["native"]).abs().max()) <= 2e-5, float((out["fused"] - out["native"]).abs().max())
 
 
 @pytest.mark.parametrize("builtin", ["icdar15", "pp_dstext"])
