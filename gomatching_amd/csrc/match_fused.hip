@@ -45,40 +45,57 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target)
     __threadfence();                                             // acquire: drop what this CU cached of the other CUs' buffers
 }
 
-// C[M, Nout] = act(A[M, K] . W[Nout, K]^T + bias + R): one wave per (8 rows, column), as gemm_small_kernel
+// C[M, Nout] = act(A[M, K] . W[Nout, K]^T + bias + R): a wave owns CB columns x 8 rows per item -- the per-output arithmetic
+// of gemm_small_kernel (lane-strided fp32 FMA chains + a fixed butterfly), but CB weight rows stream at once and the 8
+// activation rows are loaded once for all of them, so that a persistent wave has 12 independent 16-byte loads in flight
+// per step instead of 9 (of which 8 hit the same few cache lines)
+constexpr int CB = 4;
 __device__ void linear_phase(const float* A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
                              const float* R, int ldr, int relu, float* C, int ldc, int M, int Nout, int K, int gw, int GW,
                              int lane) {
-    const int groups = (M + RM - 1) / RM;
-    for (long item = gw; item < (long)groups * Nout; item += GW) {
-        const int n = (int)(item % Nout), m0 = (int)(item / Nout) * RM;
-        const float* w = W + (size_t)n * ldw;
+    const int groups = (M + RM - 1) / RM, ncb = (Nout + CB - 1) / CB;
+    for (long item = gw; item < (long)groups * ncb; item += GW) {
+        const int n0 = (int)(item % ncb) * CB, m0 = (int)(item / ncb) * RM;
+        const float* w[CB];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) w[c] = W + (size_t)(n0 + c < Nout ? n0 + c : Nout - 1) * ldw;
         const float* a[RM];
 #pragma unroll
         for (int r = 0; r < RM; ++r) a[r] = A + (size_t)(m0 + r < M ? m0 + r : M - 1) * lda;
-        float acc[RM];
+        float acc[CB][RM];
 #pragma unroll
-        for (int r = 0; r < RM; ++r) acc[r] = 0.f;
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int r = 0; r < RM; ++r) acc[c][r] = 0.f;
+#pragma unroll 2
         for (int k = lane * 4; k < K; k += 256) {
-            const f32x4 y = *reinterpret_cast<const f32x4*>(w + k);
+            f32x4 y[CB], x[RM];
 #pragma unroll
-            for (int r = 0; r < RM; ++r) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(a[r] + k);
-                acc[r] = fmaf(x[0], y[0], acc[r]);
-                acc[r] = fmaf(x[1], y[1], acc[r]);
-                acc[r] = fmaf(x[2], y[2], acc[r]);
-                acc[r] = fmaf(x[3], y[3], acc[r]);
-            }
+            for (int c = 0; c < CB; ++c) y[c] = *reinterpret_cast<const f32x4*>(w[c] + k);
+#pragma unroll
+            for (int r = 0; r < RM; ++r) x[r] = *reinterpret_cast<const f32x4*>(a[r] + k);
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+#pragma unroll
+                for (int r = 0; r < RM; ++r) {
+                    acc[c][r] = fmaf(x[r][0], y[c][0], acc[c][r]);
+                    acc[c][r] = fmaf(x[r][1], y[c][1], acc[c][r]);
+                    acc[c][r] = fmaf(x[r][2], y[c][2], acc[c][r]);
+                    acc[c][r] = fmaf(x[r][3], y[c][3], acc[c][r]);
+                }
         }
 #pragma unroll
-        for (int r = 0; r < RM; ++r) acc[r] = wave_sum(acc[r]);
-        if (lane == 0) {
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int r = 0; r < RM; ++r) acc[c][r] = wave_sum(acc[c][r]);
+        if (lane < CB && n0 + lane < Nout) {                      // lane c stores column n0 + c
+            const int n = n0 + lane;
             const float sh = bias ? bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < RM; ++r) {
                 const int m = m0 + r;
                 if (m < M) {
-                    float v = acc[r] + sh;
+                    float v = (lane == 0 ? acc[0][r] : lane == 1 ? acc[1][r] : lane == 2 ? acc[2][r] : acc[3][r]) + sh;
                     if (R) v += R[(size_t)m * ldr + n];
                     C[(size_t)m * ldc + n] = relu ? fmaxf(v, 0.f) : v;
                 }
@@ -268,9 +285,9 @@ __global__ __launch_bounds__(256) void match_fused_kernel(const FusedArgs p) {
 }  // namespace
 
 // Workgroups of the persistent grid (all of them have to be resident before the first barrier opens).  Measured beside a
-// saturated GPU (tools/match_breakdown.py 8 <G>): 4 -> 8.0 ms per match, 8 -> 4.1, 16 -> 2.2, 32 -> 1.27, 64 -> 0.84 -- the
-// kernel is bound by its own per-wave latency (a wave walks its share of the weight rows one column at a time), not by
-// waiting for slots; the 18-kernel chain takes 0.43 ms.  Several columns per wave (more loads in flight) is the lever.
+// saturated GPU (tools/match_breakdown.py 8 <G>), one column per wave: 4 -> 8.0 ms per match, 8 -> 4.1, 16 -> 2.2, 32 -> 1.27,
+// 64 -> 0.84; with CB = 4 columns per wave: 32 -> 0.83, 64 -> 0.62, 128 -> 0.63.  The kernel is bound by its own per-wave
+// latency, not by waiting for slots; the 18-kernel chain takes 0.43 ms, so this form stays optional (ops.FUSED_MATCHER).
 static int g_fused_grid = 64;
 extern "C" int gom_match_fused_set_grid(int workgroups) {
     if (workgroups < 1 || workgroups > 256) return GOM_ERR_INVALID_ARG;

@@ -858,9 +858,9 @@ def short_term_pairs(tgt, memory, pairs, row_pair, boxes, img_w, img_h, with_iou
 
 
 # True: matches of <= 256 rows as ONE persistent kernel with grid-wide phases (match_fused.hip).  Correct (same tests as the
-# chain) but measured SLOWER beside a saturated GPU -- 840 us per match at 64 workgroups against 430 us for the 18-kernel
-# chain (fewer workgroups are slower still: each wave walks its share of the weight rows with little memory-level
-# parallelism, where the chain's kernels spread over every free wave slot of the chip) -- so it stays off.
+# chain) but measured SLOWER beside a saturated GPU -- 620 us per match at 64 workgroups (840 before four columns per wave)
+# against 430 us for the 18-kernel chain, whose kernels each spread over every free wave slot of the chip -- so it stays
+# off.
 FUSED_MATCHER = False
 NATIVE_MATCHER = True      # False: compose the match from per-kernel calls in Python (kept for the A/B parity test)
 
