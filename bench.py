@@ -66,12 +66,12 @@ def calibrate(model, inputs, frac=0.3):
     logit_thr = float(np.log(thr / (1 - thr)))
     T = model.cfg.MODEL.TRANSFORMER
     m = out["pred_logits"].view(T.NUM_QUERIES, T.NUM_POINTS).mean(1)
-    shift = logit_thr - float(torch.quantile(m, 1 - frac))
+    shift = logit_thr - float(torch.quantile(m, max(0.0, 1 - frac))) + (1.0 if frac >= 1.0 else 0.0)
     model.detection_transformer.ctrl_class[1].add_(shift)
     re_shift = None
     if model.with_rescore:
         r = model.roi_heads.rescoring_head(out["query_features"]).view(T.NUM_QUERIES, T.NUM_POINTS).mean(1)
-        re_shift = logit_thr - float(torch.quantile(r, 1 - frac * 0.6))
+        re_shift = logit_thr - float(torch.quantile(r, max(0.0, 1 - frac * 0.6)))
         model.roi_heads._rescoring[1].add_(re_shift)
     return shift, re_shift
 
@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--backbone", default="r50", choices=["r50", "swin", "vitae"],
                     help="r50 = BASELINE.json's workload; swin = side measurement of the Swin-T backbone (§8-f3) on the "
                          "same frames (not the BASELINE workload)")
+    ap.add_argument("--detect-frac", type=float, default=0.3,
+                    help="fraction of the queries the calibrated biases let through the score threshold (SURVEY.md §8-d: "
+                         "0.3 for the BASELINE workload; 1.0 = the tracker-stress variant, every query a detection before NMS)")
     ap.add_argument("--h2d", default=None, choices=["kernel", "dma", "sync"],
                     help="diagnostic: how the tracker uploads its per-match descriptors (GoMatching.h2d_mode)")
     ap.add_argument("--emulate-world", type=int, default=1,
@@ -170,7 +173,7 @@ def main():
     # every rank calibrates on the SAME frame (frame 0 of the clip) so that all ranks hold identical weights
     cal_inputs, _ = predictor.prepare([clip[0][:, :, ::-1]])
     cal_inputs = [dict(x, image=x["image"].to(device)) for x in cal_inputs]
-    shift, re_shift = calibrate(model, cal_inputs)
+    shift, re_shift = calibrate(model, cal_inputs, frac=args.detect_frac)
 
     from gomatching_amd.dist import exchange_and_track
     from gomatching_amd.predictor import ClipPipeline
@@ -264,6 +267,7 @@ def main():
                    "frames_per_step": FRAMES_PER_GPU * world, "emulated_world": args.emulate_world, "pipelining": "detector(step i+1) overlaps tracker(step i)", "detector_hipgraph": graphed,
                    "parallelism": "frame-sharded dp%d + 1 all-gather/step"
                    % world if world > 1 else "single GPU",
+                   "detect_frac": args.detect_frac,
                    "detections_per_frame": [len(r["instances"]) for r in res[:FRAMES_PER_GPU]],
                    "tracks": int(id_count)},
         "roofline": {"bound": "mfma", "kernel": PEAKS[args.gemm][0], "achieved": achieved,
