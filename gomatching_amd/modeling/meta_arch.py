@@ -65,6 +65,7 @@ class GoMatching:
         # tracker descriptor uploads (see _h2d): "kernel" = a copy kernel reads the device-mapped pinned staging buffer, so
         # the upload is ordered against the match kernels by plain kernel order; "dma" = async hipMemcpy; "sync" = dma + wait
         self.h2d_mode = "kernel"
+        self.pinned_d2h = True             # tracker scores land in pinned memory (see _d2h); False: Tensor.cpu()
         self.training = False
 
         sd = normalize_state_dict(state_dict)
@@ -286,7 +287,7 @@ class GoMatching:
         self._ensure_pool(n_total)
         row0 = self._pool_used
         if n_total:
-            rows_d = torch.from_numpy(rows.astype(np.int32)).to(self.device)
+            rows_d = self._h2d(rows.astype(np.int32))
             qf = out["query_features"].view(B * nq, P * T.HIDDEN_DIM)
             # split-K always: a row's embedding then never depends on how many detections share the launch
             x = ops.gemm(qf, self.roi_heads.fcs[0][0], bias=self.roi_heads.fcs[0][1], rows=rows_d, relu=True,
@@ -381,6 +382,30 @@ class GoMatching:
         ev.record()
         slot[1] = ev
         return dev
+
+    def _d2h(self, t):
+        """device tensor -> numpy through a pinned landing ring + one event wait: the tracker's scores never travel through
+        the runtime's pageable staging (which it would share with whatever pageable upload the caller's frames are doing on
+        the detector stream at that moment)."""
+        if not self.pinned_d2h:
+            return t.cpu().numpy()
+        t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        if nbytes == 0:
+            return t.cpu().numpy()
+        ring = getattr(self, "_land_ring", None)
+        if ring is None or ring[0].numel() < nbytes:
+            cap = max(1 << 16, 2 * nbytes)
+            ring = [torch.empty((cap,), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self._land_ring, self._land_next = ring, 0
+        slot = ring[self._land_next]
+        self._land_next = (self._land_next + 1) % len(ring)
+        host = slot[:nbytes].view(t.dtype).view(t.shape)
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ev.synchronize()
+        return host.numpy().copy()
 
     def _reid_rows(self, inst, sel):
         """Pool rows of the selected detections of one frame (re-homes foreign features into the pool)."""
@@ -479,9 +504,9 @@ class GoMatching:
                                            short_term, hw, M, self.with_iou,
                                            self.max_center_dist if not short_term else 0.0)
         if prof is None:
-            return traj.cpu().numpy(), uniq, ids
+            return self._d2h(traj), uniq, ids
         t_issue = time.perf_counter()
-        out = traj.cpu().numpy()
+        out = self._d2h(traj)
         t_done = time.perf_counter()
         prof["host_prep"] += t_host - t_in
         prof["issue"] += t_issue - t_host
@@ -518,11 +543,11 @@ class GoMatching:
             off += n_prev + n_cur
         if not pairs:
             return {}
-        rows_d = torch.from_numpy(np.concatenate(rows).astype(np.int32)).to(self.device)
-        boxes_d = torch.from_numpy(np.concatenate(boxes).astype(np.float32)).to(self.device)     # once per call: pageable
+        rows_d = self._h2d(np.concatenate(rows).astype(np.int32))
+        boxes_d = self._h2d(np.concatenate(boxes).astype(np.float32))
         src_all = ops.gather_rows(self._pool, rows_d)
-        scores = self.roi_heads.short_term_scores(src_all, pairs, boxes_d, frames[1].image_size)
-        flat = torch.cat([s.reshape(-1) for s in scores]).cpu().numpy()      # the one sync of the short-term path
+        scores = self.roi_heads.short_term_scores(src_all, pairs, boxes_d, frames[1].image_size, h2d=self._h2d)
+        flat = self._d2h(torch.cat([s.reshape(-1) for s in scores]))         # the one sync of the short-term path
         out, o = {}, 0
         for t, (_, n_prev, n_cur) in zip(which, pairs):
             out[t] = flat[o:o + n_cur * n_prev].reshape(n_cur, n_prev)

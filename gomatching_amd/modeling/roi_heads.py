@@ -193,7 +193,7 @@ class _MatcherBase:
         return ops.track_score(act, meta, decay, boxes, hw[1], hw[0], hi - lo, N - (hi - lo), num_tracks, with_iou,
                                max_center_dist)
 
-    def short_term_scores(self, src_all, pairs, boxes_all, image_size):
+    def short_term_scores(self, src_all, pairs, boxes_all, image_size, h2d=None):
         """For every (prev, cur) pair: S[i, j] = max(activated association of cur i with prev j, IoU(i, j)).
         Within one frame track ids are unique, so the reference's trajectory score of cur detection i for track m
         (gom_lstmatcher.py:429-445) is exactly S[i, j_m] with j_m the previous-frame detection carrying id m: the
@@ -216,7 +216,7 @@ class _MatcherBase:
                 s_off += n_cur * n_prev
             parts = [np.asarray(seg_enc, np.int32), np.asarray(seg_dec, np.int32), np.asarray(desc, np.int32),
                      np.concatenate(row_pair), np.concatenate(cur_rows)]
-            buf = torch.from_numpy(np.concatenate(parts)).to(self.device)
+            buf = h2d(np.concatenate(parts)) if h2d is not None else torch.from_numpy(np.concatenate(parts)).to(self.device)
             o = np.cumsum([0] + [len(p) for p in parts])
             seg = (buf[o[0]:o[1]], buf[o[1]:o[2]], buf[o[4]:o[5]], max(p[1] + p[2] for p in pairs),
                    max(p[2] for p in pairs))
@@ -240,7 +240,7 @@ class _MatcherBase:
             parts.append(p)
             where.append(o)
             o += len(p)
-        buf = torch.from_numpy(np.concatenate(parts)).to(self.device)
+        buf = h2d(np.concatenate(parts)) if h2d is not None else torch.from_numpy(np.concatenate(parts)).to(self.device)
         out = []
         for (off, n_prev, n_cur), lg, o in zip(pairs, logits, where):
             act = ops.asso_activate(lg, buf[o:o + 3], 2)

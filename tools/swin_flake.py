@@ -41,6 +41,10 @@ out = {}
 for hw in ((96, 128), (90, 130)):
     clip = make_clip(6, hw[0], hw[1], clip_id=2)
     images = [torch.as_tensor(f.astype("float32").transpose(2, 0, 1)) for f in clip]
+    if switch == "devinput":            # frames already in HBM: no pageable host->device staging beside the tracker's D2H copies
+        images = [im.to(DEV) for im in images]
+    if switch == "pininput":
+        images = [im.pin_memory() for im in images]
     model = GoMatching(cfg, sd, device=DEV, frames_per_step=3)
     if switch == "nograph":
         model.use_graphs = False
