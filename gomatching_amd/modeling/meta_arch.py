@@ -352,10 +352,9 @@ class GoMatching:
     def _h2d(self, arr):
         """numpy -> device through a pinned staging ring (a pageable copy costs ~40 us and stalls the stream; the
         tracker issues one per match).  A slot is rewritten only after the event recorded behind its last copy.
-        The default moves the words with a kernel rather than the DMA engine: with the async-DMA form a rare (~3 % of
-        fresh processes, one build) run-to-run difference of the track ids was observed while the detector's hipGraph
-        replayed on the other stream -- detector outputs bit-identical, any change of timing made it disappear, root
-        cause not established ("tracker determinism").  The kernel form has no DMA-to-kernel hand-over."""
+        The default moves the words with a kernel rather than the DMA engine (no DMA-to-kernel hand-over, same cost): a
+        hardening step after a rare run-to-run difference of the track ids was observed while the detector's hipGraph
+        replayed on the other stream -- not a proven fix, root cause not established ("Tracker determinism")."""
         arr = np.ascontiguousarray(arr)
         t = torch.from_numpy(arr)
         nbytes = arr.nbytes
