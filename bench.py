@@ -137,11 +137,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     import torch.distributed as dist
+    # GOM_BENCH_BACKEND=gloo is a dry-run aid only: several ranks share the one GPU of a test box and exchange through host
+    # memory, which exercises the whole N>1 code path except RCCL itself (the driver's multi-GPU runs use the default)
+    backend = os.environ.get("GOM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from gomatching_amd import ops
     from gomatching_amd.config import setup_cfg
@@ -225,7 +233,7 @@ def main():
     elapsed = time.time() - t0
     assert done == args.steps
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
