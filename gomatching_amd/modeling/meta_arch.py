@@ -669,6 +669,8 @@ class GoMatching:
     def track_frames(self, dets, batch_id, id_count, instances, time_cost, frame_offset=0):
         """The per-frame id recurrence of gom_lstmatcher.py:369-403 over already detected frames
         (`frame_offset` = number of this batch's frames already tracked by earlier calls)."""
+        if ops.NATIVE_TRACKER and len(dets):
+            return self._track_frames_native(dets, batch_id, id_count, instances, time_cost, frame_offset)
         start_frame_id = batch_id * 100 + frame_offset
         t0 = time.time()
         base = len(instances)
@@ -712,6 +714,79 @@ class GoMatching:
             self._defer_ids = False
         self._flush_ids(dets)
         return instances, id_count
+
+    def _track_frames_native(self, dets, batch_id, id_count, instances, time_cost, frame_offset):
+        """`track_frames` with the per-frame loop in native code (csrc/tracker_rt.hip): this method only gathers the host
+        mirrors of the window (carried frames + new ones), runs the batched short-term device work, and hands everything
+        over in ONE call; ids come back for all new frames."""
+        import ctypes
+        L = ops._L()
+        start = batch_id * 100 + frame_offset
+        t0 = time.time()
+        base = len(instances)
+        carried = list(instances[-max(self.test_len - 1, 1):]) if base else []
+        self._home_features(carried + list(dets))
+        st = self.precompute_short_term(([instances[-1]] if base else []) + list(dets))
+        shift = 1 if base else 0
+        window = carried + list(dets)
+        first_new = len(carried)
+        hosts = [self._host(w) for w in window]
+        n = np.asarray([len(w) for w in window], np.int32)
+        tot = int(n.sum())
+        boxes = np.ascontiguousarray(np.concatenate([h["boxes"].reshape(-1, 4) for h in hosts]) if tot
+                                     else np.zeros((0, 4)), dtype=np.float32)
+        rows = np.ascontiguousarray(np.concatenate([self._rows_full(w) for w in window]) if tot else np.zeros((0,)),
+                                    dtype=np.int32)
+        ids = np.full((tot,), -1, np.int64)
+        o = 0
+        for h, m in zip(hosts[:first_new], n[:first_new]):
+            ids[o:o + m] = h["ids"]
+            o += int(m)
+        s_off = np.full((len(window),), -1, np.int64)
+        chunks, so = [], 0
+        for j in range(len(dets)):
+            S = st.get(j + shift)
+            if S is not None:
+                s_off[first_new + j] = so
+                chunks.append(np.ascontiguousarray(S, dtype=np.float32).reshape(-1))
+                so += chunks[-1].size
+        S_all = np.concatenate(chunks) if chunks else np.zeros((1,), np.float32)
+        if getattr(self, "_ntrk", None) is None:
+            m = self.roi_heads._matcher(False)
+            self._ntrk = L.gom_tracker_create(self.test_len, float(self.overlap_thresh), 1 if self.not_mult_thresh else 0,
+                                              1 if self.decay_time > 0 else 0, 1 if self.with_iou else 0,
+                                              float(self.max_center_dist), m._enc_c, len(m.enc), m._dec_c, len(m.dec), m.d,
+                                              m.heads, m.ffn)
+            if not self._ntrk:
+                raise ops._lib_mod.GomError("gom_tracker_create failed")
+            self._decay_table = np.power(np.float32(self.decay_time if self.decay_time > 0 else 1.0),
+                                         np.arange(self.test_len + 1).astype(np.float32)).astype(np.float32)
+        idc = ctypes.c_long(int(id_count) if id_count else 0)
+        secs = (ctypes.c_double * 2)(0.0, 0.0)
+        hw = dets[0].image_size
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        time_cost["short_match"] += time.time() - t0
+        ops.check(L.gom_tracker_run(self._ntrk, len(window), ptr(n), ptr(boxes), ptr(rows), ptr(ids), first_new, start,
+                                    ptr(S_all), ptr(s_off), ctypes.c_void_p(self._pool.data_ptr()), self._pool.stride(0),
+                                    float(hw[1]), float(hw[0]), ptr(self._decay_table), ctypes.byref(idc), secs,
+                                    ops._stream()), "gom_tracker_run")
+        time_cost["short_match"] += secs[0]
+        time_cost["long_match"] += secs[1]
+        self._defer_ids = True
+        try:
+            o = int(n[:first_new].sum())
+            for j, d in enumerate(dets):
+                m = int(n[first_new + j])
+                self._set_ids(d, ids[o:o + m].copy())
+                o += m
+                instances.append(d)
+                real = start + j
+                if real - self.test_len >= 0:
+                    instances[real - self.test_len].remove("reid_features")
+        finally:
+            self._defer_ids = False
+        self._flush_ids(dets)
+        return instances, int(idc.value)
 
     def _remove_short_track(self, instances):
         """gom_lstmatcher.py:566-577.  The per-frame boolean indexing of the reference (seven index kernels and a

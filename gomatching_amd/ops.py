@@ -862,6 +862,7 @@ def short_term_pairs(tgt, memory, pairs, row_pair, boxes, img_w, img_h, with_iou
 # against 430 us for the 18-kernel chain, whose kernels each spread over every free wave slot of the chip -- so it stays
 # off.
 FUSED_MATCHER = False
+NATIVE_TRACKER = True      # the per-frame id recurrence of a track_frames call in native code (tracker_rt.hip); False: Python loop
 NATIVE_MATCHER = True      # False: compose the match from per-kernel calls in Python (kept for the A/B parity test)
 
 

@@ -355,6 +355,17 @@ int gom_match_scores_fused_f32(const float* pool, int ld_pool, const int* rows, 
                                const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec, int n_dec, int d,
                                int heads, int ffn, float img_w, float img_h, int with_iou, float max_center_dist,
                                float* workspace, long workspace_floats, float* traj, void* stream);
+/* [host + device] The per-frame id recurrence of GoMatching.track_frames for all frames of a call behind ONE crossing
+ * (tracker_rt.hip; gom_lstmatcher.py:366-564): short-term assignment from precomputed score matrices, long-term match
+ * (selection, descriptors, gom_match_scores_f32, LSA, thresholds, id allocation).  Host arrays in, ids out; see the
+ * comment above gom_tracker_run in tracker_rt.hip for the layout.  The handle owns its device / pinned scratch. */
+void* gom_tracker_create(int test_len, float overlap_thresh, int not_mult_thresh, int use_decay, int with_iou,
+                         float max_center_dist, const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec,
+                         int n_dec, int d, int heads, int ffn);
+void gom_tracker_destroy(void* tracker);
+int gom_tracker_run(void* tracker, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
+                    long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool, float img_w,
+                    float img_h, const float* decay_table, long* id_count_io, double* secs, void* stream);
 /* [host] rectangular assignment, SciPy-compatible tie-breaking (gom_lstmatcher.py:447,549).  Returns the number
  * of assigned pairs (min(nr,nc)) or a negative error. */
 int gom_linear_sum_assignment(const double* cost, long nr, long nc, long* row_ind, long* col_ind);

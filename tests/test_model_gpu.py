@@ -126,15 +126,17 @@ def test_matcher_heads_golden(builtin, tag):
         _close(rh._activate_asso(logits, n_t), g["asso%d_out" % ci], 1e-4, "asso act")
 
 
-@pytest.fixture(params=["fused", "native", "python"])
+@pytest.fixture(params=["tracker_rt", "fused", "native", "python"])
 def matcher_runtime(request):
-    """The per-match device chain as ONE persistent kernel (optional), issued kernel by kernel by the native runtime (one
-    FFI call; default), or composed kernel by kernel in Python."""
+    """tracker_rt: the whole per-frame recurrence in native code (default).  Otherwise the Python loop of `track_frames`
+    with the per-match device chain as ONE persistent kernel (fused), issued kernel by kernel by the native runtime (one
+    FFI call per match), or composed kernel by kernel in Python."""
     from gomatching_amd import ops
-    old = ops.NATIVE_MATCHER, ops.FUSED_MATCHER
+    old = ops.NATIVE_MATCHER, ops.FUSED_MATCHER, ops.NATIVE_TRACKER
+    ops.NATIVE_TRACKER = request.param == "tracker_rt"
     ops.NATIVE_MATCHER, ops.FUSED_MATCHER = request.param != "python", request.param == "fused"
     yield request.param
-    ops.NATIVE_MATCHER, ops.FUSED_MATCHER = old
+    ops.NATIVE_MATCHER, ops.FUSED_MATCHER, ops.NATIVE_TRACKER = old
 
 
 @pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
