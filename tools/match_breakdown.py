@@ -29,6 +29,8 @@ for name, key in (("_assign", "assign"), ("precompute_short_term", "short"), ("t
     setattr(G, name, wrap)
 
 import bench
+from gomatching_amd import ops as _ops0
+_ops0.NATIVE_TRACKER = False          # these tools dissect the PYTHON loop of track_frames (the native runtime is one opaque call)
 if len(sys.argv) > 2:
     from gomatching_amd import lib as _lib, ops as _ops
     if sys.argv[2] == "chain":

@@ -18,6 +18,8 @@ def wrapped(self, *a, **k):
 
 G.track_frames = wrapped
 import bench
+from gomatching_amd import ops as _ops0
+_ops0.NATIVE_TRACKER = False          # these tools dissect the PYTHON loop of track_frames (the native runtime is one opaque call)
 sys.argv = ["bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--emulate-world", sys.argv[1] if len(sys.argv) > 1 else "8"]
 bench.main()
 s = io.StringIO()
