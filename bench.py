@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--detect-frac", type=float, default=0.3,
                     help="fraction of the queries the calibrated biases let through the score threshold (SURVEY.md §8-d: "
                          "0.3 for the BASELINE workload; 1.0 = the tracker-stress variant, every query a detection before NMS)")
+    ap.add_argument("--fused-matcher", type=int, default=0,
+                    help="diagnostic: long-term matches through the persistent one-kernel matcher with this many workgroups")
     ap.add_argument("--h2d", default=None, choices=["kernel", "dma", "sync"],
                     help="diagnostic: how the tracker uploads its per-match descriptors (GoMatching.h2d_mode)")
     ap.add_argument("--emulate-world", type=int, default=1,
@@ -168,6 +170,11 @@ def main():
         src_hw = (1024, 1792)                                  # ViTAE needs multiples of 32 (the reference asserts): frames
         cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 1024, 2000     # arrive at network size, the resize is a no-op
     model, sd = build_model(cfg, device)
+    if args.fused_matcher:
+        from gomatching_amd import lib as _lib
+        _lib.load().gom_tracker_set_fused(1)
+        _lib.load().gom_match_fused_set_grid(args.fused_matcher)
+        ops.FUSED_MATCHER = True
     if args.h2d:
         model.h2d_mode = args.h2d
     predictor = GoMBatchPredictor(cfg, model)

@@ -98,6 +98,7 @@ SIGNATURES = {
     "gom_match_fused_supported": (I, [I, I, I, I, I, I]),
     "gom_tracker_create": (P, [I, F, I, I, I, F, P, I, P, I, I, I, I]),
     "gom_tracker_destroy": (None, [P]),
+    "gom_tracker_set_fused": (I, [I]),
     "gom_tracker_run": (I, [P, I, P, P, P, P, I, L, P, P, P, I, F, F, P, P, P, P]),
     "gom_match_fused_set_grid": (I, [I]),
     "gom_linear_sum_assignment": (I, [ctypes.POINTER(ctypes.c_double), L, L, ctypes.POINTER(c_long),

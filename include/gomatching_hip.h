@@ -363,6 +363,7 @@ void* gom_tracker_create(int test_len, float overlap_thresh, int not_mult_thresh
                          float max_center_dist, const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec,
                          int n_dec, int d, int heads, int ffn);
 void gom_tracker_destroy(void* tracker);
+int gom_tracker_set_fused(int on);      /* [host] long-term matches through gom_match_scores_fused_f32 when supported (default off) */
 int gom_tracker_run(void* tracker, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
                     long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool, float img_w,
                     float img_h, const float* decay_table, long* id_count_io, double* secs, void* stream);
