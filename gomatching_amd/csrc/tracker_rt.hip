@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -86,6 +88,7 @@ std::vector<long> sorted_unique(std::vector<long> v) {
     return v;
 }
 
+int g_double_check = -1;             // GOM_TRACKER_DOUBLE_CHECK=1: run every long-term chain twice and compare (diagnostic)
 int g_tracker_fused = 0;             // long-term matches through the persistent one-kernel matcher when it takes the problem
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -142,6 +145,10 @@ extern "C" int gom_tracker_run(void* handle, int F, const int* n, const float* b
     if (off[F] > 0 && (!boxes || !rows)) return GOM_ERR_INVALID_ARG;
     long id_count = *id_count_io;
     hipStream_t st = (hipStream_t)stream;
+    if (g_double_check < 0) {
+        const char* e = getenv("GOM_TRACKER_DOUBLE_CHECK");
+        g_double_check = (e && e[0] == '1') ? 1 : 0;
+    }
     std::vector<long> track_ids, uniq, ids_nonk, cur;
     for (int f = first_new; f < F; ++f) {
         const long real = first_real + (f - first_new);
@@ -268,6 +275,17 @@ extern "C" int gom_tracker_run(void* handle, int F, const int* n, const float* b
             if (rc != GOM_OK) return rc;
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+            if (g_double_check) {                                // diagnostic: the same chain again must give the same bits
+                std::vector<float> first(t->traj_pin, t->traj_pin + (size_t)n_k * M);
+                rc = chain(pool_dev, ld_pool, d_rows, d_offs, d_meta, d_boxes, d_decay, N, T, lo, lo + n_k, M, t->enc, t->n_enc,
+                           t->dec, t->n_dec, t->d, t->heads, t->ffn, img_w, img_h, t->with_iou, t->max_center_dist, t->ws_dev,
+                           nws, t->traj_dev, stream);
+                if (rc == GOM_OK) rc = gom_copy_words(t->traj_dev, t->traj_pin, (long)n_k * M, stream);
+                if (rc != GOM_OK) return rc;
+                if (hipStreamSynchronize(st) != hipSuccess) return GOM_ERR_HIP_BASE;
+                if (std::memcmp(first.data(), t->traj_pin, sizeof(float) * (size_t)n_k * M) != 0)
+                    fprintf(stderr, "TRAJ MISMATCH at frame %ld (N %d, n_k %d, M %d)\n", real, N, n_k, M);
+            }
             assign(*t, t->traj_pin, n_k, uniq, ids_nonk, new_ids);
         }
         for (int i = 0; i < n_k; ++i)

@@ -13,6 +13,7 @@ eval.py drive it unchanged.  What differs is the schedule:
     bookkeeping + assignment; its float arithmetic runs in HIP kernels.
 Training (`forward` returning losses) is out of scope and raises.
 """
+import os
 import time
 
 import numpy as np
@@ -545,8 +546,30 @@ class GoMatching:
         rows_d = self._h2d(np.concatenate(rows).astype(np.int32))
         boxes_d = self._h2d(np.concatenate(boxes).astype(np.float32))
         src_all = ops.gather_rows(self._pool, rows_d)
+        check = os.environ.get("GOM_TRACKER_DOUBLE_CHECK") == "1"
+        if check:
+            src_first, rows_first, boxes_first = src_all.clone(), rows_d.clone(), boxes_d.clone()
         scores = self.roi_heads.short_term_scores(src_all, pairs, boxes_d, frames[1].image_size, h2d=self._h2d)
         flat = self._d2h(torch.cat([s.reshape(-1) for s in scores]))         # the one sync of the short-term path
+        if check:                                                # diagnostic: were the inputs final when they were first read?
+            torch.cuda.current_stream().synchronize()
+            again = ops.gather_rows(self._pool, rows_d)
+            for name, a, b in (("SRC", src_first, again), ("ROWS", rows_first, rows_d), ("BOXES", boxes_first, boxes_d),
+                               ("SRC-vs-its-clone", src_first, src_all)):
+                if not torch.equal(a, b):
+                    print("%s MISMATCH in precompute_short_term: %d elements differ" % (name, int((a != b).sum())), flush=True)
+            runs = []
+            for _ in range(2):                                   # twice more with every stage of the matcher tapped
+                self.roi_heads._stage_taps = []
+                sc = self.roi_heads.short_term_scores(again, pairs, boxes_d, frames[1].image_size, h2d=self._h2d)
+                torch.cuda.current_stream().synchronize()
+                runs.append(self.roi_heads._stage_taps + [("S", torch.cat([s.reshape(-1) for s in sc]))])
+            self.roi_heads._stage_taps = None
+            for (name, a), (_, b) in zip(*runs):
+                if not torch.equal(a, b):
+                    print("FIRST IRREPRODUCIBLE STAGE: %s (%d of %d elements, max |d| %.3e; shape %s)" % (
+                        name, int((a != b).sum()), a.numel(), float((a - b).abs().max()), tuple(a.shape)), flush=True)
+                    break
         out, o = {}, 0
         for t, (_, n_prev, n_cur) in zip(which, pairs):
             out[t] = flat[o:o + n_cur * n_prev].reshape(n_cur, n_prev)
@@ -727,6 +750,12 @@ class GoMatching:
         carried = list(instances[-max(self.test_len - 1, 1):]) if base else []
         self._home_features(carried + list(dets))
         st = self.precompute_short_term(([instances[-1]] if base else []) + list(dets))
+        if os.environ.get("GOM_TRACKER_DOUBLE_CHECK") == "1":    # diagnostic: the same device work again, same bits?
+            st2 = self.precompute_short_term(([instances[-1]] if base else []) + list(dets))
+            for key in st:
+                if not np.array_equal(st[key], st2[key]):
+                    print("S MISMATCH pair %d (frame_offset %d): max |d| %.3e" % (key, frame_offset,
+                                                                                float(np.abs(st[key] - st2[key]).max())), flush=True)
         shift = 1 if base else 0
         window = carried + list(dets)
         first_new = len(carried)

@@ -170,7 +170,8 @@ def test_no_kernel_reads_uninitialised_memory(backbone, poison_value, graphs, mo
     def poison(x):
         if x.is_cuda:
             big = poison_value if x.dtype in (torch.float32, torch.float64) else max(-6e4, min(6e4, poison_value))
-            x.fill_(big if x.is_floating_point() else (1 << 30 if x.dtype in (torch.int32, torch.int64) else 1))
+            # byte buffers are the split-K workspaces (fp32 partial sums behind a uint8 tensor): 0xFF bytes read back as NaN
+            x.fill_(big if x.is_floating_point() else (1 << 30 if x.dtype in (torch.int32, torch.int64) else 255))
         return x
 
     monkeypatch.setattr(torch, "empty", lambda *a, **k: poison(real_empty(*a, **k)))
