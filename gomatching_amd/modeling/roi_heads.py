@@ -60,13 +60,9 @@ class _MatcherTransformer:
             qkv = ops.gemm(memory, L["in"][0], bias=L["in"][1], small=True)                       # [N, 3E]
             f = qkv.view(-1)
             a = self._attend(f, f[E:], f[2 * E:], 3 * E, 3 * E, N, N)
-            tap("enc.attn", a)
             memory = ops.gemm(a, L["out"][0], bias=L["out"][1], R=memory, small=True)
-            tap("enc.out", memory)
             h = ops.gemm(memory, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True)
-            tap("enc.lin1", h)
             memory = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=memory, small=True)
-            tap("enc.lin2", memory)
         tgt = src[lo:hi]                                     # tgt = src[query_inds] (transformer.py:80-84)
         M = hi - lo
         for L in self.dec:                                   # no decoder self-attention (transformer.py:270-294)
@@ -75,16 +71,14 @@ class _MatcherTransformer:
             kv = ops.gemm(memory, w[E:], bias=b[E:], small=True)                                  # [N, 2E]
             f = kv.view(-1)
             a = self._attend(q, f, f[E:], E, 2 * E, M, N)
-            tap("dec.attn", a)
             tgt = ops.gemm(a, L["out"][0], bias=L["out"][1], R=tgt, small=True)
-            tap("dec.out", tgt)
             if not self.only_crs:
                 h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True)
                 tgt = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt, small=True)
         return tgt, memory
 
 
-    def forward_pairs(self, src_all, pairs, seg=None, taps=None):
+    def forward_pairs(self, src_all, pairs, seg=None):
         """Batched forward over independent (previous frame, current frame) pairs -- the short-term matcher input
         depends only on the two frames' embeddings, never on track ids, so all pairs of a batch of frames share
         every GEMM (weights streamed once); the attention cores run as ONE ragged launch per layer when `seg` =
@@ -94,10 +88,8 @@ class _MatcherTransformer:
         E, H = self.d, self.heads
         Nall = src_all.shape[0]
         memory = src_all
-        tap = (lambda name, t: taps.append((name, t.clone()))) if taps is not None else (lambda name, t: None)
         for L in self.enc:
             qkv = ops.gemm(memory, L["in"][0], bias=L["in"][1], small=True)
-            tap("enc.qkv", qkv)
             a = torch.empty((Nall, E), dtype=_f32, device=src_all.device)
             if seg is not None:
                 f = qkv.view(-1)
@@ -125,7 +117,6 @@ class _MatcherTransformer:
             w, b = L["in"]
             q = ops.gemm(tgt, w[:E], bias=b[:E], small=True)
             kv = ops.gemm(memory, w[E:], bias=b[E:], small=True)
-            tap("dec.q", q); tap("dec.kv", kv)
             a = torch.empty((M, E), dtype=_f32, device=src_all.device)
             if seg is not None:
                 f = kv.view(-1)
@@ -229,7 +220,7 @@ class _MatcherBase:
             o = np.cumsum([0] + [len(p) for p in parts])
             seg = (buf[o[0]:o[1]], buf[o[1]:o[2]], buf[o[4]:o[5]], max(p[1] + p[2] for p in pairs),
                    max(p[2] for p in pairs))
-            tgt, memory, _ = self._matcher(True).forward_pairs(src_all, pairs, seg, taps=getattr(self, "_stage_taps", None))
+            tgt, memory, _ = self._matcher(True).forward_pairs(src_all, pairs, seg)
             S = ops.short_term_pairs(tgt, memory, buf[o[2]:o[3]], buf[o[3]:o[4]], boxes_all, image_size[1], image_size[0],
                                      self.cfg.VIDEO_TEST.WITH_IOU, cur_off, max_prev, s_off)
             out, s_off = [], 0
