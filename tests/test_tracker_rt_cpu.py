@@ -1,0 +1,137 @@
+"""Host logic of the native tracker runtime (csrc/tracker_rt.hip) without a GPU: frame-0 initialisation, frame-1 id
+allocation (the pre-increment quirk of gom_lstmatcher.py:379,458-459), the mapping of short-term score columns to track
+ids (stable argsort / sorted-unique), LSA + threshold, ids carried across calls -- on windows whose short-term matching
+leaves no detection unmatched, so that no long-term match (device work) is triggered.  Expected ids come from a numpy /
+SciPy restatement of GoMatching.run_short_term_match."""
+import ctypes
+
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment
+
+from gomatching_amd import lib as gom_lib
+
+
+def _expected(n, S_list, first_new, first_real, carried_ids, id_count, thresh=0.2):
+    ids = [np.asarray(x, np.int64) for x in carried_ids]
+    for f in range(first_new, len(n)):
+        real = first_real + (f - first_new)
+        if real == 0:
+            ids.append(np.arange(1, n[f] + 1, dtype=np.int64))
+            id_count = n[f] + 1
+            continue
+        prev = ids[f - 1]
+        uniq = np.unique(prev)
+        S = S_list[f]
+        traj = S[:, np.argsort(prev, kind="stable")] if S is not None else np.zeros((n[f], len(uniq)), np.float32)
+        out = np.full((n[f],), -1, np.int64)
+        if traj.size:
+            mi, mj = linear_sum_assignment(-traj.astype(np.float64))
+            for i, j in zip(mi, mj):
+                if traj[i, j] > np.float32(thresh):
+                    out[i] = uniq[j]
+        if real == 1:
+            for i in range(n[f]):
+                if out[i] < 0:
+                    id_count += 1
+                    out[i] = id_count
+        assert (out >= 0).all(), "the test window must not need a long-term match"
+        ids.append(out)
+    return ids, id_count
+
+
+def _run(L, n, S_list, first_new, first_real, carried_ids, id_count):
+    h = L.gom_tracker_create(6, 0.2, 1, 1, 1, 1.0, None, 0, None, 0, 1024, 8, 1024)
+    assert h
+    try:
+        n_arr = np.asarray(n, np.int32)
+        tot = int(n_arr.sum())
+        boxes = np.random.default_rng(0).random((tot, 4)).astype(np.float32)
+        rows = np.arange(tot, dtype=np.int32)
+        ids = np.full((tot,), -1, np.int64)
+        o = 0
+        for c in carried_ids:
+            ids[o:o + len(c)] = c
+            o += len(c)
+        s_off = np.full((len(n),), -1, np.int64)
+        chunks, so = [], 0
+        for f, S in enumerate(S_list):
+            if S is not None:
+                s_off[f] = so
+                chunks.append(np.ascontiguousarray(S, np.float32).reshape(-1))
+                so += chunks[-1].size
+        S_all = np.concatenate(chunks) if chunks else np.zeros((1,), np.float32)
+        decay = np.power(np.float32(0.9), np.arange(7).astype(np.float32)).astype(np.float32)
+        idc = ctypes.c_long(id_count)
+        secs = (ctypes.c_double * 2)(0.0, 0.0)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = L.gom_tracker_run(h, len(n), p(n_arr), p(boxes), p(rows), p(ids), first_new, first_real, p(S_all), p(s_off),
+                               None, 1024, 128.0, 96.0, p(decay), ctypes.byref(idc), secs, None)
+        assert rc == 0, rc
+        offs = np.concatenate([[0], np.cumsum(n_arr)])
+        return [ids[offs[f]:offs[f + 1]].copy() for f in range(len(n))], int(idc.value)
+    finally:
+        L.gom_tracker_destroy(h)
+
+
+def _scores(rng, n_cur, n_prev, strong=True):
+    """[n_cur, n_prev]: every current detection has one clear partner among the previous ones (n_cur <= n_prev)."""
+    S = (rng.random((n_cur, n_prev)) * 0.15).astype(np.float32)
+    if strong:
+        perm = rng.permutation(n_prev)[:n_cur]
+        S[np.arange(n_cur), perm] = (0.5 + 0.4 * rng.random(n_cur)).astype(np.float32)
+    return S
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_short_term_recurrence_from_frame_zero(seed):
+    L = gom_lib.load()
+    rng = np.random.default_rng(seed)
+    n0 = int(rng.integers(3, 9))
+    n = [n0, n0 + int(rng.integers(0, 4))]                      # frame 1 may have MORE detections: new ids are allocated
+    S_list = [None, _scores(rng, n[1], n[0], strong=False)]
+    S_list[1][:min(n), :min(n)] += np.eye(min(n), dtype=np.float32)[rng.permutation(min(n))] * 0.6
+    for _ in range(4):                                            # later frames: never more detections than before
+        n.append(int(rng.integers(1, n[-1] + 1)))
+        S_list.append(_scores(rng, n[-1], n[-2]))
+    want, want_count = _expected(n, S_list, 0, 0, [], 0)
+    got, got_count = _run(L, n, S_list, 0, 0, [], 0)
+    assert got_count == want_count
+    for f in range(len(n)):
+        assert got[f].tolist() == want[f].tolist(), (f, got[f], want[f])
+    assert want[1].max() >= n0 + 2 or n[1] == n0               # the id n0 + 1 is never issued (pre-increment quirk)
+
+
+def test_carried_frames_and_empty_frames():
+    L = gom_lib.load()
+    rng = np.random.default_rng(42)
+    carried = [np.array([7, 3, 12, 5], np.int64), np.array([12, 3, 7], np.int64)]     # two frames of an earlier call
+    n = [4, 3, 3, 0, 0, 2]
+    S_list = [None, None, _scores(rng, 3, 3), None, None, None]   # frame 3 empty: no matrix; frame 5 follows an empty frame
+    with pytest.raises(AssertionError):                           # ... whose detections can only be unmatched: needs the
+        _expected(n, S_list, 2, 250, carried, 40)                 # long-term matcher, outside this CPU test's scope
+    n, S_list = n[:5], S_list[:5]
+    want, want_count = _expected(n, S_list, 2, 250, carried, 40)
+    got, got_count = _run(L, n, S_list, 2, 250, carried, 40)
+    assert got_count == want_count == 40
+    assert [g.tolist() for g in got] == [w.tolist() for w in want]
+
+
+def test_rejects_bad_windows():
+    L = gom_lib.load()
+    h = L.gom_tracker_create(6, 0.2, 1, 1, 1, 1.0, None, 0, None, 0, 1024, 8, 1024)
+    try:
+        n = np.asarray([2, 2], np.int32)
+        ids = np.full((4,), -1, np.int64)
+        idc = ctypes.c_long(0)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        s_off = np.full((2,), -1, np.int64)
+        boxes, rows = np.zeros((4, 4), np.float32), np.zeros((4,), np.int32)
+        # frame 1 with both frames non-empty but no score matrix
+        rc = L.gom_tracker_run(h, 2, p(n), p(boxes), p(rows), p(ids), 0, 0, None, p(s_off), None, 1024, 1.0, 1.0, None,
+                               ctypes.byref(idc), None, None)
+        assert rc != 0
+        assert L.gom_tracker_run(None, 2, p(n), p(boxes), p(rows), p(ids), 0, 0, None, p(s_off), None, 1024, 1.0, 1.0, None,
+                                 ctypes.byref(idc), None, None) != 0
+    finally:
+        L.gom_tracker_destroy(h)
