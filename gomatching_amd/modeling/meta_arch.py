@@ -363,9 +363,13 @@ class GoMatching:
             return t.to(self.device)
         ring = getattr(self, "_pin_ring", None)
         if ring is None or ring[0][0].numel() < nbytes:
+            if ring is not None:                                 # the copy KERNELS still reading the old slots are invisible
+                for _, ev_old in ring:                           # to torch's host allocator: let them finish before the
+                    if ev_old is not None:                       # blocks go back to its free list
+                        ev_old.synchronize()
             cap = max(1 << 16, 2 * nbytes)
             ring = [[torch.empty((cap,), dtype=torch.uint8, pin_memory=True), None] for _ in range(4)]
-            self._pin_ring, self._pin_next = ring, 0            # old slots stay alive until their copies retire
+            self._pin_ring, self._pin_next = ring, 0
         slot = ring[self._pin_next]
         self._pin_next = (self._pin_next + 1) % len(ring)
         if slot[1] is not None:
