@@ -1,0 +1,115 @@
+"""Generate tests/golden/train_asso_*.npz by running the REFERENCE's own association head in training mode (container-only).
+
+TEST INFRASTRUCTURE.  Run in the build container, where /root/reference exists:
+
+    python -m oracle.gen_golden_train
+
+gomatching/modeling/roi_heads/{lstmatcher,shared_ffn_crsattn}.py are imported unmodified through oracle/ref_shim.py, built
+with the repo's synthetic weights and MODEL.ASSO_HEAD.DROPOUT = 0 (the only stochastic element of the training forward),
+put in train() mode, and `_forward_asso(proposals, targets)` is called on a synthetic 5-frame clip of drifting ground
+truth boxes with jittered proposals around them (+ false positives, a missed object, an empty frame).  Stored: the
+inputs, the two losses and, for four parameters, a strided sample of 4096 gradient entries + the gradient's abs-sum.  The restatement (oracle/train_oracle.py) is printed beside.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from helpers import mini_cfg                                     # noqa: E402
+from gomatching_amd.weights import synth_state_dict              # noqa: E402
+from oracle import gen_golden, ref_shim, train_oracle            # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+GRAD_KEYS = {"LSTMatcher": ["asso_head.fc2.weight", "long_term_matcher.decoder.layers.0.multihead_attn.in_proj_weight",
+                            "short_term_matcher.encoder.layers.0.linear1.weight", "long_term_matcher.encoder.layers.0.self_attn.out_proj.bias"],
+             "SHA_FFN_CRSATTN": ["asso_head.fc2.weight", "shared_matcher.decoder.layers.0.multihead_attn.in_proj_weight",
+                                 "asso_head.fc1.bias", "shared_matcher.decoder.layers.0.multihead_attn.out_proj.weight"]}
+
+
+def make_clip(seed, size=(96, 128), frames=5, nobj=6):
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(nobj, 2, generator=g) * torch.tensor([80.0, 50.0]) + 5
+    wh = torch.rand(nobj, 2, generator=g) * 18 + 10
+    vel = (torch.rand(nobj, 2, generator=g) - 0.5) * 5
+    props, targets = [], []
+    for t in range(frames):
+        alive = [o for o in range(nobj) if not (o == 2 and t == 3)]
+        if t == 2 and seed % 2:
+            alive = []                                           # an empty frame (no ground truth, no proposals)
+        gt = torch.stack([torch.cat([xy[o] + vel[o] * t, xy[o] + vel[o] * t + wh[o]]) for o in alive]) if alive else torch.zeros(0, 4)
+        ids = torch.tensor([o + 1 for o in alive], dtype=torch.long)
+        seen = [i for i, o in enumerate(alive) if not (o == 4 and t == 1)]           # one missed detection
+        pb = gt[seen] + (torch.rand(len(seen), 4, generator=g) - 0.5) * 3 if seen else torch.zeros(0, 4)
+        fp = torch.rand(2, 2, generator=g) * torch.tensor([90.0, 60.0])
+        pb = torch.cat([pb, torch.cat([fp, fp + 8], 1)]) if alive else pb          # two false positives
+        n = pb.shape[0]
+        perm = torch.randperm(n, generator=g)
+        props.append({"image_size": size, "proposal_boxes": pb[perm],
+                      "objectness_logits": torch.cat([torch.rand(n - 1, generator=g) * 0.5 + 0.4, torch.tensor([0.05])])[perm]
+                      if n else torch.zeros(0),
+                      "query_features": (torch.randn(n, 25, 256, generator=g) * 0.5).half().float()})      # fp16-exact: stored as fp16
+        targets.append({"image_size": size, "gt_boxes": gt, "gt_instance_ids": ids})
+    return props, targets
+
+
+def to_ref(props, targets):
+    I, B = ref_shim.Instances, ref_shim.Boxes
+    rp, rt = [], []
+    for p, t in zip(props, targets):
+        a = I(p["image_size"])
+        a.proposal_boxes = B(p["proposal_boxes"].clone())
+        a.objectness_logits = p["objectness_logits"].clone()
+        a.query_features = p["query_features"].clone()
+        rp.append(a)
+        b = I(t["image_size"])
+        b.gt_boxes = B(t["gt_boxes"].clone())
+        b.gt_instance_ids = t["gt_instance_ids"].clone()
+        rt.append(b)
+    return rp, rt
+
+
+def main():
+    for builtin, tag in (("icdar15", "lst"), ("pp_dstext", "pp")):
+        cfg = mini_cfg(builtin)
+        cfg.MODEL.ASSO_HEAD.DROPOUT = 0.0
+        sd = synth_state_dict(cfg, seed=7)
+        rh = gen_golden.build_ref_roi_heads(cfg, sd).train()
+        out = {}
+        for ci, seed in enumerate((3, 4)):
+            props, targets = make_clip(seed)
+            rp, rt = to_ref(props, targets)
+            rh.zero_grad()
+            losses = rh._forward_asso(rp, rt)
+            (losses["loss_long_asso"] + losses["loss_short_asso"]).backward()
+            params = dict(rh.named_parameters())
+            sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("roi_heads.")}
+            mine = train_oracle.asso_losses({**sd, **sdg}, cfg, props, targets)
+            (mine["loss_long_asso"] + mine["loss_short_asso"]).backward()
+            for k in ("loss_long_asso", "loss_short_asso"):
+                print("%s case %d %s: reference %.6f oracle %.6f" % (tag, ci, k, float(losses[k]), float(mine[k])))
+                out["c%d_%s" % (ci, k)] = np.float32(float(losses[k]))
+            for gk in GRAD_KEYS[cfg.MODEL.ROI_HEADS.NAME]:
+                ref_g = params[gk].grad
+                my_g = sdg["roi_heads." + gk].grad
+                print("   grad %s: |ref| %.3e max|d| %.3e" % (gk, float(ref_g.abs().max()), float((ref_g - my_g).abs().max())))
+                flat = ref_g.reshape(-1)
+                out["c%d_gsample_%s" % (ci, gk)] = flat[::max(1, flat.numel() // 4096)][:4096].numpy().astype(np.float32)
+                out["c%d_gabs_%s" % (ci, gk)] = np.float64(float(flat.double().abs().sum()))
+            for f, (p, t) in enumerate(zip(props, targets)):
+                out["c%d_f%d_pb" % (ci, f)] = p["proposal_boxes"].numpy()
+                out["c%d_f%d_obj" % (ci, f)] = p["objectness_logits"].numpy()
+                out["c%d_f%d_qf" % (ci, f)] = p["query_features"].numpy().astype(np.float16)     # stored as fp16: the test feeds
+                out["c%d_f%d_gt" % (ci, f)] = t["gt_boxes"].numpy()                              # exactly these values back
+                out["c%d_f%d_ids" % (ci, f)] = t["gt_instance_ids"].numpy()
+        np.savez_compressed(os.path.join(GOLD, "train_asso_%s.npz" % tag), **out)
+        print("wrote", "train_asso_%s.npz" % tag, os.path.getsize(os.path.join(GOLD, "train_asso_%s.npz" % tag)))
+
+
+if __name__ == "__main__":
+    main()
