@@ -111,5 +111,37 @@ def main():
         print("wrote", "train_asso_%s.npz" % tag, os.path.getsize(os.path.join(GOLD, "train_asso_%s.npz" % tag)))
 
 
+def main_res():
+    """loss_res (lstmatcher.py:237-268): the reference's rescoring loss on synthetic detector outputs."""
+    cfg = mini_cfg("icdar15")
+    cfg.MODEL.ASSO_HEAD.DROPOUT = 0.0
+    sd = synth_state_dict(cfg, seed=7)
+    rh = gen_golden.build_ref_roi_heads(cfg, sd).train()
+    g = torch.Generator().manual_seed(1)
+    B, nq = 2, cfg.MODEL.TRANSFORMER.NUM_QUERIES
+    qf = torch.randn(B, nq, 25, 256, generator=g).half().float()
+    pts = torch.rand(B, nq, 25, 2, generator=g)
+    targets = []
+    for b in range(B):
+        gc = 3 + b
+        sel = torch.randperm(nq, generator=g)[:gc]
+        targets.append({"labels": torch.zeros(gc, dtype=torch.long),
+                        "ctrl_points": pts[b, sel] + (torch.rand(gc, 25, 2, generator=g) - 0.5) * 0.02})
+    outputs = {"query_features": qf, "pred_ctrl_points": pts, "re_pred_logits": rh.rescoring_head(qf)}
+    ref = rh.loss_res(outputs, targets)
+    rh.zero_grad()
+    ref["loss_res"].backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("roi_heads.rescoring")}
+    mine = train_oracle.loss_res({**sd, **params}, cfg, qf, pts, targets)
+    print("loss_res reference %.7f oracle %.7f" % (float(ref["loss_res"]), float(mine["loss_res"])))
+    out = {"qf": qf.numpy().astype(np.float16), "pts": pts.numpy(), "loss_res": np.float32(float(ref["loss_res"])),
+           "grad_w": rh.rescoring_head.weight.grad.numpy(), "grad_b": rh.rescoring_head.bias.grad.numpy()}
+    for b, t in enumerate(targets):
+        out["t%d_ctrl" % b] = t["ctrl_points"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "train_res_ic15.npz"), **out)
+    print("wrote train_res_ic15.npz", os.path.getsize(os.path.join(GOLD, "train_res_ic15.npz")))
+
+
 if __name__ == "__main__":
     main()
+    main_res()

@@ -5,8 +5,8 @@ fixture generator.  Plain differentiable torch: autograd through it gives the he
 
 PINNED by tests/golden/train_asso_*.npz, which oracle/gen_golden_train.py produces by calling the reference's own
 `_forward_asso` in training mode (dropout switched off: it is the one stochastic element) on the repo's synthetic weights.
-Only the association head trains in the reference (freeze_layers.py:20-37); the rescoring loss (`loss_res`, Hungarian
-matching of control points) is NOT restated yet.
+Only `roi_heads` trains in the reference (freeze_layers.py:20-37): the association losses above and `loss_res` of the
+rescoring head (further down; pinned by tests/golden/train_res_ic15.npz).
 """
 import torch
 import torch.nn.functional as F
@@ -122,3 +122,52 @@ def asso_losses(sd, cfg, frames, targets):
         loss_short = loss_short + one(props[c - 1:c + 1], tsl, reid[lo:hi], n_t[c - 1:c + 1], True)
     loss_short = loss_short / (eff + 1e-4)
     return {"loss_long_asso": A.ASSO_WEIGHT * loss_long, "loss_short_asso": A.ASSO_WEIGHT_LOCAL * loss_short}
+
+
+def point_matching(cfg, re_logits, pred_ctrl_points, targets):
+    """CtrlPointHungarianMatcher4GM.forward (third_party/adet/modeling/model/matcher.py:175-198): focal class cost of the
+    RESCORED logits averaged over the 25 points + L1 distance of the control points, one assignment per image."""
+    from scipy.optimize import linear_sum_assignment
+    L = cfg.MODEL.TRANSFORMER.LOSS
+    with torch.no_grad():
+        sizes = [len(t["labels"]) for t in targets]
+        bs, nq = re_logits.shape[:2]
+        prob = re_logits.flatten(0, 1).sigmoid()
+        out_pts = pred_ctrl_points.flatten(0, 1).flatten(-2)
+        tgt_pts = torch.cat([t["ctrl_points"] for t in targets]).flatten(-2)
+        neg = (1 - L.FOCAL_ALPHA) * (prob ** L.FOCAL_GAMMA) * (-(1 - prob + 1e-8).log())
+        pos = L.FOCAL_ALPHA * ((1 - prob) ** L.FOCAL_GAMMA) * (-(prob + 1e-8).log())
+        cost_class = (pos[..., 0] - neg[..., 0]).mean(-1, keepdims=True)
+        C = L.POINT_CLASS_WEIGHT * cost_class + L.POINT_COORD_WEIGHT * torch.cdist(out_pts, tgt_pts, p=1)
+        C = C.view(bs, nq, -1)
+        out = []
+        for i, c in enumerate(C.split(sizes, -1)):
+            r, col = linear_sum_assignment(c[i].numpy())
+            out.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(col, dtype=torch.int64)))
+        return out
+
+
+def loss_res(sd, cfg, query_features, pred_ctrl_points, targets):
+    """LSTMatcher.loss_res (lstmatcher.py:237-268) for one process: the rescoring head (Linear 256 -> 1 on every point
+    feature, :185-186) under a sigmoid focal loss against the Hungarian-matched queries.  query_features [B,nq,25,256] and
+    pred_ctrl_points [B,nq,25,2] are the frozen detector's outputs; targets: {"labels" [g], "ctrl_points" [g,25,2]}."""
+    L = cfg.MODEL.TRANSFORMER.LOSS
+    num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    logits = O.linear(query_features, sd, "roi_heads.rescoring_head")            # [B,nq,25,1]
+    indices = point_matching(cfg, logits, pred_ctrl_points, targets)
+    num_inst = max(float(sum(len(t["labels"]) for t in targets)), 1.0)
+    batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+    src_idx = torch.cat([src for src, _ in indices])
+    target_classes = torch.full(logits.shape[:-1], num_classes, dtype=torch.int64)
+    matched = torch.cat([t["labels"][j] for t, (_, j) in zip(targets, indices)])
+    target_classes[batch_idx, src_idx] = matched[..., None]
+    onehot = torch.zeros(list(logits.shape[:-1]) + [logits.shape[-1] + 1], dtype=logits.dtype)
+    onehot.scatter_(-1, target_classes.unsqueeze(-1), 1)
+    onehot = onehot[..., :-1]
+    prob = logits.sigmoid()
+    ce = F.binary_cross_entropy_with_logits(logits, onehot, reduction="none")
+    p_t = prob * onehot + (1 - prob) * (1 - onehot)
+    loss = ce * ((1 - p_t) ** L.FOCAL_GAMMA)
+    if L.FOCAL_ALPHA >= 0:
+        loss = (L.FOCAL_ALPHA * onehot + (1 - L.FOCAL_ALPHA) * (1 - onehot)) * loss
+    return {"loss_res": loss.mean((1, 2)).sum() / num_inst * logits.shape[1]}

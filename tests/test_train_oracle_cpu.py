@@ -70,3 +70,31 @@ def test_association_ground_truth_table():
     gt, cues = train_oracle.asso_gt(pb, pt, tb, tt, ids, [2, 2])
     assert gt.tolist() == [[0, 0], [1, 2]]                       # track 9 is not seen in frame 1 -> background (= n_t = 2)
     assert cues.tolist() == [0, 1, 0, -1]
+
+
+def test_rescoring_loss_and_gradient():
+    """loss_res: Hungarian matching of control points (CtrlPointHungarianMatcher4GM) + sigmoid focal loss of the rescoring
+    head, against the reference's own value and gradient."""
+    g = golden("train_res_ic15.npz")
+    cfg = mini_cfg("icdar15")
+    sd = synth_state_dict(cfg, seed=7)
+    qf, pts = torch.from_numpy(g["qf"].astype(np.float32)), torch.from_numpy(g["pts"])
+    targets = []
+    b = 0
+    while "t%d_ctrl" % b in g:
+        c = torch.from_numpy(g["t%d_ctrl" % b])
+        targets.append({"labels": torch.zeros(c.shape[0], dtype=torch.long), "ctrl_points": c})
+        b += 1
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("roi_heads.rescoring")}
+    out = train_oracle.loss_res({**sd, **params}, cfg, qf, pts, targets)
+    assert abs(float(out["loss_res"].detach()) - float(g["loss_res"])) <= 2e-6
+    out["loss_res"].backward()
+    assert float((params["roi_heads.rescoring_head.weight"].grad - torch.from_numpy(g["grad_w"])).abs().max()) <= 1e-6
+    assert float((params["roi_heads.rescoring_head.bias"].grad - torch.from_numpy(g["grad_b"])).abs().max()) <= 1e-6
+    idx = train_oracle.point_matching(cfg, O_linear(qf, sd), pts, targets)
+    assert [len(i) for i, _ in idx] == [len(t["labels"]) for t in targets]
+
+
+def O_linear(qf, sd):
+    from oracle import gom_oracle as O
+    return O.linear(qf, sd, "roi_heads.rescoring_head")
