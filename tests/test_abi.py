@@ -45,3 +45,29 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libgomatching_hip.so")
     with pytest.raises(lib.GomError):
         lib.load()
+
+
+def test_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument checks run before any HIP call: the newer entry points turn nonsense into GOM_ERR_INVALID_ARG /
+    GOM_ERR_UNSUPPORTED instead of launching (error behaviour of the boundary; no compute, no device needed)."""
+    import ctypes
+    from gomatching_amd import lib
+    L = lib.load()
+    INVALID = 1                                                   # GOM_ERR_INVALID_ARG (include/gomatching_hip.h)
+    p = ctypes.c_void_p(0x1000)                                   # a non-null, 16-byte aligned address that is never dereferenced
+    assert L.gom_flash_attention_f32(p, p, p, p, 1, 64, 2, 32, 192, 64, None, None) == INVALID         # head_dim 32: not served
+    assert L.gom_flash_attention_f32(None, p, p, p, 1, 64, 2, 64, 384, 128, None, None) == INVALID
+    assert L.gom_flash_attention_f32(p, p, p, p, 1, 64, 2, 64, 100, 128, None, None) == INVALID         # row stride < 3C
+    assert L.gom_im2col_nhwc_f32(p, p, 1, 8, 8, 3, 3, 3, 1, 1, 1, 32, None) == INVALID                  # C % 4 != 0
+    assert L.gom_im2col_nhwc_f32(p, p, 1, 8, 8, 4, 3, 3, 1, 1, 1, 20, None) == INVALID                  # ldo < KH*KW*C
+    assert L.gom_grouped_conv3x3_nhwc_f32(p, p, None, p, None, 0, p, 1, 8, 8, 64, 64, 8, 1, None) == INVALID   # 8 channels per group: only 4 and 16 are built
+    assert L.gom_grouped_conv3x3_nhwc_f32(p, p, None, p, None, 7, p, 1, 8, 8, 64, 64, 16, 1, None) == INVALID  # unknown activation
+    assert L.gom_vitae_window_attention_f32(p, p, 4, 3, 96, None) == INVALID                             # head_dim 32
+    assert L.gom_softmax_rows_scaled_f32(p, 4, 9000, 9000, 1.0, None) == INVALID                         # > 8192 columns
+    assert L.gom_transpose_f32(p, p, 8, 8, 4, 8, None) == INVALID                                        # ld < cols
+    assert L.gom_copy_words(None, p, 4, None) == INVALID
+    assert L.gom_match_fused_supported(300, 10, 1024, 8, 1, 1) == 0 and L.gom_match_fused_supported(64, 10, 1024, 8, 1, 1) == 1
+    assert L.gom_match_fused_supported(64, 10, 1024, 16, 1, 1) == 0                                      # head_dim 64
+    assert L.gom_match_fused_set_grid(0) == INVALID and L.gom_match_fused_set_grid(64) == 0
+    assert L.gom_tracker_create(0, 0.2, 1, 1, 1, 1.0, None, 0, None, 0, 1024, 8, 1024) is None           # test_len < 1
+    assert L.gom_tracker_create(6, 0.2, 1, 1, 1, 1.0, None, 1, None, 0, 1024, 8, 1024) is None           # layers without weights
