@@ -135,3 +135,13 @@ def test_rejects_bad_windows():
                                  ctypes.byref(idc), None, None) != 0
     finally:
         L.gom_tracker_destroy(h)
+
+
+def test_decay_table_equals_the_vectorised_power_of_the_python_loop():
+    """tracker_rt takes decay_time ** e from a table; the Python loop calls np.power on an array of exponents
+    (meta_arch._match).  Both must give the same float32 bits whatever the array length (SIMD tails included)."""
+    tab = np.power(np.float32(0.9), np.arange(7).astype(np.float32)).astype(np.float32)
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        e = rng.integers(0, 7, size=int(rng.integers(1, 400))).astype(np.float32)
+        assert np.array_equal(np.power(np.float32(0.9), e).astype(np.float32), tab[e.astype(int)])
