@@ -35,14 +35,17 @@ struct FusedArgs {
 };
 
 __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its stores before the barrier
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();                                         // release: this workgroup's writes are visible device-wide
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the write-back completes before the arrival is published
         atomicAdd(counter, 1u);
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
     }
     __syncthreads();
     __threadfence();                                             // acquire: drop what this CU cached of the other CUs' buffers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ... and wait for the invalidate before the next phase loads
 }
 
 // C[M, Nout] = act(A[M, K] . W[Nout, K]^T + bias + R): a wave owns CB columns x 8 rows per item -- the per-output arithmetic
