@@ -98,3 +98,34 @@ def test_rescoring_loss_and_gradient():
 def O_linear(qf, sd):
     from oracle import gom_oracle as O
     return O.linear(qf, sd, "roi_heads.rescoring_head")
+
+
+@pytest.mark.parametrize("tag", ["lst", "pp"])
+def test_host_association_targets_equal_the_oracle(tag):
+    """gomatching_amd.training.association_targets (numpy, product side) against the pinned torch restatement on the
+    fixture clips (false positives, a missed object, an empty frame) and on random boxes."""
+    from gomatching_amd import training
+    g = golden("train_asso_%s.npz" % tag)
+    cfg = mini_cfg("icdar15" if tag == "lst" else "pp_dstext")
+    for ci in (0, 1):
+        props, targets = _clip(g, ci)
+        keep = [p["objectness_logits"] > cfg.MODEL.ASSO_HEAD.ASSO_THRESH for p in props]
+        fr = [{"image_size": p["image_size"], "proposal_boxes": p["proposal_boxes"][k]} for p, k in zip(props, keep)]
+        n_t = [len(f["proposal_boxes"]) for f in fr]
+        pb, pt = train_oracle._boxes_time(fr, "proposal_boxes")
+        tb, tt = train_oracle._boxes_time(targets, "gt_boxes")
+        ids = torch.cat([t["gt_instance_ids"] for t in targets if len(t["gt_boxes"]) > 0])
+        want_gt, want_cues = train_oracle.asso_gt(pb, pt, tb, tt, ids, n_t)
+        sizes = [p["image_size"] for p in props]
+        npb, npt = training.normalised_boxes_and_times([f["proposal_boxes"].numpy() for f in fr], sizes)
+        ntb, ntt = training.normalised_boxes_and_times([t["gt_boxes"].numpy() for t in targets], sizes)
+        assert np.array_equal(npb, pb.numpy()) and np.array_equal(npt, pt.numpy())
+        got_gt, got_cues = training.association_targets(npb, npt, ntb, ntt, ids.numpy(), n_t)
+        assert got_gt.tolist() == want_gt.tolist() and got_cues.tolist() == want_cues.tolist()
+    rng = np.random.default_rng(3)
+    a = rng.random((40, 2)).astype(np.float32)
+    b = rng.random((30, 2)).astype(np.float32)
+    A = np.concatenate([a, a + rng.random((40, 2)).astype(np.float32) * 0.3], 1)
+    B = np.concatenate([b, b + rng.random((30, 2)).astype(np.float32) * 0.3], 1)
+    ref = train_oracle._pairwise_iou(torch.from_numpy(A), torch.from_numpy(B)).numpy()
+    assert np.abs(training.pairwise_iou(A, B) - ref).max() <= 1e-7
