@@ -67,3 +67,22 @@ def association_targets(pred_box, pred_time, target_box, target_time, target_ins
             else:
                 gt[k, t] = n_t[t]
     return gt, cues
+
+
+def point_matching(re_logits, pred_ctrl_points, target_ctrl_points, focal_alpha=0.25, focal_gamma=2.0, class_weight=1.0,
+                   coord_weight=1.0):
+    """`CtrlPointHungarianMatcher4GM.forward` (third_party/adet/modeling/model/matcher.py:175-198) for ONE image on numpy
+    arrays: re_logits [nq, P, 1] (rescoring head), pred_ctrl_points [nq, P, 2], target_ctrl_points [g, P, 2] (normalised) ->
+    (query indices [min(nq,g)], target indices) of the minimum-cost assignment, solved by the library's host LSA
+    (`gom_linear_sum_assignment`, SciPy's tie-breaking)."""
+    from . import ops
+    x = np.asarray(re_logits, np.float32)
+    prob = (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
+    neg = (1 - focal_alpha) * (prob ** focal_gamma) * (-np.log(1 - prob + np.float32(1e-8)))
+    pos = focal_alpha * ((1 - prob) ** focal_gamma) * (-np.log(prob + np.float32(1e-8)))
+    cost_class = (pos[..., 0] - neg[..., 0]).mean(-1, keepdims=True)                    # [nq, 1]
+    a = np.asarray(pred_ctrl_points, np.float32).reshape(x.shape[0], -1)
+    b = np.asarray(target_ctrl_points, np.float32).reshape(-1, a.shape[1])
+    cost_pts = np.abs(a[:, None, :] - b[None, :, :]).sum(-1)                             # torch.cdist(p=1)
+    cost = class_weight * cost_class + coord_weight * cost_pts
+    return ops.linear_sum_assignment(cost.astype(np.float64))

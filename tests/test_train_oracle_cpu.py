@@ -129,3 +129,24 @@ def test_host_association_targets_equal_the_oracle(tag):
     B = np.concatenate([b, b + rng.random((30, 2)).astype(np.float32) * 0.3], 1)
     ref = train_oracle._pairwise_iou(torch.from_numpy(A), torch.from_numpy(B)).numpy()
     assert np.abs(training.pairwise_iou(A, B) - ref).max() <= 1e-7
+
+
+def test_host_point_matching_equals_the_oracle():
+    """Product-side Hungarian matching of control points (numpy cost + the library's C++ LSA) against the pinned oracle."""
+    from gomatching_amd import training
+    g = golden("train_res_ic15.npz")
+    cfg = mini_cfg("icdar15")
+    sd = synth_state_dict(cfg, seed=7)
+    qf, pts = torch.from_numpy(g["qf"].astype(np.float32)), torch.from_numpy(g["pts"])
+    targets, b = [], 0
+    while "t%d_ctrl" % b in g:
+        c = torch.from_numpy(g["t%d_ctrl" % b])
+        targets.append({"labels": torch.zeros(c.shape[0], dtype=torch.long), "ctrl_points": c})
+        b += 1
+    logits = O_linear(qf, sd)
+    want = train_oracle.point_matching(cfg, logits, pts, targets)
+    L = cfg.MODEL.TRANSFORMER.LOSS
+    for i, t in enumerate(targets):
+        r, c = training.point_matching(logits[i].numpy(), pts[i].numpy(), t["ctrl_points"].numpy(), L.FOCAL_ALPHA, L.FOCAL_GAMMA,
+                                       L.POINT_CLASS_WEIGHT, L.POINT_COORD_WEIGHT)
+        assert r.tolist() == want[i][0].tolist() and c.tolist() == want[i][1].tolist()
