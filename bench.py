@@ -5,7 +5,9 @@
 
 A "step" is one pass of the hot path -- the reference's timed window, GoMBatchPredictor.__call__ from
 `batch_inference` through short-track removal and rescaling (text_track_visualizer.py:325-334) -- over
-one synthetic clip whose frames are already resident in HBM.  Workload (BASELINE.json configs[1]):
+one synthetic clip.  `value` times the reference's window as it stands: the resized fp32 frames
+start in (pinned) host memory and their H2D copy is inside the window, on an upload stream under the previous step's
+detector; `value_hbm_resident` is the same K steps with the frames already in HBM.  Workload (BASELINE.json configs[1]):
 1280x720 source frames -> harness resize to 1000x1778 (MIN_SIZE_TEST=1000), 8 frames per GPU,
 GoMatching_ICDAR15 config (R-50, 100 queries, LSTMatcher, rescoring), random-init synthetic weights.
 With N > 1 the clip has 8*N frames, block-sharded 8 per rank, one RCCL all-gather of per-frame
@@ -35,13 +37,27 @@ DTYPES = {"fp32": "f32 (exact fp32 MFMA)",
           "f16x3": "f32 (f16x3 split MFMA: 22-bit significand products, fp32 accumulate; parity tests at fp32 tolerances)"}
 
 
+def kernel_source_hash():
+    """sha1 over the GEMM kernel sources: profiles/pmc_traffic.json records the hash of the build its counters were taken
+    on (tools/pmc_traffic.py), and `roofline.traffic` is only printed while that build is still the current one."""
+    import hashlib
+    h = hashlib.sha1()
+    for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "common.h"):
+        with open(os.path.join(ROOT, "gomatching_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
-    gfx950 per MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMCs itself."""
+    """HBM bytes per launch of the dominant kernel's GEMM-API launches from the committed rocprofv3 PMC passes (FETCH_SIZE
+    x2 on gfx950 per MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMCs itself.  None when the counters
+    belong to another build of the kernel."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
+        if rec.get("_meta", {}).get("kernel_source_hash") != kernel_source_hash():
+            return None
         return rec[kernel]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
@@ -76,10 +92,11 @@ def calibrate(model, inputs, frac=0.3):
     return shift, re_shift
 
 
-def cpu_baseline(cfg, sd, shift, re_shift, frame_chw, gpu_frame0):
-    """The CPU oracle ("port") timed on the host cores, on a bounded sample: ONE 1000x1778 frame through
-    detection + embedding + id initialisation (short-track removal is skipped: it would delete every track of a
-    1-frame sample).  The same run doubles as a full-size parity check of frame 0 against the HIP path."""
+def cpu_baseline(cfg, sd, shift, re_shift, frames_chw, orig_hw, gpu_res, gpu_id_count):
+    """The CPU oracle ("port") timed on the host cores over the WHOLE clip of one step (8 frames of 1000x1778 through
+    detection, embedding, tracker, short-track removal and rescaling: oracle/gom_oracle.py run_clip), and the same run as
+    the full-size parity check of the HIP path: per frame the detections, characters and TRACK IDS must be identical,
+    points within 1e-3 px (north_star)."""
     from oracle import gom_oracle as O
     cores = min(os.cpu_count() or 1, 32)                    # torch's CPU kernels stop scaling (and thrash) beyond this
     torch.set_num_threads(cores)
@@ -89,31 +106,45 @@ def cpu_baseline(cfg, sd, shift, re_shift, frame_chw, gpu_frame0):
     if re_shift is not None:
         sd["roi_heads.rescoring_head.bias"] = sd["roi_heads.rescoring_head.bias"] + re_shift
     t0 = time.time()
-    with torch.no_grad():
-        dets = O.detect_frames(sd, cfg, [frame_chw])
-        O.track_clip(sd, cfg, dets)
+    ref, ref_idc = O.run_clip(sd, cfg, frames_chw, orig_hw=orig_hw)
     dt = time.time() - t0
-    ref = dets[0]
-    n = len(ref)
-    parity = {"detections_cpu": n, "detections_gpu": len(gpu_frame0)}
-    if n == len(gpu_frame0) and n > 0:
-        parity["max_abs_score"] = float((gpu_frame0.scores.cpu() - ref["scores"]).abs().max())
-        parity["max_abs_bd_px"] = float((gpu_frame0.bd.cpu() - ref["bd"]).abs().max())
-        parity["max_abs_ctrl_px"] = float((gpu_frame0.ctrl_points.cpu() - ref["ctrl_points"]).abs().max())
-        parity["recs_identical"] = bool(torch.equal(gpu_frame0.recs.cpu(), ref["recs"]))
-        parity["max_abs_reid"] = float((gpu_frame0.reid_features.cpu() - ref["reid_features"]).abs().max())
-    return {"value": 1.0 / dt, "unit": "frames/sec", "cores": cores, "kind": "port",
-            "sample": "1 frame 1280x720->1000x1778 through oracle/gom_oracle.py detect_frames+track_clip "
-                      "(%.1f s of CPU work on %d threads)" % (dt, cores),
-            "full_size_parity_frame0": parity}
+    parity = {"frames": len(ref), "id_count_cpu": int(ref_idc), "id_count_gpu": int(gpu_id_count),
+              "detections_cpu": [len(r["instances"]) for r in ref],
+              "detections_gpu": [len(r["instances"]) for r in gpu_res]}
+    same_n = parity["detections_cpu"] == parity["detections_gpu"]
+    ids_same = recs_same = same_n
+    mx = {"score": 0.0, "bd_px": 0.0, "ctrl_px": 0.0}
+    if same_n:
+        for r, g in zip(ref, gpu_res):
+            r, g = r["instances"], g["instances"]
+            if len(r) == 0:
+                continue
+            ids_same = ids_same and bool(torch.equal(g.track_ids.cpu(), r["track_ids"]))
+            recs_same = recs_same and bool(torch.equal(g.recs.cpu(), r["recs"]))
+            mx["score"] = max(mx["score"], float((g.scores.cpu() - r["scores"]).abs().max()))
+            mx["bd_px"] = max(mx["bd_px"], float((g.bd.cpu() - r["bd"]).abs().max()))
+            mx["ctrl_px"] = max(mx["ctrl_px"], float((g.ctrl_points.cpu() - r["ctrl_points"]).abs().max()))
+    parity.update({"track_ids_identical": ids_same, "recs_identical": recs_same, "max_abs_score": mx["score"],
+                   "max_abs_bd_px": mx["bd_px"], "max_abs_ctrl_px": mx["ctrl_px"]})
+    n = len(frames_chw)
+    return {"value": n / dt, "unit": "frames/sec", "cores": cores, "kind": "port",
+            "sample": "the whole %d-frame clip of one step (1280x720 -> %dx%d) through oracle/gom_oracle.py run_clip: detector, "
+                      "embedding, tracker, short-track removal, rescaling (%.1f s of CPU work on %d threads)"
+                      % (n, frames_chw[0].shape[-2], frames_chw[0].shape[-1], dt, cores),
+            "full_size_parity_clip": parity}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-backends", action="store_true",
+                    help="skip the short secondary measurements of the other two contraction back-ends (N=1 only)")
+    ap.add_argument("--inputs", default="host", choices=["host", "hbm"],
+                    help="where the frames are when the timed window starts: pinned host memory with the H2D inside the "
+                         "window (the reference's window, `value`), or already in HBM (then `value` is that figure)")
     ap.add_argument("--backbone", default="r50", choices=["r50", "swin", "vitae"],
                     help="r50 = BASELINE.json's workload; swin = side measurement of the Swin-T backbone (§8-f3) on the "
                          "same frames (not the BASELINE workload)")
@@ -155,11 +186,11 @@ def main():
 
     from gomatching_amd import ops
     from gomatching_amd.config import setup_cfg
-    from gomatching_amd.dist import sharded_batch_inference
     from gomatching_amd.predictor import GoMBatchPredictor, new_time_cost
     from gomatching_amd.synth import make_clip
+    from gomatching_amd.dist import exchange_and_track
+    from gomatching_amd.predictor import ClipPipeline
 
-    ops.GEMM_MODE = args.gemm
     cfg = setup_cfg(builtin="icdar15")
     cfg.MODEL.DEVICE = "cuda"
     src_hw = SRC_HW
@@ -169,80 +200,103 @@ def main():
         cfg.MODEL.BACKBONE.NAME = "build_vitaev2_backbone"
         src_hw = (1024, 1792)                                  # ViTAE needs multiples of 32 (the reference asserts): frames
         cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 1024, 2000     # arrive at network size, the resize is a no-op
-    model, sd = build_model(cfg, device)
-    if args.fused_matcher:
-        from gomatching_amd import lib as _lib
-        _lib.load().gom_tracker_set_fused(1)
-        _lib.load().gom_match_fused_set_grid(args.fused_matcher)
-        ops.FUSED_MATCHER = True
-    if args.h2d:
-        model.h2d_mode = args.h2d
-    predictor = GoMBatchPredictor(cfg, model)
 
     # this rank's block of the clip: frames [rank*8, rank*8+8) of a world*8-frame synthetic video
     clip = make_clip(FRAMES_PER_GPU * world, src_hw[0], src_hw[1], clip_id=0, num_rects=12)
     mine = [f[:, :, ::-1] for f in clip[rank * FRAMES_PER_GPU:(rank + 1) * FRAMES_PER_GPU]]   # harness takes BGR
-    inputs, hw = predictor.prepare(mine)                       # host resize etc.: outside the timed window
-    inputs = [dict(x, image=x["image"].to(device)) for x in inputs]      # resident in HBM before timing starts
-    net_hw = tuple(inputs[0]["image"].shape[-2:])
-    # every rank calibrates on the SAME frame (frame 0 of the clip) so that all ranks hold identical weights
-    cal_inputs, _ = predictor.prepare([clip[0][:, :, ::-1]])
+    host_inputs, hw = GoMBatchPredictor(cfg, None).prepare(mine)      # host resize etc.: outside the timed window
+    host_inputs = [dict(x, image=x["image"].pin_memory()) for x in host_inputs]
+    hbm_inputs = [dict(x, image=x["image"].to(device)) for x in host_inputs]
+    net_hw = tuple(host_inputs[0]["image"].shape[-2:])
+    cal_inputs, _ = GoMBatchPredictor(cfg, None).prepare([clip[0][:, :, ::-1]])
     cal_inputs = [dict(x, image=x["image"].to(device)) for x in cal_inputs]
-    shift, re_shift = calibrate(model, cal_inputs, frac=args.detect_frac)
+    shifts = {}
 
-    from gomatching_amd.dist import exchange_and_track
-    from gomatching_amd.predictor import ClipPipeline
-
-    def finish(h):
-        """Tracker half of a step (runs on the tracker stream, overlapping the next step's detection)."""
-        model.begin_batch([], FRAMES_PER_GPU * world * args.emulate_world)
-        dets = model.detect_finish(h, tc)
-        if args.emulate_world > 1 and world == 1:
-            from gomatching_amd.dist import pack_records, unpack_records
-            T = cfg.MODEL.TRANSFORMER
-            rec = pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, device)
-            dets = unpack_records(torch.cat([rec] * args.emulate_world), dets[0].image_size, model.roi_heads.feature_dim,
-                                  T.NUM_POINTS)
-            insts, id_count = model.track_frames(dets, 0, 0, [], tc)
-        elif world > 1:
-            insts, id_count = exchange_and_track(model, dets, 0, 0, [], tc)
+    def make(mode):
+        """Model + pipeline of one contraction back-end; every rank (and every back-end) calibrates on frame 0 of the
+        clip, the default back-end's shifts being reused so that all of them hold identical weights."""
+        ops.GEMM_MODE = mode
+        model, sd = build_model(cfg, device)
+        if args.fused_matcher:
+            from gomatching_amd import lib as _lib
+            _lib.load().gom_tracker_set_fused(1)
+            _lib.load().gom_match_fused_set_grid(args.fused_matcher)
+            ops.FUSED_MATCHER = True
+        if args.h2d:
+            model.h2d_mode = args.h2d
+        if not shifts:
+            shifts["s"], shifts["r"] = calibrate(model, cal_inputs, frac=args.detect_frac)
         else:
-            insts, id_count = model.track_frames(dets, 0, 0, [], tc)
-        if model.min_track_len > 0:
-            insts = model._remove_short_track(insts)
-        return model.batch_postprocess(insts, [hw] * len(insts)), id_count
+            model.detection_transformer.ctrl_class[1].add_(shifts["s"])
+            if shifts["r"] is not None:
+                model.roi_heads._rescoring[1].add_(shifts["r"])
+        tc_box = [new_time_cost()]
+
+        def finish(h):
+            """Tracker half of a step (runs on the tracker stream, overlapping the next step's detection)."""
+            tc = tc_box[0]
+            model.begin_batch([], FRAMES_PER_GPU * world * args.emulate_world)
+            dets = model.detect_finish(h, tc)
+            if args.emulate_world > 1 and world == 1:
+                from gomatching_amd.dist import pack_records, unpack_records
+                T = cfg.MODEL.TRANSFORMER
+                rec = pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, device)
+                dets = unpack_records(torch.cat([rec] * args.emulate_world), dets[0].image_size,
+                                      model.roi_heads.feature_dim, T.NUM_POINTS)
+                insts, id_count = model.track_frames(dets, 0, 0, [], tc)
+            elif world > 1:
+                insts, id_count = exchange_and_track(model, dets, 0, 0, [], tc)
+            else:
+                insts, id_count = model.track_frames(dets, 0, 0, [], tc)
+            if model.min_track_len > 0:
+                insts = model._remove_short_track(insts)
+            return model.batch_postprocess(insts, [hw] * len(insts)), id_count
+
+        return model, sd, ClipPipeline(model, finish), tc_box
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipe = ClipPipeline(model, finish)
-    tc = new_time_cost()
-    for _ in range(2):                                         # setup, not warm-up: eager pass (per-resolution caches)
-        pipe.push(inputs, tc)                                  # + hipGraph capture of the detector
-    pipe.flush()
-    for _ in range(args.warmup):
-        pipe.push(inputs, tc)
-    pipe.flush()
-    tc = new_time_cost()
-    barrier()
-    t0 = time.time()
-    done = 0
-    for _ in range(args.steps):                                # K steps: detector(i+1) overlaps tracker(i)
-        r = pipe.push(inputs, tc)
-        if r is not None:
-            res, id_count = r
-            done += 1
-    res, id_count = pipe.flush()
-    done += 1
-    barrier()
-    elapsed = time.time() - t0
-    assert done == args.steps
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    def timed(pipe, tc_box, inputs, steps, warmup):
+        """W untimed + exactly K timed steps (detector(i+1) overlaps tracker(i)); max over ranks."""
+        for _ in range(warmup):
+            pipe.push(inputs, tc_box[0])
+        pipe.flush()
+        tc_box[0] = new_time_cost()
+        barrier()
+        t0 = time.time()
+        done = 0
+        for _ in range(steps):
+            r = pipe.push(inputs, tc_box[0])
+            if r is not None:
+                res, id_count = r
+                done += 1
+        res, id_count = pipe.flush()
+        done += 1
+        barrier()
+        elapsed = time.time() - t0
+        assert done == steps
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        return elapsed, res, id_count
+
+    def setup(pipe, tc_box, inputs):
+        for _ in range(2):                                     # setup, not warm-up: eager pass (per-resolution caches)
+            pipe.push(inputs, tc_box[0])                       # + hipGraph capture of the detector
+        pipe.flush()
+
+    model, sd, pipe, tc_box = make(args.gemm)
+    primary = host_inputs if args.inputs == "host" else hbm_inputs
+    setup(pipe, tc_box, primary)
+    elapsed, res, id_count = timed(pipe, tc_box, primary, args.steps, args.warmup)
+    tc = tc_box[0]
+    elapsed_hbm = elapsed
+    if args.inputs == "host":                                  # secondary: the same K steps with the frames already in HBM
+        elapsed_hbm, _, _ = timed(pipe, tc_box, hbm_inputs, args.steps, 1)
 
     # Roofline leg.  The timed steps replay the detector as a hipGraph, which hides individual launches from HIP
     # events; the dominant kernel is therefore bracketed with events in PROFILE_STEPS eager steps of the same
@@ -252,10 +306,10 @@ def main():
     model.use_graphs = False
     prof = []
     ops.set_gemm_profile(prof)                                 # HIP events around the dominant kernel's launches
-    tcp = new_time_cost()
     PROFILE_STEPS = 2
+    tc_box[0] = new_time_cost()
     for _ in range(PROFILE_STEPS):
-        pipe.push(inputs, tcp)
+        pipe.push(hbm_inputs, tc_box[0])
     pipe.flush()
     barrier()
     ops.set_gemm_profile(None)
@@ -267,11 +321,19 @@ def main():
     flops = sum(p[2] for p in prof)
     alg_bytes = sum(p[3] for p in prof)
     achieved = flops / (dur_ms * 1e-3) / 1e12 if dur_ms > 0 else 0.0
+    by_shape = {}
+    for p_ in prof:
+        if len(p_) > 4:
+            d = by_shape.setdefault(p_[4], [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += p_[0].elapsed_time(p_[1])
+            d[2] += p_[2]
     line = {
         "metric": "frames/sec (whole node), 1280x720 clip, 100 queries/frame",
         "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPES[args.gemm], "data": "synthetic",
+        "value_hbm_resident": total_frames / elapsed_hbm,
         "config": {"workload": ("configs[1]: 1280x720 ICDAR15-video clip -> %dx%d net input, %d frames/GPU, "
                                 "100 queries, GoMatching_ICDAR15 (R-50 + DeepSolo + LSTMatcher, rescoring), "
                                 "random-init synthetic weights" % (net_hw[0], net_hw[1], FRAMES_PER_GPU))
@@ -279,7 +341,14 @@ def main():
                    ("NOT the BASELINE workload: %s backbone side measurement, %dx%d net input, %d frames/GPU, 100 "
                     "queries, DeepSolo + LSTMatcher, random-init synthetic weights"
                     % ({"swin": "Swin-T", "vitae": "ViTAEv2-S"}[args.backbone], net_hw[0], net_hw[1], FRAMES_PER_GPU)),
-                   "frames_per_step": FRAMES_PER_GPU * world, "emulated_world": args.emulate_world, "pipelining": "detector(step i+1) overlaps tracker(step i)", "detector_hipgraph": graphed,
+                   "inputs": ("resized fp32 CHW frames in pinned HOST memory when the timed window starts; the H2D copy "
+                              "(%.0f MB per step) is inside the window, on an upload stream under the previous step's detector "
+                              "(text_track_visualizer.py:325-334 + gom_lstmatcher.py:164-170); value_hbm_resident = same steps, "
+                              "frames already in HBM" % (FRAMES_PER_GPU * 3 * net_hw[0] * net_hw[1] * 4 / 1e6))
+                   if args.inputs == "host" else "frames resident in HBM when the timed window starts",
+                   "frames_per_step": FRAMES_PER_GPU * world, "emulated_world": args.emulate_world,
+                   "pipelining": "upload(step i+1) and detector(step i+1) overlap tracker(step i)",
+                   "detector_hipgraph": graphed,
                    "parallelism": "frame-sharded dp%d + 1 all-gather/step"
                    % world if world > 1 else "single GPU",
                    "detect_frac": args.detect_frac,
@@ -290,20 +359,38 @@ def main():
                      "traffic": pmc_traffic(PEAKS[args.gemm][0]), "mfma_passes_per_product": PEAKS[args.gemm][2],
                      "peak_note": {"fp32": "dense fp32-input MFMA peak",
                                    "bf16x6": "algorithmic fp32-equivalent FLOP/s; dense bf16 MFMA peak 2500 / 6 passes",
-                                   "f16x3": "algorithmic fp32-equivalent FLOP/s; dense fp16 MFMA peak 2500 / 3 passes"}[args.gemm], "launches_per_step": len(prof) // PROFILE_STEPS,
+                                   "f16x3": "algorithmic fp32-equivalent FLOP/s; dense fp16 MFMA peak 2500 / 3 passes"}[args.gemm],
+                     "launches_per_step": len(prof) // PROFILE_STEPS,
                      "avg_launch_us": dur_ms * 1e3 / max(len(prof), 1),
                      "flops_per_launch_avg": flops / max(len(prof), 1),
                      "algorithmic_bytes_per_launch_avg": alg_bytes / max(len(prof), 1),
                      "share_of_step_time": (dur_ms / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
+                     "by_shape_MxNxK": {k: {"launches_per_step": v[0] // PROFILE_STEPS, "avg_us": v[1] * 1e3 / v[0],
+                                            "tflops": v[2] / (v[1] * 1e-3) / 1e12,
+                                            "frac": v[2] / (v[1] * 1e-3) / 1e12 / PEAKS[args.gemm][1]}
+                                        for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:12]},
                      "measured_in": "%d eager steps after the timed region (timed steps are hipGraph replays)" % PROFILE_STEPS
                      if graphed else "%d eager steps after the timed region" % PROFILE_STEPS},
         "stage_ms_per_step": {k: v / args.steps * 1e3 for k, v in tc.items() if isinstance(v, float) and v > 0},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.backbone == "r50":
+    solo = rank == 0 and world == 1 and args.backbone == "r50" and args.emulate_world == 1
+    if solo and not args.no_alt_backends:
+        # the other two contraction back-ends on the same window, a few steps each (secondary figures, same process)
+        alt = {}
+        for mode in [m for m in ("f16x3", "bf16x6", "fp32") if m != args.gemm]:
+            m2, _, pipe2, tcb2 = make(mode)
+            setup(pipe2, tcb2, primary)
+            e2, _, _ = timed(pipe2, tcb2, primary, 4, 1)
+            alt[mode] = {"value": FRAMES_PER_GPU * 4 / e2, "ms_per_step": e2 / 4 * 1e3, "steps": 4}
+            del m2, pipe2, tcb2
+            torch.cuda.empty_cache()
+        ops.GEMM_MODE = args.gemm
+        line["alt_backends"] = alt
+    if solo and not args.no_cpu_baseline:
         cpu_cfg = setup_cfg(builtin="icdar15")
         cpu_cfg.MODEL.DEVICE = "cpu"
-        gpu0 = model.inference(inputs[:1], new_time_cost())[0]
-        line["cpu_baseline"] = cpu_baseline(cpu_cfg, sd, shift, re_shift, inputs[0]["image"].cpu(), gpu0)
+        line["cpu_baseline"] = cpu_baseline(cpu_cfg, sd, shifts["s"], shifts["r"], [x["image"] for x in host_inputs],
+                                            hw, res, id_count)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

@@ -14,6 +14,10 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 SOURCES = ["abi.hip", "gemm_conv.hip", "gemm_bf16x6.hip", "gemm_f16x3.hip", "gemm_planes.hip", "gemm_small.hip", "msda.hip", "norm.hip", "attn.hip", "elementwise.hip", "topk.hip",
            "detect.hip", "track.hip", "ingest.hip", "swin.hip", "vitae.hip", "attn_flash.hip", "match_fused.hip", "tracker_rt.hip", "lsa.cpp", "matcher_rt.cpp"]
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
+# device code is built without packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): DESIGN.md,
+# "Tracker determinism"
+NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+NOPK_FILES = os.environ.get("GOM_NOPK_FILES")          # diagnostic: comma-separated subset; default = every .hip source
 
 
 def _hipcc():
@@ -25,8 +29,16 @@ def _stamp(path):
     for dep in [path, os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "gomatching_hip.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + _extra(os.path.basename(path))).encode())
     return h.hexdigest()
+
+
+def _extra(src):
+    if not src.endswith(".hip"):
+        return []
+    if NOPK_FILES is None or src in NOPK_FILES.split(","):
+        return NOPK
+    return []
 
 
 def _compile(src):
@@ -36,12 +48,13 @@ def _compile(src):
     stamp = _stamp(path)
     if os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         return obj, False
-    cmd = [_hipcc()] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + _extra(src) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
+    err = "\n".join(l for l in r.stderr.splitlines() if "is not a recognized feature for this target" not in l)
+    if err.strip():                                          # (the x86 host pass does not know the device feature)
+        sys.stderr.write(err + "\n")
     with open(stamp_file, "w") as f:
         f.write(stamp)
     return obj, True

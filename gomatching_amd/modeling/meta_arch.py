@@ -125,10 +125,52 @@ class GoMatching:
             out = torch.empty((len(frames),) + tuple(frames[0].shape), dtype=dtype, device=self.device)
         if all(f.device == self.device and f.dtype == dtype for f in frames):
             torch.stack(frames, out=out)                         # one launch for the whole step
+        elif all(f.device.type == "cpu" and f.dtype == dtype for f in frames):
+            out.copy_(self._upload(frames, dtype))               # H2D on the upload stream, then one D2D launch
+            self._stage_release()
         else:
             for i, f in enumerate(frames):
                 out[i].copy_(f, non_blocking=True)
         return out, kind
+
+    def _upload(self, frames, dtype):
+        """Host frames (the reference hands `image` over as CPU tensors and moves them inside the timed window,
+        gom_lstmatcher.py:164-170) -> one of two device staging buffers, copied on a stream of their own: the caller queues
+        step i+1 while the detector of step i still runs, so the PCIe transfer hides under it instead of sitting in front of
+        the detector on its stream.  Asynchronous for pinned frames; pageable ones make the host wait for each copy.
+        The current stream is made to wait for the transfer; `_stage_release` marks the buffer reusable."""
+        key = (len(frames), tuple(frames[0].shape), dtype)
+        st = getattr(self, "_stage", None)
+        if st is None or st["key"] != key:
+            if st is not None:
+                torch.cuda.synchronize(self.device)              # the old buffers may still be read or written
+            st = {"key": key, "next": 0, "free": [None, None],
+                  "buf": [torch.empty((len(frames),) + tuple(frames[0].shape), dtype=dtype, device=self.device)
+                          for _ in range(2)]}
+            self._stage = st
+        if getattr(self, "_up_stream", None) is None:
+            self._up_stream = torch.cuda.Stream(device=self.device)
+        k = st["next"]
+        st["next"] = k ^ 1
+        st["last"] = k
+        up, cur = self._up_stream, torch.cuda.current_stream()
+        if st["free"][k] is not None:
+            up.wait_event(st["free"][k])                         # whoever read this buffer's previous frames is done
+        else:
+            up.wait_stream(cur)                                  # first use: the allocation itself is stream-ordered
+        with torch.cuda.stream(up):
+            for i, f in enumerate(frames):
+                st["buf"][k][i].copy_(f, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(up)
+        cur.wait_event(ev)
+        return st["buf"][k]
+
+    def _stage_release(self):
+        st = self._stage
+        ev = torch.cuda.Event()
+        ev.record()
+        st["free"][st["last"]] = ev
 
     def _normalise(self, raw, kind):
         if kind[0] == "u8":
@@ -551,21 +593,53 @@ class GoMatching:
         boxes_d = self._h2d(np.concatenate(boxes).astype(np.float32))
         src_all = ops.gather_rows(self._pool, rows_d)
         check = os.environ.get("GOM_TRACKER_DOUBLE_CHECK") == "1"
+        tap = check and os.environ.get("GOM_TRACKER_TAP") == "1"
         if check:
+            from . import roi_heads as _rh
             src_first, rows_first, boxes_first = src_all.clone(), rows_d.clone(), boxes_d.clone()
+            if tap:
+                _rh.TAP = tap1 = [("src", src_all), ("rows", rows_d), ("boxes", boxes_d)]   # references: no extra kernels
         scores = self.roi_heads.short_term_scores(src_all, pairs, boxes_d, frames[1].image_size, h2d=self._h2d)
         flat = self._d2h(torch.cat([s.reshape(-1) for s in scores]))         # the one sync of the short-term path
         if check:                                                # diagnostic: were the inputs final when they were first read?
+            _rh.TAP = None
             torch.cuda.current_stream().synchronize()
             again = ops.gather_rows(self._pool, rows_d)
             for name, a, b in (("SRC", src_first, again), ("ROWS", rows_first, rows_d), ("BOXES", boxes_first, boxes_d),
                                ("SRC-vs-its-clone", src_first, src_all)):
                 if not torch.equal(a, b):
                     print("%s MISMATCH in precompute_short_term: %d elements differ" % (name, int((a != b).sum())), flush=True)
+            if tap:
+                _rh.TAP = tap2 = [("src", again), ("rows", rows_d), ("boxes", boxes_d)]
             flat2 = self._d2h(torch.cat([s.reshape(-1) for s in self.roi_heads.short_term_scores(
                 again, pairs, boxes_d, frames[1].image_size, h2d=self._h2d)]))
+            _rh.TAP = None
+            if not np.isfinite(flat).all():
+                print("S of the FIRST evaluation is not finite: %d of %d elements" % (int((~np.isfinite(flat)).sum()), flat.size), flush=True)
             if not np.array_equal(flat, flat2):
-                print("S-RECOMPUTE MISMATCH (same inputs, after a sync): max |d| %.3e" % float(np.abs(flat - flat2).max()), flush=True)
+                bad = np.nonzero(flat != flat2)[0]
+                where, o = [], 0
+                for t, (_, n_prev, n_cur) in zip(which, pairs):
+                    b = bad[(bad >= o) & (bad < o + n_cur * n_prev)] - o
+                    if len(b):
+                        where.append("pair@%d %dx%d rows %s cols %s" % (t, n_cur, n_prev, sorted(set((b // n_prev).tolist())),
+                                                                       sorted(set((b % n_prev).tolist()))))
+                    o += n_cur * n_prev
+                print("S-RECOMPUTE MISMATCH (same inputs, after a sync): max |d| %.3e, %d of %d elements; %s; pairs %s" % (
+                    float(np.abs(flat - flat2).max()), len(bad), flat.size, " | ".join(where), pairs), flush=True)
+                if tap:
+                    torch.cuda.synchronize()
+                    for (na, a), (nb, b) in zip(tap1, tap2):
+                        a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+                        if not torch.equal(a2, b2):
+                            ne = a2 != b2
+                            rws = torch.nonzero(ne.any(1)).flatten().tolist()
+                            cls = torch.nonzero(ne.any(0)).flatten().tolist()
+                            print("  TAP %s %s: %d elements differ, max |d| %.3e, rows %s, cols %s%s" % (
+                                na, tuple(a.shape), int(ne.sum()), float((a2.double() - b2.double()).abs().max()), rws[:24],
+                                cls[:16], " ..." if len(cls) > 16 else ""), flush=True)
+            elif tap:
+                print("S-RECOMPUTE SAME", flush=True)
         out, o = {}, 0
         for t, (_, n_prev, n_cur) in zip(which, pairs):
             out[t] = flat[o:o + n_cur * n_prev].reshape(n_cur, n_prev)

@@ -14,6 +14,14 @@ from .. import ops
 
 _f32 = torch.float32
 
+TAP = None          # diagnostic: a list that receives (stage name, tensor) of every intermediate of the short-term path
+
+
+def _tap(name, t):
+    if TAP is not None:
+        TAP.append((name, t))
+    return t
+
 
 def _dev(t, device):
     return t.detach().float().contiguous().to(device)
@@ -89,7 +97,7 @@ class _MatcherTransformer:
         Nall = src_all.shape[0]
         memory = src_all
         for L in self.enc:
-            qkv = ops.gemm(memory, L["in"][0], bias=L["in"][1], small=True)
+            qkv = _tap("enc.qkv", ops.gemm(memory, L["in"][0], bias=L["in"][1], small=True))
             a = torch.empty((Nall, E), dtype=_f32, device=src_all.device)
             if seg is not None:
                 f = qkv.view(-1)
@@ -100,23 +108,24 @@ class _MatcherTransformer:
                     n = n_prev + n_cur
                     f = qkv[off:off + n].view(-1)
                     self._attend_into(a[off:off + n], f, f[E:], f[2 * E:], 3 * E, 3 * E, n, n)
-            memory = ops.gemm(a, L["out"][0], bias=L["out"][1], R=memory, small=True)
-            h = ops.gemm(memory, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True)
-            memory = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=memory, small=True)
+            _tap("enc.attn", a)
+            memory = _tap("enc.out", ops.gemm(a, L["out"][0], bias=L["out"][1], R=memory, small=True))
+            h = _tap("enc.lin1", ops.gemm(memory, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True))
+            memory = _tap("enc.lin2", ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=memory, small=True))
         if seg is not None:
             cur_rows = seg[2]
         else:
             cur_rows = torch.cat([torch.arange(off + n_prev, off + n_prev + n_cur, dtype=torch.int32)
                                   for off, n_prev, n_cur in pairs]).to(src_all.device)
-        tgt = ops.gather_rows(src_all, cur_rows)
+        tgt = _tap("dec.tgt0", ops.gather_rows(src_all, cur_rows))
         M = tgt.shape[0]
         cur_off = [0]
         for _, _, n_cur in pairs:
             cur_off.append(cur_off[-1] + n_cur)
         for L in self.dec:
             w, b = L["in"]
-            q = ops.gemm(tgt, w[:E], bias=b[:E], small=True)
-            kv = ops.gemm(memory, w[E:], bias=b[E:], small=True)
+            q = _tap("dec.q", ops.gemm(tgt, w[:E], bias=b[:E], small=True))
+            kv = _tap("dec.kv", ops.gemm(memory, w[E:], bias=b[E:], small=True))
             a = torch.empty((M, E), dtype=_f32, device=src_all.device)
             if seg is not None:
                 f = kv.view(-1)
@@ -127,10 +136,11 @@ class _MatcherTransformer:
                     f = kv[off:off + n].view(-1)
                     self._attend_into(a[cur_off[i]:cur_off[i + 1]], q[cur_off[i]:cur_off[i + 1]], f, f[E:], E, 2 * E,
                                       n_cur, n)
-            tgt = ops.gemm(a, L["out"][0], bias=L["out"][1], R=tgt, small=True)
+            _tap("dec.attn", a)
+            tgt = _tap("dec.out", ops.gemm(a, L["out"][0], bias=L["out"][1], R=tgt, small=True))
             if not self.only_crs:
-                h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True)
-                tgt = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt, small=True)
+                h = _tap("dec.lin1", ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True, small=True))
+                tgt = _tap("dec.lin2", ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt, small=True))
         return tgt, memory, cur_off
 
     def _attend_into(self, out, q, k, v, ld_q, ld_kv, Lq, Lk):
@@ -217,12 +227,14 @@ class _MatcherBase:
             parts = [np.asarray(seg_enc, np.int32), np.asarray(seg_dec, np.int32), np.asarray(desc, np.int32),
                      np.concatenate(row_pair), np.concatenate(cur_rows)]
             buf = h2d(np.concatenate(parts)) if h2d is not None else torch.from_numpy(np.concatenate(parts)).to(self.device)
+            _tap("desc", buf)
             o = np.cumsum([0] + [len(p) for p in parts])
             seg = (buf[o[0]:o[1]], buf[o[1]:o[2]], buf[o[4]:o[5]], max(p[1] + p[2] for p in pairs),
                    max(p[2] for p in pairs))
             tgt, memory, _ = self._matcher(True).forward_pairs(src_all, pairs, seg)
             S = ops.short_term_pairs(tgt, memory, buf[o[2]:o[3]], buf[o[3]:o[4]], boxes_all, image_size[1], image_size[0],
                                      self.cfg.VIDEO_TEST.WITH_IOU, cur_off, max_prev, s_off)
+            _tap("S", S)
             out, s_off = [], 0
             for off, n_prev, n_cur in pairs:
                 out.append(S[s_off:s_off + n_cur * n_prev].view(n_cur, n_prev))

@@ -164,7 +164,7 @@ def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols=None):
     if prof is not None:
         e1.record()
         nbytes = 4.0 * M * K + 2.0 * pl.shape[0] * N * pl.shape[2] + 4.0 * M * N + (4.0 * M * rc if R is not None else 0.0)
-        prof.append((e0, e1, 2.0 * M * N * K, nbytes))
+        prof.append((e0, e1, 2.0 * M * N * K, nbytes, "%dx%dx%d" % (M, N, K)))
     return out
 
 
@@ -242,7 +242,7 @@ def gemm_planes(A, W, bias=None, scale=None, R=None, relu=False, out=None, out_p
         e1.record()
         nbytes = 6.0 * M * K + 6.0 * N * pl.shape[2] + (4.0 * M * N if out is not None else 0.0) \
             + (6.0 * M * N if cp is not None else 0.0) + (4.0 * M * rc if R is not None else 0.0)
-        prof.append((e0, e1, 2.0 * M * N * K, nbytes))
+        prof.append((e0, e1, 2.0 * M * N * K, nbytes, "%dx%dx%d" % (M, N, K)))
     if want == "both":
         return out, out_planes
     return out if want == "f32" else out_planes
@@ -315,7 +315,8 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
                             1 if relu else 0, _p(out), ldc, M, N, K, _stream()), "gom_gemm_f32")
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N + (M * N if R is not None else 0))))
+        prof.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N + (M * N if R is not None else 0)),
+                     "%dx%dx%d" % (M, N, K)))
     return out
 
 

@@ -64,7 +64,9 @@ class GoMBatchPredictor:
         height, width = original_frames[0].shape[:2]
         frames = [resize_shortest_edge(np.ascontiguousarray(x), self.min_size, self.max_size)
                   for x in original_frames]
-        frames = [torch.as_tensor(x.astype("float32").transpose(2, 0, 1)) for x in frames]
+        # CHW float32, contiguous (the reference hands over the transposed VIEW, whose `.to(device)` inside the window first
+        # makes it contiguous on the host; doing that here, outside the window, lets the upload be one async copy per frame)
+        frames = [torch.as_tensor(np.ascontiguousarray(x.astype("float32").transpose(2, 0, 1))) for x in frames]
         inputs = [{"image": x, "height": height, "width": width, "video_id": 0} for x in frames]
         return inputs, (height, width)
 

@@ -71,3 +71,39 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.gom_match_fused_set_grid(0) == INVALID and L.gom_match_fused_set_grid(64) == 0
     assert L.gom_tracker_create(0, 0.2, 1, 1, 1, 1.0, None, 0, None, 0, 1024, 8, 1024) is None           # test_len < 1
     assert L.gom_tracker_create(6, 0.2, 1, 1, 1, 1.0, None, 1, None, 0, 1024, 8, 1024) is None           # layers without weights
+
+
+def test_library_has_no_packed_fp32_instructions():
+    """DESIGN.md "Tracker determinism": `v_pk_fma_f32` gave wrong low halves beside the bf16x6 GEMM kernel on MI355X, so
+    the device code is built with the packed-fp32 target feature off.  Checked on the disassembly of the shipped library."""
+    import shutil
+    import subprocess
+    from gomatching_amd import build
+    lib = build.build()
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    if not (os.path.exists(objdump) and os.path.exists(bundler) and os.path.exists(objcopy)):
+        pytest.skip("ROCm llvm tools not found")
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        total = 0
+        for src in build.SOURCES:
+            if not src.endswith(".hip") or src == "abi.hip":       # abi.hip holds no kernel
+                continue
+            obj = os.path.join(build.OBJ, src + ".o")
+            fat, co = os.path.join(tmp, src + ".fatbin"), os.path.join(tmp, src + ".co")
+            r = subprocess.run([objcopy, "--dump-section", ".hip_fatbin=" + fat, obj], capture_output=True, text=True)
+            if r.returncode != 0 and "not found" in r.stderr:      # host-only translation unit (no kernel)
+                continue
+            assert r.returncode == 0 and os.path.getsize(fat) > 0, (src, r.stderr)
+            r = subprocess.run([bundler, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                "--input=" + fat, "--output=" + co], capture_output=True, text=True)
+            assert r.returncode == 0 and os.path.getsize(co) > 0, (src, r.stderr)
+            dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout
+            assert "s_endpgm" in dis, src
+            bad = [l for l in dis.splitlines() if "v_pk_fma_f32" in l or "v_pk_add_f32" in l or "v_pk_mul_f32" in l]
+            assert not bad, (src, bad[:3])
+            total += dis.count("s_endpgm")
+        assert total > 50
+    assert os.path.exists(lib)

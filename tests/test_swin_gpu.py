@@ -98,7 +98,7 @@ def test_window_attention_vs_torch():
 
 
 @pytest.mark.parametrize("hw", [(96, 128), (90, 130)])
-def test_swin_end_to_end_clip_vs_oracle(gemm_mode, hw, request):
+def test_swin_end_to_end_clip_vs_oracle(gemm_mode, hw):
     """The whole path with the Swin-T backbone (build_swin_backbone) on a 6-frame clip against the CPU oracle: identical
     ids and characters, points within 1e-3 px.  90x130 needs every internal padding of Swin (patch embed to 4, windows
     to 7, odd maps in the merges); the reference never pads the batch itself (gom_lstmatcher.py:169)."""
@@ -106,12 +106,6 @@ def test_swin_end_to_end_clip_vs_oracle(gemm_mode, hw, request):
     from gomatching_amd.modeling import GoMatching
     from gomatching_amd.synth import make_clip
     from oracle import gom_oracle as O
-    if gemm_mode == "bf16x6" and hw == (90, 130):
-        # KNOWN OPEN ISSUE (DESIGN.md §5 "Tracker determinism", §8 item 1): in ~2 % of fresh processes the FIRST evaluation of
-        # the batched short-term scores differs while the detector graph of the next step replays, and on exactly this clip and
-        # back-end that flips a track id.  Non-strict: a pass is a pass; a mismatch is reported as xfail with both id lists.
-        request.applymarker(pytest.mark.xfail(strict=False, reason="first-evaluation irreproducibility of the batched "
-                                                                   "short-term scores (DESIGN.md §8 item 1)"))
     cfg = mini_cfg("icdar15", device=DEV)
     cfg.MODEL.BACKBONE.NAME = "build_swin_backbone"
     sd = synth_state_dict(cfg, seed=7, cls_bias={"detection_transformer.ctrl_point_class.0.bias": 0.8,

@@ -16,7 +16,8 @@ DEV = "cuda"
 mode = sys.argv[1] if len(sys.argv) > 1 else "bf16x6"
 ref_path = "gpurun_out/flake_ref_%s.pt" % mode
 ops.GEMM_MODE = mode
-switch = os.environ.get("FLAKE_SWITCH", "")
+switches = set(x for x in os.environ.get("FLAKE_SWITCH", "").split(",") if x)
+switch = next(iter(sorted(switches - {"prewarm_alloc", "fill_nan", "fill_zero", "prewarm_kernels"})), "")
 if switch == "nonative":
     ops.NATIVE_MATCHER = False
 if switch == "nobatched":
@@ -52,6 +53,29 @@ for hw in ((96, 128), (90, 130)):
         model.h2d_mode = switch[3:]
     if switch == "onestream":
         model._trk_stream = torch.cuda.current_stream()
+    if "prewarm_kernels" in switches:      # every kernel of the short-term path launched once before any detection
+        with torch.cuda.stream(model._tracker_stream()):
+            g = torch.Generator().manual_seed(1)
+            src = torch.randn((48, 1024), generator=g).to(DEV)
+            bx = (torch.rand((48, 4), generator=g) * 40).to(DEV)
+            bx[:, 2:] += bx[:, :2]
+            model.roi_heads.short_term_scores(src, [(0, 12, 12), (24, 12, 12)], bx, hw, h2d=model._h2d)
+        torch.cuda.synchronize()
+    if "prewarm_alloc" in switches:        # the tracker stream's allocator cache refilled after every detect_launch
+        real_launch2 = model.detect_launch
+
+        def launch2(inputs, tc_, _real=real_launch2, _m=model):
+            h = _real(inputs, tc_)
+            with torch.cuda.stream(_m._tracker_stream()):
+                xs = [torch.empty((n,), dtype=torch.uint8, device=DEV) for n in
+                      [512] * 32 + [1 << 14] * 16 + [1 << 18] * 16 + [1 << 20] * 8 + [4 << 20] * 4 + [24 << 20] * 2]
+                if "fill_nan" in switches or "fill_zero" in switches:      # what the recycled blocks hold when they are reused
+                    for x in xs:
+                        x.fill_(0xFF if "fill_nan" in switches else 0)
+                    torch.cuda.current_stream().synchronize()
+                del xs
+            return h
+        model.detect_launch = launch2
     if switch in ("emptycache", "syncafter", "zerows"):
         import gc
         real_launch = model.detect_launch
