@@ -1,0 +1,157 @@
+"""The META_ARCH class Detectron2 builds for `MODEL.META_ARCHITECTURE: "GoMatchingMI355X"`
+(counterpart of /root/reference/gomatching/modeling/meta_arch/gom_lstmatcher.py:113-190).
+
+    from gomatching_amd.compat import d2_register
+    d2_register.register()                    # into detectron2's META_ARCH_REGISTRY (or a registry handed in)
+    cfg.MODEL.META_ARCHITECTURE = "GoMatchingMI355X"
+    model = build_model(cfg); DetectionCheckpointer(model).load(cfg.MODEL.WEIGHTS)      # train_net.py:183-190, eval.py
+
+A real `nn.Module`: every weight of the reference's state dict is a parameter / buffer under the reference's own name, so
+the call sites that walk the module tree keep working unchanged --
+  * `model.roi_heads.rescoring_head.parameters()` / `model.detection_transformer.ctrl_point_class[-1].parameters()`
+    (train_net.py:97-104; the six head copies are ONE shared module, detection_transformer_wobackbone.py:141-153),
+  * `model.roi_heads.children()`, `model.parameters()` (gomatching/modeling/freeze_layers.py:20-37),
+  * `DetectionCheckpointer.load` -> `load_state_dict` (keys = the reference's; official DeepSolo checkpoints are renamed by
+    `weights.normalize_state_dict` with the rule of tools/decouple_deepsolo.py:13-19).
+Inference calls (`batch_inference`, `inference`, `_remove_short_track`, `batch_postprocess`, `run_*_match`, `min_track_len`)
+go to the HIP implementation, which is (re)built from the CURRENT parameter values whenever they changed since the last
+build.  `forward(batched_inputs)` is the reference's training entry (gom_lstmatcher.py:213-266): losses of the trainable
+head (`gomatching_amd/training.py`)."""
+import torch
+from torch import nn
+
+from ..config import CfgNode, _wrap
+from ..weights import canonical_keys, normalize_state_dict
+
+ARCH_NAME = "GoMatchingMI355X"
+_DELEGATED = ("batch_inference", "inference", "_remove_short_track", "batch_postprocess", "run_short_term_match",
+              "run_long_term_match", "detect_launch", "detect_finish", "track_frames", "begin_batch", "preprocess_image")
+
+
+class _Node(nn.Module):
+    """A container named like the reference's sub-module; numeric children index like an nn.ModuleList."""
+
+    def __getitem__(self, i):
+        return list(self._modules.values())[i]                  # (children() would drop the shared copies)
+
+    def __len__(self):
+        return len(self._modules)
+
+
+def _is_buffer(key):
+    # Detectron2's FrozenBatchNorm2d keeps weight / bias / running stats as buffers; so do the BatchNorm statistics of ViTAE
+    return ".norm." in key and key.startswith("backbone.") or key.endswith(("running_mean", "running_var", "num_batches_tracked"))
+
+
+def _cfg_of(cfg):
+    if isinstance(cfg, CfgNode):
+        return cfg
+    if hasattr(cfg, "dump") and hasattr(cfg, "items"):          # a yacs / Detectron2 CfgNode
+        import yaml
+        return _wrap(yaml.safe_load(cfg.dump()))
+    return _wrap(dict(cfg))
+
+
+class GoMatchingMI355X(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = _cfg_of(cfg)
+        V = self.cfg.VIDEO_TEST
+        self.min_track_len = V.MIN_TRACK_LEN
+        self.with_rescore = self.cfg.MODEL.ROI_HEADS.WITH_RESR
+        n_dec = self.cfg.MODEL.TRANSFORMER.DEC_LAYERS
+        shared = {}
+        for key, shape in canonical_keys(self.cfg).items():
+            parts = key.split(".")
+            node = self
+            for depth, p in enumerate(parts[:-1]):
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+                # the per-decoder-layer head copies of DeepSolo are one shared module listed n_dec times
+                if parts[0] == "detection_transformer" and depth == 1 and parts[1] in (
+                        "ctrl_point_class", "ctrl_point_coord", "ctrl_point_text", "boundary_offset") and parts[2] == "0":
+                    shared[parts[1]] = True
+            t = torch.zeros(tuple(shape), dtype=torch.float32)
+            if _is_buffer(key):
+                node.register_buffer(parts[-1], t)
+            else:
+                node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=parts[0] == "roi_heads"))
+        dt = self._modules.get("detection_transformer")
+        for name in shared:
+            lst = dt._modules[name]
+            for i in range(1, n_dec):
+                if str(i) not in lst._modules:
+                    lst.add_module(str(i), lst._modules["0"])        # same object: parameters() yields it once
+        self._impl = None
+        self._impl_version = None
+        self._device = torch.device(self.cfg.MODEL.DEVICE if self.cfg.MODEL.DEVICE != "cpu" else "cpu")
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict, strict=False, assign=False):
+        """Accepts the reference's checkpoints (incl. un-decoupled DeepSolo ones and the six expanded head copies)."""
+        sd = normalize_state_dict(dict(state_dict))
+        own = dict(self.named_parameters(remove_duplicate=True))
+        own.update(dict(self.named_buffers()))
+        missing, unexpected = [], []
+        with torch.no_grad():
+            for k, dst in own.items():
+                if k in sd:
+                    src = torch.as_tensor(sd[k]).to(dst.dtype)
+                    if tuple(src.shape) != tuple(dst.shape):
+                        raise RuntimeError("size mismatch for %s: checkpoint %s vs model %s" % (k, tuple(src.shape), tuple(dst.shape)))
+                    dst.copy_(src)
+                else:
+                    missing.append(k)
+        from ..weights import expand_for_reference
+        aliases = set(expand_for_reference({k: None for k in own}, self.cfg.MODEL.TRANSFORMER.DEC_LAYERS))
+        unexpected = [k for k in sd if k not in own and k not in aliases]       # the reference's duplicated head keys are fine
+        if strict and (missing or unexpected):
+            raise RuntimeError("missing keys %s, unexpected keys %s" % (missing[:5], unexpected[:5]))
+        self._impl = None
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def _version(self):
+        return tuple(p._version for p in self.parameters()) + (str(self._device),)
+
+    def impl(self):
+        """The HIP model, rebuilt when a parameter changed (optimizer step, checkpoint load, .to())."""
+        v = self._version()
+        if self._impl is None or self._impl_version != v:
+            from ..modeling import GoMatching
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("GoMatchingMI355X runs on an MI355X only: move the model to the GPU first (model.to('cuda'))")
+            sd = {k: t.detach() for k, t in self.state_dict().items()}
+            self._impl = GoMatching(self.cfg, sd, device=dev)
+            self._impl_version = v
+        return self._impl
+
+    def __getattr__(self, name):
+        if name in _DELEGATED:
+            return getattr(self.impl(), name)
+        return super().__getattr__(name)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    # ------------------------------------------------------------------ training entry
+    def forward(self, batched_inputs):
+        if not self.training:
+            raise RuntimeError("inference goes through batch_inference / inference (gom_lstmatcher.py:268,366), as in the "
+                               "reference; forward() is the training entry")
+        from .. import training
+        return training.forward_losses(self, batched_inputs)
+
+
+def register(registry=None):
+    """Register the class under ARCH_NAME in Detectron2's META_ARCH_REGISTRY (or in `registry`, any object with the fvcore
+    Registry interface)."""
+    if registry is None:
+        from detectron2.modeling.meta_arch.build import META_ARCH_REGISTRY as registry
+    try:
+        registry.register(GoMatchingMI355X)
+    except (AssertionError, KeyError):                           # already registered
+        pass
+    return GoMatchingMI355X

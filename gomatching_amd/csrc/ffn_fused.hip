@@ -1,0 +1,276 @@
+// Fused transformer FFN block on the fp16 matrix cores (f16x3 split, fp32-class accuracy):
+//
+//   Y = LayerNorm( X + relu(X W1^T + b1) W2^T + b2 ) * gamma + beta        X, Y [M, 256] fp32, hidden width F
+//
+// = `linear1 -> ReLU -> linear2 -> +residual -> norm` of every DeepSolo encoder / decoder layer
+// (/root/reference/third_party/adet/layers/deformable_transformer.py:250-251,266-273 encoder `forward_ffn` + norm2,
+//  :352-354,368-369 decoder `forward_ffn` + norm3).  As three launches (GEMM, GEMM, LayerNorm) the block moves
+// 1 + 4 | 4 + 1 + 1 | 1 + 1 = 13 KB per row through HBM for 1.05 MFLOP per row -- 80 FLOP/B, below the chip's balance, i.e.
+// HBM-bound at ~500 TFLOP/s even with perfect kernels.  Fused, the hidden activations never leave the CU: 2 KB per row.
+//
+// Structure (one workgroup = 4 waves = 128 rows, one wave per SIMD with the whole 512-register file):
+//   * each wave owns 32 rows.  Their two fp16 planes (x = x0 + x1, 22 significand bits: gemm_f16x3.hip) stay in 128 VGPRs for
+//     the whole kernel, already in the MFMA operand layout;
+//   * both products are computed TRANSPOSED so that the row of X is the LANE of every accumulator:
+//       H^T[32 hidden x 32 rows]  = W1c[32 x 256] . X^T        (A = weight fragment from LDS, B = X fragment in registers)
+//       Y^T[256 x 32 rows]       += W2[:, chunk] . H^T          (A = weight fragment from LDS, B = H^T)
+//     The accumulator of the first product IS the B operand of the second once its registers 8u..8u+7 are converted to fp16
+//     (cdna_hip_programming.md §3, "An accumulator tile as the next MFMA's operand"): no LDS round trip, no shuffle.  The k
+//     order that conversion implies (slot (h, j) of k-step u <-> hidden unit 16u + 8(j>>2) + 4h + (j&3)) is baked into the
+//     weight image, which costs nothing: the weights are constants;
+//   * the weights (2 x 2 planes x F x 256 fp16 = 2 MB at F = 1024, L2-resident) stream through a two-stage LDS ring by LDS-DMA
+//     (`global_load_lds_dwordx4`), one 65 KB stage per 32 hidden units.  The image is FRAGMENT-LINEAR: every MFMA operand
+//     fragment is one contiguous KB in the order the lanes read it, so the DMA is a linear copy and every ds_read_b128 is
+//     conflict-free by construction;
+//   * epilogue: Y^T goes through the (now free) LDS ring to row-major, then one wave per row applies the weight scale, bias,
+//     residual and the LayerNorm of norm.hip (same two-pass arithmetic) and stores whole 1 KB rows.
+// MFMA work per 128 rows: 4 waves x 3072 v_mfma_f32_32x32x16_f16; LDS reads 2/3 KB per MFMA; L2 -> LDS 2 MB.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int D = 256;                                   // model width (fixed: every shipped config)
+constexpr int CH = 32;                                   // hidden units per weight chunk
+constexpr int FRAG = 1024;                               // bytes of one MFMA operand fragment (64 lanes x 8 fp16)
+constexpr int W1_FRAGS = (D / 16) * 2;                   // k-steps x planes
+constexpr int W2_FRAGS = (D / 32) * (CH / 16) * 2;       // n-tiles x k-steps x planes
+constexpr int STAGE_FRAGS = W1_FRAGS + W2_FRAGS + 1;     // + one fragment of (1 / row scale, bias) of the chunk
+constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG;
+constexpr int BM = 128;
+constexpr int LDS_BYTES = 2 * STAGE_BYTES > BM * D * 4 ? 2 * STAGE_BYTES : BM * D * 4;
+
+struct FfnArgs {
+    const float* X;
+    const unsigned char* img;
+    const float* s2;
+    const float* b2;
+    const float* gamma;
+    const float* beta;
+    float* Y;
+    int* flag;
+    float eps;
+    int ldx, ldy, M, chunks;
+};
+
+__device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) {
+    const f32x2 v = {x, y};
+    const half2_t h0 = __builtin_convertvector(v, half2_t);
+    const f32x2 b = __builtin_convertvector(h0, f32x2);
+    const f32x2 r = {x - b[0], y - b[1]};
+    const half2_t h1 = __builtin_convertvector(r, half2_t);
+    q0 = __builtin_bit_cast(unsigned int, h0);
+    q1 = __builtin_bit_cast(unsigned int, h1);
+}
+
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8& p0, half8& p1) {
+    unsigned int l0, l1, l2, l3, h0, h1, h2, h3;
+    split2(a[0], a[1], l0, h0);
+    split2(a[2], a[3], l1, h1);
+    split2(b[0], b[1], l2, h2);
+    split2(b[2], b[3], l3, h3);
+    p0 = __builtin_bit_cast(half8, (u32x4{l0, l1, l2, l3}));
+    p1 = __builtin_bit_cast(half8, (u32x4{h0, h1, h2, h3}));
+}
+
+__device__ __forceinline__ void dma_fragment(const unsigned char* src_lane, unsigned char* lds_frag) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane,
+                                     (__attribute__((address_space(3))) void*)lds_frag, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const long row0 = (long)blockIdx.x * BM + wave * 32;
+
+    auto dma_stage = [&](int c, int stage) {                 // 65 fragments, dealt to the four waves
+        const unsigned char* src = p.img + (size_t)c * STAGE_BYTES + lane * 16;
+        unsigned char* dst = smem + stage * STAGE_BYTES;
+        for (int f = wave; f < STAGE_FRAGS; f += 4) dma_fragment(src + f * FRAG, dst + f * FRAG);
+    };
+    dma_stage(0, 0);
+
+    // ---- this wave's 32 rows of X as B-operand fragments: lane (r, h) holds X[row r][16 s + 8 h .. + 7], two planes -------
+    half8 xf[2][D / 16];
+    {
+        long r = row0 + fr;
+        if (r > p.M - 1) r = p.M - 1;                         // tail rows recompute the last row (never stored)
+        const float* xr = p.X + (size_t)r * p.ldx + fh * 8;
+#pragma unroll
+        for (int s = 0; s < D / 16; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
+            split8(a, b, xf[0][s], xf[1][s]);
+        }
+    }
+
+    f32x16 acc2[D / 32];
+#pragma unroll
+    for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc2[t][g] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int c = 0; c < p.chunks; ++c) {
+        const int st = c & 1;
+        if (c + 1 < p.chunks) dma_stage(c + 1, st ^ 1);
+        const unsigned char* base = smem + st * STAGE_BYTES + lane * 16;
+
+        // ---- H^T chunk = W1c . X^T : one accumulator, 16 k-steps x 3 plane products (smallest terms first) ----
+        f32x16 acc1;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc1[g] = 0.f;
+#pragma unroll
+        for (int s = 0; s < D / 16; ++s) {
+            const half8 w0 = *reinterpret_cast<const half8*>(base + (2 * s) * FRAG);
+            const half8 w1 = *reinterpret_cast<const half8*>(base + (2 * s + 1) * FRAG);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xf[0][s], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, xf[1][s], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, xf[0][s], acc1, 0, 0, 0);
+        }
+        // ---- relu(acc / row scale + bias), split into two fp16 planes: registers 8u..8u+7 are the B fragment of k-step u ----
+        const float* aux = reinterpret_cast<const float*>(smem + st * STAGE_BYTES + (W1_FRAGS + W2_FRAGS) * FRAG);
+        half8 hf[2][CH / 16];
+#pragma unroll
+        for (int u = 0; u < CH / 16; ++u) {
+            f32x4 v[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * u + qq;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(aux + 8 * q + 4 * fh);
+                const f32x4 bi = *reinterpret_cast<const f32x4*>(aux + CH + 8 * q + 4 * fh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[qq][e] = fmaxf(fmaf(acc1[4 * q + e], sc[e], bi[e]), 0.f);
+            }
+            split8(v[0], v[1], hf[0][u], hf[1][u]);
+        }
+        // ---- Y^T += W2[:, chunk] . H^T : eight independent accumulators ----
+#pragma unroll
+        for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+            for (int u = 0; u < CH / 16; ++u) {
+                const int f = W1_FRAGS + (t * (CH / 16) + u) * 2;
+                const half8 w0 = *reinterpret_cast<const half8*>(base + f * FRAG);
+                const half8 w1 = *reinterpret_cast<const half8*>(base + (f + 1) * FRAG);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, hf[0][u], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, hf[1][u], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, hf[0][u], acc2[t], 0, 0, 0);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of the next stage has landed
+        __syncthreads();                                     // ... and everybody's; nobody still reads this stage
+    }
+
+    // ---- epilogue: Y^T (row of X on the lane, output feature in the registers) -> row-major through LDS ----
+    float* stg = reinterpret_cast<float*>(smem);             // [128][256] fp32; 16-byte chunk c of row r at chunk c ^ (r & 7)
+    {
+        float* mine = stg + (wave * 32 + fr) * D;
+#pragma unroll
+        for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
+                const int chunk = 8 * t + 2 * q + fh;        // features 32 t + 8 q + 4 h .. + 3
+                *reinterpret_cast<f32x4*>(mine + ((chunk ^ (fr & 7)) << 2)) = v;
+            }
+    }
+    __syncthreads();
+    const f32x4 s2 = *reinterpret_cast<const f32x4*>(p.s2 + lane * 4);
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + lane * 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + lane * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + lane * 4);
+    int bad = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+        const long m = row0 + i;
+        if (m >= p.M) break;                                 // wave-uniform
+        f32x4 v = *reinterpret_cast<const f32x4*>(stg + (wave * 32 + i) * D + ((lane ^ (i & 7)) << 2));
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * p.ldx + lane * 4);
+        v = v * s2 + b2 + x;
+        const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / D);
+        const f32x4 d = v - mean;
+        const float rstd = rsqrtf(wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.f / D) + p.eps);
+        const f32x4 o = d * rstd * ga + be;
+        bad |= !(fabsf(o[0]) <= 3.4e38f) | !(fabsf(o[1]) <= 3.4e38f) | !(fabsf(o[2]) <= 3.4e38f) | !(fabsf(o[3]) <= 3.4e38f);
+        *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + lane * 4) = o;
+    }
+    if (bad && p.flag) atomicOr(p.flag, 1);                  // an activation left fp16's range (gemm_f16x3.hip contract)
+}
+
+// Fragment-linear weight image.  Per chunk c of 32 hidden units, 65 fragments of 1 KB; element j (0..7) of lane l = (r, h):
+//   f = 2 s + p      (s = 0..15)                 : plane p of W1s[32 c + r][16 s + 8 h + j]
+//   f = 32 + 4 t + 2 u + p  (t = 0..7, u = 0..1) : plane p of W2s[32 t + r][32 c + 16 u + 8 (j >> 2) + 4 h + (j & 3)]
+//   f = 64                                       : floats 0..31 = 1 / (row scale of W1s) of the chunk, 32..63 = b1 of the chunk
+// (W1s / W2s = the row-scaled planes of gom_split_f16x2).
+__global__ __launch_bounds__(256) void ffn_image_kernel(const unsigned short* __restrict__ p1, long ps1, int ld1,
+                                                        const float* __restrict__ inv1, const float* __restrict__ b1,
+                                                        const unsigned short* __restrict__ p2, long ps2, int ld2, int F,
+                                                        unsigned short* __restrict__ img) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;      // one fp16 element of the image
+    const long total = (long)(F / CH) * STAGE_FRAGS * 512;
+    if (i >= total) return;
+    const int e = (int)(i % 512), f = (int)((i / 512) % STAGE_FRAGS), c = (int)(i / (512L * STAGE_FRAGS));
+    const int l = e >> 3, j = e & 7, r = l & 31, h = l >> 5;
+    if (f < W1_FRAGS) {
+        const int s = f >> 1, pl = f & 1;
+        img[i] = p1[pl * ps1 + (size_t)(CH * c + r) * ld1 + 16 * s + 8 * h + j];
+    } else if (f < W1_FRAGS + W2_FRAGS) {
+        const int id = f - W1_FRAGS, t = id >> 2, u = (id >> 1) & 1, pl = id & 1;
+        img[i] = p2[pl * ps2 + (size_t)(32 * t + r) * ld2 + CH * c + 16 * u + 8 * (j >> 2) + 4 * h + (j & 3)];
+    } else {
+        const int fi = e >> 1;                                // float index inside the fragment (two fp16 slots per float)
+        float v = 0.f;
+        if (fi < CH) v = inv1[CH * c + fi];
+        else if (fi < 2 * CH) v = b1 ? b1[CH * c + fi - CH] : 0.f;
+        const unsigned bits = __builtin_bit_cast(unsigned, v);
+        img[i] = (unsigned short)((e & 1) ? (bits >> 16) : (bits & 0xffffu));
+    }
+}
+
+}  // namespace
+
+extern "C" long gom_ffn_fused_image_bytes(int d_model, int d_hidden) {
+    if (d_model != D || d_hidden <= 0 || (d_hidden % CH) != 0) return -1;
+    return (long)(d_hidden / CH) * STAGE_BYTES;
+}
+
+extern "C" int gom_ffn_fused_image(const void* w1_planes, long w1_plane_stride, int ld1, const float* w1_inv_scale,
+                                   const float* b1, const void* w2_planes, long w2_plane_stride, int ld2, int d_model,
+                                   int d_hidden, void* image, long image_bytes, void* stream) {
+    GOM_CHECK_ARG(w1_planes && w1_inv_scale && w2_planes && image);
+    GOM_CHECK_ARG(d_model == D && d_hidden > 0 && (d_hidden % CH) == 0 && ld1 >= D && ld2 >= d_hidden);
+    GOM_CHECK_ARG(image_bytes >= gom_ffn_fused_image_bytes(d_model, d_hidden));
+    const long total = (long)(d_hidden / CH) * STAGE_FRAGS * 512;
+    hipLaunchKernelGGL(ffn_image_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)w1_planes, w1_plane_stride, ld1, w1_inv_scale, b1,
+                       (const unsigned short*)w2_planes, w2_plane_stride, ld2, d_hidden, (unsigned short*)image);
+    return gom_launch_status();
+}
+
+extern "C" int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, const float* w2_inv_scale, const float* b2,
+                                    const float* gamma, const float* beta, float eps, float* Y, int ldy, int M, int d_model,
+                                    int d_hidden, int* flag, void* stream) {
+    GOM_CHECK_ARG(X && image && w2_inv_scale && b2 && gamma && beta && Y);
+    GOM_CHECK_ARG(M >= 0 && d_model == D && d_hidden > 0 && (d_hidden % CH) == 0);
+    GOM_CHECK_ARG(ldx >= D && ldy >= D && (ldx % 4) == 0 && (ldy % 4) == 0);
+    GOM_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)image % 16) == 0);
+    if (M == 0) return GOM_OK;
+    FfnArgs a{};
+    a.X = X; a.img = (const unsigned char*)image; a.s2 = w2_inv_scale; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = Y;
+    a.flag = flag; a.eps = eps; a.ldx = ldx; a.ldy = ldy; a.M = M; a.chunks = d_hidden / CH;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    return gom_launch_status();
+}

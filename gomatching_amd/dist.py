@@ -8,7 +8,7 @@ A clip of F*world frames is split into contiguous blocks of F frames per rank.  
 and runs the tracker replicated (deterministic => no broadcast of ids needed).
 
 Record layout, fp32, per frame: [nq + 1, D] with D = F_reid + 4 + 1 + 2P + 4P + P
-    row 0       : [count, 0, ...]
+    row 0       : [count, image height, image width, 0, ...]   (frames of different ranks may differ in size: BASELINE config 5)
     rows 1..nq  : reid[F_reid] | box[4] | score | ctrl[2P] | bd[4P] | recs[P]   (first `count` rows valid)
 = 0.48 MB/frame at nq=100 (1.45 MB at nq=300): the exchange is latency-bound on xGMI, hence one fused
 buffer per step rather than per-field collectives.
@@ -24,13 +24,23 @@ def record_dim(feature_dim, num_points):
 
 
 def pack_records(dets, nq, feature_dim, num_points, device):
-    """dets: list of per-frame Instances from GoMatching.inference -> [F, nq+1, D] fp32 on `device`."""
+    """dets: list of per-frame Instances from GoMatching.inference -> [F, nq+1, D] fp32 on `device`.
+    Frames that come straight out of `GoMatching.detect_finish` (one step: nq-padded device arrays + consecutive pool rows)
+    are packed by ONE kernel (csrc/records.hip); anything else takes the generic per-field path."""
     P = num_points
     D = record_dim(feature_dim, P)
+    g0 = getattr(dets[0], "_gom", None) if dets else None
+    det = g0.get("det") if g0 else None
+    if det is not None and det["ctrl"].is_cuda and all(
+            getattr(r, "_gom", None) is not None and r._gom.get("det") is det and r._gom.get("b") == b
+            and r.image_size == dets[0].image_size for b, r in enumerate(dets)) and len(dets) == det["count"].numel():
+        from . import ops
+        return ops.pack_records(g0["pool"], g0["row0"], det, len(dets), nq, feature_dim, P, dets[0].image_size)
     buf = torch.zeros((len(dets), nq + 1, D), dtype=torch.float32, device=device)
     for f, r in enumerate(dets):
         n = len(r)
         buf[f, 0, 0] = float(n)
+        buf[f, 0, 1], buf[f, 0, 2] = float(r.image_size[0]), float(r.image_size[1])
         if n == 0:
             continue
         o = 0
@@ -45,9 +55,11 @@ def pack_records(dets, nq, feature_dim, num_points, device):
 
 def unpack_records(buf, image_size, feature_dim, num_points):
     """[F, nq+1, D] -> list of Instances (device tensors are views into `buf` / into per-call bulk conversions, so
-    the number of kernels does not grow with F) with host mirrors attached."""
+    the number of kernels does not grow with F) with host mirrors attached.  Every frame takes its image size from its own
+    record header (`image_size` is only the fall-back for records written without one)."""
     P = num_points
-    counts = buf[:, 0, 0].cpu().numpy().astype(np.int64)
+    hdr = buf[:, 0, :3].cpu().numpy()
+    counts = hdr[:, 0].astype(np.int64)
     small = buf[:, 1:, feature_dim:feature_dim + 5].cpu().numpy()          # boxes + score, one D2H
     o_rec = feature_dim + 5 + 6 * P
     recs_all = buf[:, 1:, o_rec:o_rec + P].to(torch.int64)                  # one conversion for every frame
@@ -58,7 +70,8 @@ def unpack_records(buf, image_size, feature_dim, num_points):
         n = int(counts[f])
         row = buf[f, 1:n + 1]
         o = feature_dim
-        r = Instances(image_size)
+        hw = (int(hdr[f, 1]), int(hdr[f, 2])) if hdr[f, 1] > 0 and hdr[f, 2] > 0 else image_size
+        r = Instances(hw)
         r.reid_features = row[:, :feature_dim]
         r.pred_boxes = Boxes(row[:, o:o + 4])
         r.scores = row[:, o + 4]

@@ -41,6 +41,10 @@ SIGNATURES = {
     "gom_split_f16x2": (I, [P, I, I, I, P, I, P, P]),
     "gom_gemm_f32_f16x3": (I, [P, P, I, P, L, I, P, P, P, P, I, I, I, P, I, I, I, I, P, P]),
     "gom_conv2d_nhwc_f32_f16x3": (I, [P, P, L, I, P, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, L, I, P, P]),
+    "gom_ffn_fused_image_bytes": (L, [I, I]),
+    "gom_ffn_fused_image": (I, [P, L, I, P, P, P, L, I, I, I, P, L, P]),
+    "gom_ffn_fused_ln_f32": (I, [P, I, P, P, P, P, P, F, P, I, I, I, I, P, P]),
+    "gom_pack_records_f32": (I, [P, I, I, P, P, P, P, P, P, I, I, I, I, F, F, P, P]),
     "gom_layernorm_f32": (I, [P, P, P, P, P, L, I, F, P]),
     "gom_groupnorm32_nhwc_f32": (I, [P, P, P, P, P, L, I, I, I, F, P]),
     "gom_mha_core_f32": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.POINTER(c_long), P]),

@@ -69,6 +69,14 @@ class DeepSolo:
         def norm(name):                                      # LayerNorm gain / bias stay plain fp32 vectors
             return g(name + ".weight"), g(name + ".bias")
 
+        def ffn(p, norm_name):
+            """linear1 -> ReLU -> linear2 -> + residual -> norm as ONE launch (csrc/ffn_fused.hip) under the f16x3 back-end:
+            the hidden activations never reach HBM (13 KB -> 2 KB per token).  None: the three-launch path."""
+            if ops.GEMM_MODE != "f16x3" or not ops.FUSED_FFN or T.DIM_FEEDFORWARD % 32:
+                return None
+            return ops.FusedFFN(g(p + "linear1.weight"), g(p + "linear1.bias"), g(p + "linear2.weight"),
+                                g(p + "linear2.bias"), g(p + norm_name + ".weight"), g(p + norm_name + ".bias"))
+
         def msda(name):
             w = torch.cat([sd[prefix + name + ".sampling_offsets.weight"],
                            sd[prefix + name + ".attention_weights.weight"]], 0)
@@ -85,7 +93,7 @@ class DeepSolo:
         for i in range(self.n_enc):
             p = t + "encoder.layers.%d." % i
             self.enc.append({"attn": msda(p + "self_attn"), "norm1": norm(p + "norm1"), "lin1": lin(p + "linear1"),
-                             "lin2": lin(p + "linear2"), "norm2": norm(p + "norm2")})
+                             "lin2": lin(p + "linear2"), "norm2": norm(p + "norm2"), "ffn": ffn(p, "norm2")})
         self.dec = []
         for i in range(self.n_dec):
             p = t + "decoder.layers.%d." % i
@@ -95,7 +103,8 @@ class DeepSolo:
                 "inter_in": (ops.prep_weight(g(p + "attn_inter.in_proj_weight")), g(p + "attn_inter.in_proj_bias")),
                 "inter_out": lin(p + "attn_inter.out_proj"), "norm_inter": norm(p + "norm_inter"),
                 "cross": msda(p + "attn_cross"), "norm_cross": norm(p + "norm_cross"),
-                "lin1": lin(p + "linear1"), "lin2": lin(p + "linear2"), "norm3": norm(p + "norm3")})
+                "lin1": lin(p + "linear1"), "lin2": lin(p + "linear2"), "norm3": norm(p + "norm3"),
+                "ffn": ffn(p, "norm3")})
         # all six cross-attention value projections as one [6*256, 256] weight
         vp = [t + "decoder.layers.%d.attn_cross.value_proj" % i for i in range(self.n_dec)]
         self.dec_value_w = ops.prep_weight(torch.cat([g(n + ".weight") for n in vp], 0).contiguous())
@@ -227,6 +236,9 @@ class DeepSolo:
             samp = ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, geo["vr"])
             x = ops.gemm(samp, L["attn"]["out"][0], bias=L["attn"]["out"][1], R=src)
             src = ops.layernorm(x, *L["norm1"])
+            if L["ffn"] is not None:
+                src = ops.ffn_fused_ln(src, L["ffn"])
+                continue
             h = ops.gemm(src, L["lin1"][0], bias=L["lin1"][1], relu=True)
             x = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=src)
             src = ops.layernorm(x, *L["norm2"])
@@ -290,9 +302,12 @@ class DeepSolo:
                                       nq * P, vr)
             x = ops.gemm(samp, L["cross"]["out"][0], bias=L["cross"]["out"][1], R=tgt)
             tgt = ops.layernorm(x, *L["norm_cross"])
-            h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True)
-            x = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt)
-            tgt = ops.layernorm(x, *L["norm3"])
+            if L["ffn"] is not None:
+                tgt = ops.ffn_fused_ln(tgt, L["ffn"])
+            else:
+                h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True)
+                x = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt)
+                tgt = ops.layernorm(x, *L["norm3"])
             # reference refinement (:484-488)
             d = self._mlp3(tgt, self.ctrl_coord)
             refs = ops.ref_sigmoid(d, refs, 2)

@@ -354,7 +354,8 @@ class GoMatching:
             r.ctrl_points = det["ctrl"][b, :n]
             r.recs = det["recs"][b, :n]
             r.bd = det["bd"][b, :n]
-            r._gom = {"boxes": boxes_h[b, :n].copy(), "scores": scores_h[b, :n].copy(), "row0": off, "ids": None}
+            r._gom = {"boxes": boxes_h[b, :n].copy(), "scores": scores_h[b, :n].copy(), "row0": off, "ids": None,
+                      "det": det, "b": b, "pool": self._pool}       # lets dist.pack_records pack the step in one launch
             results.append(r)
             off += n
         return results

@@ -377,6 +377,47 @@ def groupnorm32_into(x, gamma, beta, out_view, out_batch_stride, eps=1e-5):
                                         eps, _stream()), "gom_groupnorm32_nhwc_f32")
 
 
+FUSED_FFN = True         # f16x3 back-end: FFN blocks as one fused launch (False: GEMM, GEMM, LayerNorm)
+
+
+class FusedFFN:
+    """Weights of one `linear1 -> ReLU -> linear2 -> + residual -> LayerNorm` block prepared for gom_ffn_fused_ln_f32: the
+    fragment-linear image of both weight matrices + what the epilogue needs.  Built once per layer (f16x3 mode only)."""
+
+    def __init__(self, w1, b1, w2, b2, gamma, beta, eps=1e-5):
+        F_, D_ = w1.shape
+        assert w2.shape == (D_, F_)
+        nbytes = _L().gom_ffn_fused_image_bytes(D_, F_)
+        if nbytes < 0:
+            raise _lib_mod.GomError("fused FFN kernel does not serve d_model %d / d_hidden %d" % (D_, F_))
+        s1, s2 = split_weight(w1.contiguous(), kind="f16x3"), split_weight(w2.contiguous(), kind="f16x3")
+        self.image = torch.empty((nbytes,), dtype=torch.uint8, device=w1.device)
+        p1, p2 = s1.planes, s2.planes
+        check(_L().gom_ffn_fused_image(_p(p1), p1.stride(0), p1.stride(1), _p(s1.inv_scale), _p(b1), _p(p2), p2.stride(0),
+                                       p2.stride(1), D_, F_, _p(self.image), nbytes, _stream()), "gom_ffn_fused_image")
+        self.inv2, self.b2, self.gamma, self.beta, self.eps = s2.inv_scale, b2, gamma, beta, eps
+        self.D, self.F = D_, F_
+
+
+def ffn_fused_ln(x, ffn, out=None):
+    """LayerNorm(x + FFN(x)) in one launch (csrc/ffn_fused.hip); x [M, 256] row-strided."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == ffn.D and x.dtype == _f32
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty((M, ffn.D), dtype=_f32, device=x.device)
+    prof = _gemm_profile if (_gemm_profile is not None and M > 0) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().gom_ffn_fused_ln_f32(_p(x), x.stride(0) if M > 1 else ffn.D, _p(ffn.image), _p(ffn.inv2), _p(ffn.b2),
+                                    _p(ffn.gamma), _p(ffn.beta), ffn.eps, _p(out), out.stride(0) if M > 1 else ffn.D, M,
+                                    ffn.D, ffn.F, _p(range_flag(x.device)), _stream()), "gom_ffn_fused_ln_f32")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 4.0 * M * ffn.D * ffn.F, 8.0 * M * ffn.D + ffn.image.numel(), "ffn%dx%dx%d" % (M, ffn.D, ffn.F)))
+    return out
+
+
 # ------------------------------------------------------------------------------------------ MSDA
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
     """Same signature as the reference's adet._C.ms_deform_attn_forward (im2col_step accepted, unused)."""
@@ -843,6 +884,19 @@ def track_score(act, meta, decay, boxes, img_w, img_h, n_k, Np, M, with_iou, max
                                    n_k, Np, M, 1 if with_iou else 0, float(max_center_dist), _p(traj), _stream()),
           "gom_track_score_f32")
     return traj
+
+
+def pack_records(pool, row_base, det, frames, nq, feature_dim, num_points, image_size):
+    """One launch: a step's detections (the nq-padded arrays of detect_post + their pool rows) -> [frames, nq+1, D] fp32."""
+    D = feature_dim + 5 + 7 * num_points
+    out = torch.empty((frames, nq + 1, D), dtype=_f32, device=pool.device)
+    recs = det["recs"]
+    assert recs.dtype == torch.int64 and recs.is_contiguous() and det["ctrl"].is_contiguous() and det["bd"].is_contiguous()
+    check(_L().gom_pack_records_f32(_p(pool), pool.stride(0), int(row_base), _p(det["count"]), _p(det["boxes"]),
+                                    _p(det["scores"]), _p(det["ctrl"]), _p(det["bd"]), _p(recs), frames, nq, feature_dim,
+                                    num_points, float(image_size[0]), float(image_size[1]), _p(out), _stream()),
+          "gom_pack_records_f32")
+    return out
 
 
 BATCHED_SHORT_TERM = True  # False: per-pair kernels (kept for the A/B parity test and for > 320 detections per frame)

@@ -123,6 +123,23 @@ int gom_conv2d_nhwc_f32_f16x3(const float* X, const void* Wplanes, long w_plane_
                               int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
                               long workspace_bytes, int splits, int* flag, void* stream);
 
+/* Fused FFN block of a DeepSolo transformer layer (deformable_transformer.py:250-251,266-273 encoder linear1/ReLU/linear2 +
+ * residual + norm2; :352-354,368-369 decoder + norm3):
+ *     Y = LayerNorm(X + relu(X W1^T + b1) W2^T + b2) * gamma + beta,   X, Y [M, d_model] fp32 (row strides ldx / ldy; Y may
+ * alias X), d_model = 256, d_hidden a multiple of 32, on the f16x3 scheme of gom_gemm_f32_f16x3 (same accuracy and range
+ * contract, same *flag).  The hidden activations never leave the CU (csrc/ffn_fused.hip).
+ * gom_ffn_fused_image: one-time weight preparation -- the two gom_split_f16x2 plane sets (W1 [d_hidden, d_model] with its
+ * inverse row scales, W2 [d_model, d_hidden]) and b1 re-ordered into the kernel's fragment-linear stream
+ * (gom_ffn_fused_image_bytes bytes; -1 = shape not served).  gom_ffn_fused_ln_f32 additionally takes W2's inverse row
+ * scales and b2. */
+long gom_ffn_fused_image_bytes(int d_model, int d_hidden);
+int gom_ffn_fused_image(const void* w1_planes, long w1_plane_stride, int ld1, const float* w1_inv_scale, const float* b1,
+                        const void* w2_planes, long w2_plane_stride, int ld2, int d_model, int d_hidden, void* image,
+                        long image_bytes, void* stream);
+int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, const float* w2_inv_scale, const float* b2,
+                         const float* gamma, const float* beta, float eps, float* Y, int ldy, int M, int d_model,
+                         int d_hidden, int* flag, void* stream);
+
 /* Split-K form for convolutions with few output tiles and a long K (input_proj[3]: 3x3 s2 2048 -> 256 on res5, M = 3584,
  * K = 18432): `splits` K-slices run as separate workgroups into workspace [splits][M][Cout] fp32, a second kernel sums
  * them in slice order (deterministic) and applies the epilogue.  gom_conv_bf16x6_splits: recommended slice count, 0 =
@@ -370,6 +387,14 @@ int gom_tracker_run(void* tracker, int F, const int* n, const float* boxes, cons
 /* [host] rectangular assignment, SciPy-compatible tie-breaking (gom_lstmatcher.py:447,549).  Returns the number
  * of assigned pairs (min(nr,nc)) or a negative error. */
 int gom_linear_sum_assignment(const double* cost, long nr, long nc, long* row_ind, long* col_ind);
+
+/* Multi-GPU exchange: one launch packs a step's detections into the all-gather buffer [frames, nq + 1, D]
+ * fp32, D = feature_dim + 4 + 1 + 2 P + 4 P + P: row 0 of a frame = (count, image height, image width, 0...), rows 1..count =
+ * reid | box | score | ctrl | bd | recs, the rest zero.  The re-id rows of frame f start at pool row
+ * row_base + sum(counts[0..f)); boxes / scores / ctrl / bd / recs are the nq-padded arrays of gom_detect_post. */
+int gom_pack_records_f32(const float* pool, int ld_pool, int row_base, const int* counts, const float* boxes,
+                         const float* scores, const float* ctrl, const float* bd, const long* recs, int frames, int nq,
+                         int feature_dim, int num_points, float img_h, float img_w, float* out, void* stream);
 
 #ifdef __cplusplus
 }

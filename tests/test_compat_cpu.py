@@ -1,0 +1,61 @@
+"""CPU: the shipped binding stubs (gomatching_amd/compat) -- the op module's preconditions / dispatcher registration and the
+META_ARCH wrapper built against the shim registry of oracle/ref_shim.py, loaded from a synthetic checkpoint, serving the
+attribute paths the reference's training script walks (train_net.py:97-104, freeze_layers.py:20-37)."""
+import pytest
+import torch
+
+from helpers import mini_cfg
+from gomatching_amd.weights import synth_state_dict, expand_for_reference
+
+
+def test_adet_C_preconditions_and_dispatcher_registration():
+    from gomatching_amd.compat import adet_C
+    assert hasattr(torch.ops.gomatching, "ms_deform_attn_forward")
+    v = torch.zeros(2, 10, 8, 32)
+    shapes, lsi = torch.zeros(4, 2, dtype=torch.long), torch.zeros(4, dtype=torch.long)
+    loc, w = torch.zeros(2, 5, 8, 4, 4, 2), torch.zeros(2, 5, 8, 4, 4)
+    with pytest.raises(RuntimeError, match="CUDA"):              # ms_deform_attn_cuda.cu:34-38
+        adet_C.ms_deform_attn_forward(v, shapes, lsi, loc, w, 64)
+    with pytest.raises(RuntimeError, match="contiguous"):        # :28-32
+        adet_C.ms_deform_attn_forward(v.transpose(1, 2), shapes, lsi, loc, w, 64)
+    with pytest.raises(NotImplementedError):
+        adet_C.ms_deform_attn_backward(v, shapes, lsi, loc, w, v, 64)
+    # shape inference through the dispatcher (meta tensors): [B, Lq, M*D]
+    out = torch.ops.gomatching.ms_deform_attn_forward(v.to("meta"), shapes.to("meta"), lsi.to("meta"), loc.to("meta"),
+                                                      w.to("meta"), 64)
+    assert tuple(out.shape) == (2, 5, 256)
+    import sys
+    adet_C.install("adet_test_pkg._C")
+    assert sys.modules["adet_test_pkg._C"].ms_deform_attn_forward is adet_C.ms_deform_attn_forward
+
+
+def test_meta_arch_wrapper_in_the_shim_registry():
+    from oracle import ref_shim
+    from gomatching_amd.compat import d2_register
+    ref_shim.install()
+    from detectron2.modeling.meta_arch.build import META_ARCH_REGISTRY
+    d2_register.register(META_ARCH_REGISTRY)
+    cls = META_ARCH_REGISTRY.get(d2_register.ARCH_NAME)
+    cfg = mini_cfg("icdar15")
+    model = cls(cfg)
+    assert isinstance(model, torch.nn.Module)
+    sd = synth_state_dict(cfg, seed=3)
+    res = model.load_state_dict(expand_for_reference(sd))        # a reference checkpoint carries the six head copies
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in sd.items():
+        assert torch.equal(model.state_dict()[k], torch.as_tensor(v).float()), k
+    # train_net.py:97-104: rescoring head initialised from the (shared) last classifier copy
+    heads = model.detection_transformer.ctrl_point_class
+    assert len(heads) == cfg.MODEL.TRANSFORMER.DEC_LAYERS and heads[-1] is heads[0]
+    for pk, pq in zip(model.roi_heads.rescoring_head.parameters(), heads[-1].parameters()):
+        pk.data = pq.data.clone().detach()
+    assert torch.equal(model.roi_heads.rescoring_head.weight, torch.as_tensor(sd["detection_transformer.ctrl_point_class.0.weight"]))
+    # freeze_layers.py:20-37: only roi_heads trains; parameter counts of README / SURVEY (32.79 M for LSTMatcher)
+    names = [n for n, _ in model.roi_heads.named_children()]
+    assert names == ["asso_head", "rescoring_head", "long_term_matcher", "short_term_matcher"]
+    trainable = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert trainable == 32794881
+    assert all(not p.requires_grad for n, p in model.named_parameters() if not n.startswith("roi_heads."))
+    assert model.min_track_len == cfg.VIDEO_TEST.MIN_TRACK_LEN
+    with pytest.raises(RuntimeError, match="MI355X"):            # no CPU path: inference before .to('cuda') fails loudly
+        model.batch_inference([], 0, 0, [], {})

@@ -19,7 +19,7 @@ def _dets(rank, frames=3):
     out = []
     for f in range(frames):
         n = [5, 0, NQ][f % 3] if rank == 0 else [1, 7, 3][f % 3]
-        r = Instances((96, 128))
+        r = Instances((96, 128) if rank == 0 else (130, 90))         # ranks may hold frames of different sizes
         r.reid_features = torch.rand(n, F, generator=g)
         r.pred_boxes = Boxes(torch.rand(n, 4, generator=g) * 90)
         r.scores = torch.rand(n, generator=g)
@@ -47,6 +47,7 @@ def _worker(rank, world, port, q):
             for f in range(3):
                 a, b = got[r * 3 + f], exp[f]
                 ok &= len(a) == len(b)
+                ok &= a.image_size == b.image_size
                 ok &= torch.equal(a.reid_features, b.reid_features) and torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor)
                 ok &= torch.equal(a.scores, b.scores) and torch.equal(a.recs, b.recs) and torch.equal(a.bd, b.bd)
                 ok &= torch.equal(a.ctrl_points, b.ctrl_points)

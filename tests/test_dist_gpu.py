@@ -70,3 +70,25 @@ def test_sharded_equals_single_process():
     for rank, idc, ids, scores in res:
         assert idc == int(id_count), (rank, idc, id_count)
         assert ids == ref_ids, rank
+
+
+def test_pack_kernel_equals_generic_path_and_carries_image_size():
+    """A step straight out of detect_finish is packed by ONE kernel (csrc/records.hip); the result must equal the generic
+    per-field path bit for bit, and every frame's record must carry its own image size (mixed-size ranks, BASELINE config 5)."""
+    from gomatching_amd import dist as gdist
+    model, g = _model()
+    hw = tuple(int(v) for v in g["hw"])
+    T = model.cfg.MODEL.TRANSFORMER
+    model.begin_batch([], 4)
+    dets = model.detect_steps(_inputs(hw, 4), _tc())
+    assert all(d._gom.get("det") is dets[0]._gom["det"] for d in dets)
+    fast = gdist.pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, model.device)
+    for d in dets:                                            # hide the step handle: generic path
+        d._gom = dict(d._gom, det=None)
+    slow = gdist.pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, model.device)
+    torch.cuda.synchronize()
+    assert sum(len(d) for d in dets) > 0
+    assert torch.equal(fast, slow)
+    back = gdist.unpack_records(fast, (1, 1), model.roi_heads.feature_dim, T.NUM_POINTS)
+    assert all(b.image_size == hw for b in back)
+    assert [len(b) for b in back] == [len(d) for d in dets]
