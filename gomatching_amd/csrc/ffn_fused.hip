@@ -25,6 +25,8 @@
 //   * epilogue: Y^T goes through the (now free) LDS ring to row-major, then one wave per row applies the weight scale, bias,
 //     residual and the LayerNorm of norm.hip (same two-pass arithmetic) and stores whole 1 KB rows.
 // MFMA work per 128 rows: 4 waves x 3072 v_mfma_f32_32x32x16_f16; LDS reads 2/3 KB per MFMA; L2 -> LDS 2 MB.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -57,6 +59,24 @@ struct FfnArgs {
     int ldx, ldy, M, chunks;
 };
 
+// sum over the 16 lanes of a DPP row, result in every lane: quad swaps (xor 1, xor 2), then the two mirrors
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, int ctrl_tag) {
+        const int xi = __builtin_bit_cast(int, x);
+        int r;
+        if (ctrl_tag == 0) r = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+        else if (ctrl_tag == 1) r = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        else if (ctrl_tag == 2) r = __builtin_amdgcn_update_dpp(0, xi, 0x141, 0xF, 0xF, true);  // row_half_mirror
+        else r = __builtin_amdgcn_update_dpp(0, xi, 0x140, 0xF, 0xF, true);                     // row_mirror
+        return __builtin_bit_cast(float, r);
+    };
+    v += dpp(v, 0);
+    v += dpp(v, 1);
+    v += dpp(v, 2);
+    v += dpp(v, 3);
+    return v;
+}
+
 __device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) {
     const f32x2 v = {x, y};
     const half2_t h0 = __builtin_convertvector(v, half2_t);
@@ -77,11 +97,14 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8& p0, 
     p1 = __builtin_bit_cast(half8, (u32x4{h0, h1, h2, h3}));
 }
 
-__device__ __forceinline__ void dma_fragment(const unsigned char* src_lane, unsigned char* lds_frag) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane,
-                                     (__attribute__((address_space(3))) void*)lds_frag, 16, 0, 0);
+// One KB of the weight stream straight into LDS (buffer_load_dwordx4 ... lds).  The MUBUF form, not global_load_lds: hipcc
+// books a FLAT-segment LDS-DMA as "may return out of order" and from then on turns every counted s_waitcnt lgkmcnt(N) of the
+// loop into lgkmcnt(0), which serialises the fragment prefetch below (measured: no gain over three launches).
+__device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned byte_offset, unsigned char* lds_frag) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)byte_offset, 0, 0, 0);
 }
 
+template <int DIAG>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -89,14 +112,17 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     const int fr = lane & 31, fh = lane >> 5;
     const long row0 = (long)blockIdx.x * BM + wave * 32;
 
+    const __amdgpu_buffer_rsrc_t rs_img =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, p.chunks * STAGE_BYTES, 0x00020000);
     auto dma_stage = [&](int c, int stage) {                 // 65 fragments, dealt to the four waves
-        const unsigned char* src = p.img + (size_t)c * STAGE_BYTES + lane * 16;
+        const unsigned src = (unsigned)c * STAGE_BYTES + lane * 16;
         unsigned char* dst = smem + stage * STAGE_BYTES;
-        for (int f = wave; f < STAGE_FRAGS; f += 4) dma_fragment(src + f * FRAG, dst + f * FRAG);
+        for (int f = wave; f < STAGE_FRAGS; f += 4) dma_fragment(rs_img, src + f * FRAG, dst + f * FRAG);
     };
     dma_stage(0, 0);
 
     // ---- this wave's 32 rows of X as B-operand fragments: lane (r, h) holds X[row r][16 s + 8 h .. + 7], two planes -------
+    int range_bad = 0;                                       // an operand beyond fp16's range (gemm_f16x3.hip contract)
     half8 xf[2][D / 16];
     {
         long r = row0 + fr;
@@ -106,6 +132,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         for (int s = 0; s < D / 16; ++s) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s);
             const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) range_bad |= !(fabsf(a[e]) <= 65504.f) | !(fabsf(b[e]) <= 65504.f);
             split8(a, b, xf[0][s], xf[1][s]);
         }
     }
@@ -121,21 +149,43 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
 
     for (int c = 0; c < p.chunks; ++c) {
         const int st = c & 1;
-        if (c + 1 < p.chunks) dma_stage(c + 1, st ^ 1);
+        if ((DIAG == 0 || DIAG == 2) && c + 1 < p.chunks) dma_stage(c + 1, st ^ 1);     // DIAG 1: timing without the weight stream
         const unsigned char* base = smem + st * STAGE_BYTES + lane * 16;
 
+        // The 64 weight fragments of the chunk are consumed in eight groups of eight (four k-steps); with ONE wave per SIMD
+        // nothing else hides the LDS latency, so group g + 1 is read into the other register set BEFORE the twelve MFMAs of
+        // group g are issued (explicit two-deep software pipeline; the sched_group_barrier pairs pin that order -- left alone
+        // the compiler issues every fragment read right in front of its MFMAs: 2 reads, wait, 3 MFMAs, ... = 28 % MFMA busy).
+        half8 fa[8], fb[8];
+#define FFN_LOAD(dst, g)                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                          \
+        dst[i_] = *reinterpret_cast<const half8*>(base + ((g) * 8 + i_) * FRAG);
+#define FFN_PIN() \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         // ---- H^T chunk = W1c . X^T : one accumulator, 16 k-steps x 3 plane products (smallest terms first) ----
         f32x16 acc1;
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc1[g] = 0.f;
-#pragma unroll
-        for (int s = 0; s < D / 16; ++s) {
-            const half8 w0 = *reinterpret_cast<const half8*>(base + (2 * s) * FRAG);
-            const half8 w1 = *reinterpret_cast<const half8*>(base + (2 * s + 1) * FRAG);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xf[0][s], acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, xf[1][s], acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, xf[0][s], acc1, 0, 0, 0);
+#define FFN_GEMM1(src, g)                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+        const int s_ = (g) * 4 + i_;                                                                          \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_ + 1], xf[0][s_], acc1, 0, 0, 0);             \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[1][s_], acc1, 0, 0, 0);                 \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[0][s_], acc1, 0, 0, 0);                 \
+    }
+        if (DIAG == 2) {                                         // DIAG 2: timing of the weight stream alone
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            continue;
         }
+        FFN_LOAD(fa, 0)
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // group 0's reads come first, then (reads, MFMAs) pairs
+        FFN_LOAD(fb, 1) FFN_GEMM1(fa, 0) FFN_PIN()
+        FFN_LOAD(fa, 2) FFN_GEMM1(fb, 1) FFN_PIN()
+        FFN_LOAD(fb, 3) FFN_GEMM1(fa, 2) FFN_PIN()
+        FFN_LOAD(fa, 4) FFN_GEMM1(fb, 3) FFN_PIN()               // fa <- first group of W2 fragments
+        __builtin_amdgcn_sched_barrier(0);
         // ---- relu(acc / row scale + bias), split into two fp16 planes: registers 8u..8u+7 are the B fragment of k-step u ----
         const float* aux = reinterpret_cast<const float*>(smem + st * STAGE_BYTES + (W1_FRAGS + W2_FRAGS) * FRAG);
         half8 hf[2][CH / 16];
@@ -148,22 +198,33 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(aux + 8 * q + 4 * fh);
                 const f32x4 bi = *reinterpret_cast<const f32x4*>(aux + CH + 8 * q + 4 * fh);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[qq][e] = fmaxf(fmaf(acc1[4 * q + e], sc[e], bi[e]), 0.f);
+                for (int e = 0; e < 4; ++e) {
+                    if (DIAG == 3) { v[qq][e] = acc1[0] + (float)e; continue; }
+                    v[qq][e] = fmaxf(fmaf(acc1[4 * q + e], sc[e], bi[e]), 0.f);
+                    range_bad |= !(v[qq][e] <= 65504.f);       // beyond fp16 (or NaN): flagged, never a silent wrong result
+                }
             }
+            if (DIAG == 3) { hf[0][u] = __builtin_bit_cast(half8, u32x4{__builtin_bit_cast(unsigned, v[0][0]), 1u, 2u, 3u}); hf[1][u] = hf[0][u]; continue; }
             split8(v[0], v[1], hf[0][u], hf[1][u]);
         }
-        // ---- Y^T += W2[:, chunk] . H^T : eight independent accumulators ----
-#pragma unroll
-        for (int t = 0; t < D / 32; ++t)
-#pragma unroll
-            for (int u = 0; u < CH / 16; ++u) {
-                const int f = W1_FRAGS + (t * (CH / 16) + u) * 2;
-                const half8 w0 = *reinterpret_cast<const half8*>(base + f * FRAG);
-                const half8 w1 = *reinterpret_cast<const half8*>(base + (f + 1) * FRAG);
-                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, hf[0][u], acc2[t], 0, 0, 0);
-                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, hf[1][u], acc2[t], 0, 0, 0);
-                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, hf[0][u], acc2[t], 0, 0, 0);
-            }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- Y^T += W2[:, chunk] . H^T : eight independent accumulators; group g holds n-tiles 2g, 2g + 1 ----
+#define FFN_GEMM2(src, g)                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+        const int t_ = (g) * 2 + (i_ >> 1), u_ = i_ & 1;                                                      \
+        acc2[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_ + 1], hf[0][u_], acc2[t_], 0, 0, 0);     \
+        acc2[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], hf[1][u_], acc2[t_], 0, 0, 0);         \
+        acc2[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], hf[0][u_], acc2[t_], 0, 0, 0);         \
+    }
+        FFN_LOAD(fb, 5) FFN_GEMM2(fa, 0) FFN_PIN()
+        FFN_LOAD(fa, 6) FFN_GEMM2(fb, 1) FFN_PIN()
+        FFN_LOAD(fb, 7) FFN_GEMM2(fa, 2) FFN_PIN()
+        FFN_GEMM2(fb, 3)
+#undef FFN_LOAD
+#undef FFN_PIN
+#undef FFN_GEMM1
+#undef FFN_GEMM2
+        if (DIAG == 5) continue;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of the next stage has landed
         __syncthreads();                                     // ... and everybody's; nobody still reads this stage
     }
@@ -182,24 +243,50 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
             }
     }
     __syncthreads();
-    const f32x4 s2 = *reinterpret_cast<const f32x4*>(p.s2 + lane * 4);
-    const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + lane * 4);
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + lane * 4);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + lane * 4);
-    int bad = 0;
-#pragma unroll 4
-    for (int i = 0; i < 32; ++i) {
-        const long m = row0 + i;
-        if (m >= p.M) break;                                 // wave-uniform
-        f32x4 v = *reinterpret_cast<const f32x4*>(stg + (wave * 32 + i) * D + ((lane ^ (i & 7)) << 2));
-        const f32x4 x = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * p.ldx + lane * 4);
-        v = v * s2 + b2 + x;
-        const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / D);
-        const f32x4 d = v - mean;
-        const float rstd = rsqrtf(wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.f / D) + p.eps);
-        const f32x4 o = d * rstd * ga + be;
-        bad |= !(fabsf(o[0]) <= 3.4e38f) | !(fabsf(o[1]) <= 3.4e38f) | !(fabsf(o[2]) <= 3.4e38f) | !(fabsf(o[3]) <= 3.4e38f);
-        *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + lane * 4) = o;
+    // Row pass: FOUR rows per wave-instruction, 16 lanes per row, each lane four 16-byte column chunks (sub, sub + 16, ...):
+    // the two LayerNorm reductions run over 16 lanes with four DPP steps each (quad swaps + the two row mirrors) instead of
+    // six cross-lane permutes over the whole wave, and eight such groups per wave are independent chains the scheduler can
+    // overlap (one row per instruction with a 64-lane butterfly measured 21 % of the kernel).
+    const int sub = lane & 15, rsel = lane >> 4;
+    f32x4 s2[4], b2[4], ga[4], be[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int col = (sub + 16 * k) * 4;
+        s2[k] = *reinterpret_cast<const f32x4*>(p.s2 + col);
+        b2[k] = *reinterpret_cast<const f32x4*>(p.b2 + col);
+        ga[k] = *reinterpret_cast<const f32x4*>(p.gamma + col);
+        be[k] = *reinterpret_cast<const f32x4*>(p.beta + col);
+    }
+    int bad = range_bad;
+#pragma unroll 2
+    for (int g = 0; g < (DIAG == 4 ? 1 : 8); ++g) {
+        const int lr = wave * 32 + 4 * g + rsel;               // row inside the workgroup's tile
+        const long m = (long)blockIdx.x * BM + lr;
+        const long mc = m < p.M ? m : p.M - 1;                  // tail rows recompute the last row, never stored
+        f32x4 v[4];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = sub + 16 * k;
+            const f32x4 y = *reinterpret_cast<const f32x4*>(stg + lr * D + ((ch ^ (lr & 7)) << 2));
+            const f32x4 x = *reinterpret_cast<const f32x4*>(p.X + (size_t)mc * p.ldx + ch * 4);
+            v[k] = y * s2[k] + b2[k] + x;
+            sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        }
+        const float mean = row16_sum(sum) * (1.f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = v[k] - mean;
+            q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+        }
+        const float rstd = rsqrtf(row16_sum(q) * (1.f / D) + p.eps);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 o = v[k] * rstd * ga[k] + be[k];
+            bad |= !(fabsf(o[0]) <= 3.4e38f) | !(fabsf(o[1]) <= 3.4e38f) | !(fabsf(o[2]) <= 3.4e38f) | !(fabsf(o[3]) <= 3.4e38f);
+            if (m < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + (sub + 16 * k) * 4) = o;
+        }
     }
     if (bad && p.flag) atomicOr(p.flag, 1);                  // an activation left fp16's range (gemm_f16x3.hip contract)
 }
@@ -265,12 +352,22 @@ extern "C" int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, 
     FfnArgs a{};
     a.X = X; a.img = (const unsigned char*)image; a.s2 = w2_inv_scale; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = Y;
     a.flag = flag; a.eps = eps; a.ldx = ldx; a.ldy = ldy; a.M = M; a.chunks = d_hidden / CH;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-        attr_set = true;
+    static int diag = -1;
+    if (diag < 0) {
+        const char* e = getenv("GOM_FFN_DIAG");               // timing diagnostics only (results are wrong): 1 = no weight
+        diag = e ? atoi(e) : 0;                               // stream, 2 = weight stream alone
+        for (auto k : {(const void*)ffn_fused_kernel<0>, (const void*)ffn_fused_kernel<1>, (const void*)ffn_fused_kernel<2>,
+                       (const void*)ffn_fused_kernel<3>, (const void*)ffn_fused_kernel<4>, (const void*)ffn_fused_kernel<5>}) {
+            hipError_t er = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            if (er != hipSuccess) return GOM_ERR_HIP_BASE + (int)er;
+        }
     }
-    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    auto kern = ffn_fused_kernel<0>;
+    if (diag == 1) kern = ffn_fused_kernel<1>;
+    if (diag == 2) kern = ffn_fused_kernel<2>;
+    if (diag == 3) kern = ffn_fused_kernel<3>;
+    if (diag == 4) kern = ffn_fused_kernel<4>;
+    if (diag == 5) kern = ffn_fused_kernel<5>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return gom_launch_status();
 }

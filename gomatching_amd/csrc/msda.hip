@@ -17,6 +17,15 @@ namespace {
 
 constexpr int HEADS = 8, CH = 32, LEVELS = 4;
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, MI355X_MICROARCH.md), so with the plain
+// blockIdx -> query map every XCD's private L2 sees every 8th group of four queries: spatial neighbours, whose bilinear
+// corners are the same cache lines, sit on eight different L2s and every value line is fetched up to eight times.  This
+// bijective remap hands each XCD one contiguous eighth of the queries (a band of image rows per level) instead.  Speed only.
+__device__ __forceinline__ long xcd_contiguous_block(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (long)(xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 template <int POINTS>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(const float* __restrict__ value,
                                                        const int64_t* __restrict__ shapes,
@@ -24,7 +33,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ loc,
                                                        const float* __restrict__ attw, float* __restrict__ out,
                                                        int B, int Lq, long v_bs, int v_rs) {
-    const long q_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per (b, q)
+    const long q_global = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);   // one wave per (b, q)
     if (q_global >= (long)B * Lq) return;
     const int lane = threadIdx.x & 63;
     const int m = lane >> 3;            // head
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float* __restrict
                                                          int B, int Lq, long v_bs, int v_rs,
                                                          const float* __restrict__ vr) {
     constexpr int LP = LEVELS * POINTS;
-    const long q_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long q_global = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     if (q_global >= (long)B * Lq) return;
     const int lane = threadIdx.x & 63;
     const int m = lane >> 3;

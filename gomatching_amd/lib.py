@@ -45,6 +45,10 @@ SIGNATURES = {
     "gom_ffn_fused_image": (I, [P, L, I, P, P, P, L, I, I, I, P, L, P]),
     "gom_ffn_fused_ln_f32": (I, [P, I, P, P, P, P, P, F, P, I, I, I, I, P, P]),
     "gom_pack_records_f32": (I, [P, I, I, P, P, P, P, P, P, I, I, I, I, F, F, P, P]),
+    "gom_relu_backward_f32": (I, [P, P, P, L, P]),
+    "gom_softmax_rows_backward_f32": (I, [P, P, P, L, I, L, F, P]),
+    "gom_asso_ce_f32": (I, [P, I, P, I, P, L, P, P, P, P]),
+    "gom_sigmoid_focal_f32": (I, [P, P, F, F, L, P, P, P]),
     "gom_layernorm_f32": (I, [P, P, P, P, P, L, I, F, P]),
     "gom_groupnorm32_nhwc_f32": (I, [P, P, P, P, P, L, I, I, I, F, P]),
     "gom_mha_core_f32": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.POINTER(c_long), P]),

@@ -840,6 +840,44 @@ def softmax_rows_scaled_(x, cols, scale):
     return x
 
 
+def relu_backward(dy, y):
+    _chk_f32(dy, y)
+    dx = torch.empty_like(dy)
+    check(_L().gom_relu_backward_f32(_p(dy), _p(y), _p(dx), dy.numel(), _stream()), "gom_relu_backward_f32")
+    return dx
+
+
+def softmax_rows_backward(P, dP, cols, scale):
+    """dS = scale * P * (dP - rowsum(dP * P)) over the first `cols` columns of same-shape row-strided matrices."""
+    assert P.shape == dP.shape and P.stride() == dP.stride() and P.stride(1) == 1
+    dS = torch.zeros_like(P)
+    check(_L().gom_softmax_rows_backward_f32(_p(P), _p(dP), _p(dS), P.shape[0], cols, P.stride(0), float(scale), _stream()),
+          "gom_softmax_rows_backward_f32")
+    return dS
+
+
+def asso_ce(logits, frame_offsets, gt, want_loss=True, grad_scale=None):
+    """Per (row, frame) cross entropy with a zero background logit (lstmatcher.py:436-475) -> loss [rows, T] and / or
+    dlogits = grad_scale * (softmax - onehot); gt int32 [rows, T] (index in frame | n_t = background | -1 = not counted)."""
+    _chk_f32(logits)
+    R, T = gt.shape
+    assert gt.dtype == torch.int32 and gt.is_contiguous() and frame_offsets.dtype == torch.int32
+    loss = torch.empty((R, T), dtype=_f32, device=logits.device) if want_loss else None
+    dl = torch.zeros_like(logits) if grad_scale is not None else None
+    check(_L().gom_asso_ce_f32(_p(logits), logits.shape[1] if logits.dim() == 2 else 0, _p(frame_offsets), T, _p(gt), R,
+                               _p(loss), _p(grad_scale), _p(dl), _stream()), "gom_asso_ce_f32")
+    return loss, dl
+
+
+def sigmoid_focal(x, target, alpha, gamma, want_loss=True, want_grad=True):
+    _chk_f32(x, target)
+    loss = torch.empty_like(x) if want_loss else None
+    dx = torch.empty_like(x) if want_grad else None
+    check(_L().gom_sigmoid_focal_f32(_p(x), _p(target), float(alpha), float(gamma), x.numel(), _p(loss), _p(dx), _stream()),
+          "gom_sigmoid_focal_f32")
+    return loss, dx
+
+
 def transpose_into(x, out):
     """out[c, r] = x[r, c] for 2-D row-strided views (out may be wider than x has rows)."""
     assert x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1

@@ -88,53 +88,62 @@ class GoMBatchPredictor:
 
     @torch.no_grad()
     def __call__(self, original_frames, instances, batch_id, id_count, last_batch, time_cost, return_time=False):
-        inputs, (height, width) = (self.prepare_device if self.device_ingest else self.prepare)(original_frames)
-        return self.run_prepared(inputs, (height, width), instances, batch_id, id_count, last_batch, time_cost,
-                                 return_time)
+        """One batch of a video: host preparation (untimed), then the timed window."""
+        prepare = self.prepare_device if self.device_ingest else self.prepare
+        inputs, frame_hw = prepare(original_frames)
+        return self.run_prepared(inputs, frame_hw, instances, batch_id, id_count, last_batch, time_cost, return_time)
 
     @torch.no_grad()
     def run_prepared(self, inputs, hw, instances, batch_id, id_count, last_batch, time_cost, return_time=False):
-        """The timed window of the reference (:325-334)."""
-        start_time = time.time()
+        """The reference's timed window (text_track_visualizer.py:325-334): tracking of the batch and, on a video's last
+        batch, short-track removal + rescaling to the source resolution (booked under `post_process`)."""
+        window = _Stopwatch()
         instances, id_count = self.model.batch_inference(inputs, batch_id, id_count, instances, time_cost)
         if last_batch:
-            start = time.time()
+            post = _Stopwatch()
             if self.model.min_track_len > 0:
                 instances = self.model._remove_short_track(instances)
-            instances = self.model.batch_postprocess(instances, [hw for _ in range(len(instances))])
-            time_cost["post_process"] += time.time() - start
-        if return_time:
-            return instances, id_count, time.time() - start_time
-        return instances, id_count
+            instances = self.model.batch_postprocess(instances, [hw] * len(instances))
+            time_cost["post_process"] += post.seconds()
+        return (instances, id_count, window.seconds()) if return_time else (instances, id_count)
+
+
+class _Stopwatch:
+    def __init__(self):
+        self.t0 = time.time()
+
+    def seconds(self):
+        return time.time() - self.t0
 
 
 class TextDecoder:
-    """Character tables + `_ctc_decode_recognition` of the reference visualizer (:40-55,167-182)."""
+    """Character tables + the CTC-style collapse of the reference visualizer (`_ctc_decode_recognition`,
+    text_track_visualizer.py:40-55,167-182): class ids >= voc_size - 1 are blanks, a character is emitted when it follows a
+    blank or differs from its predecessor."""
 
     def __init__(self, voc_size, custom_dict=""):
         self.voc_size = voc_size
         if voc_size == 96:
-            self.labels = CTLABELS_96
+            table = CTLABELS_96
         elif voc_size == 37:
-            self.labels = CTLABELS_37
+            table = CTLABELS_37
         else:
             with open(custom_dict, "rb") as fp:
-                self.labels = pickle.load(fp)
-        assert int(voc_size - 1) == len(self.labels), \
-            "voc_size is not matched dictionary size, got {} and {}.".format(int(voc_size - 1), len(self.labels))
+                table = [chr(c) for c in pickle.load(fp)]          # the custom dictionaries store code points
+        if len(table) != int(voc_size - 1):
+            raise AssertionError("voc_size %d does not fit a dictionary of %d characters" % (voc_size, len(table)))
+        self.labels = table
+        self._table = np.asarray(table, dtype=object)
 
     def decode(self, rec):
-        last_char = "###"
-        s = ""
-        for c in rec:
-            c = int(c)
-            if c < self.voc_size - 1:
-                if last_char != c:
-                    s += self.labels[c] if self.voc_size in (37, 96) else str(chr(self.labels[c]))
-                    last_char = c
-            else:
-                last_char = "###"
-        return s
+        ids = np.asarray(rec, dtype=np.int64).reshape(-1)
+        if ids.size == 0:
+            return ""
+        char = ids < self.voc_size - 1
+        prev_ids = np.concatenate(([-1], ids[:-1]))
+        prev_char = np.concatenate(([False], char[:-1]))
+        emit = char & (~prev_char | (ids != prev_ids))             # run-length collapse, runs broken by blanks
+        return "".join(self._table[ids[emit]])
 
 
 def boundary_to_polygon(bd):

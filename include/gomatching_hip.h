@@ -396,6 +396,22 @@ int gom_pack_records_f32(const float* pool, int ld_pool, int row_base, const int
                          const float* scores, const float* ctrl, const float* bd, const long* recs, int frames, int nq,
                          int feature_dim, int num_points, float img_h, float img_w, float* out, void* stream);
 
+/* Training of the association head (only `roi_heads` trains, freeze_layers.py:20-37) -- the pieces that are
+ * not contractions (those run on gom_gemm_f32 with transposed operands, gomatching_amd/training.py):
+ *   gom_relu_backward_f32          dx = y > 0 ? dy : 0
+ *   gom_softmax_rows_backward_f32  dS = scale * P * (dP - rowsum(dP * P))                     (attention backward)
+ *   gom_asso_ce_f32                detr_asso_loss's per-frame cross entropy with a zero background logit (lstmatcher.py:
+ *                                  436-475): per (row, frame) loss and / or dlogits = *grad_scale * (softmax - onehot);
+ *                                  gt[row*T + t] = target index inside frame t, n_t = background, < 0 = pair not counted
+ *   gom_sigmoid_focal_f32          loss_res's sigmoid focal loss per element (lstmatcher.py:237-268) and / or d loss / d x */
+int gom_relu_backward_f32(const float* dy, const float* y, float* dx, long n, void* stream);
+int gom_softmax_rows_backward_f32(const float* P, const float* dP, float* dS, long rows, int cols, long ld, float scale,
+                                  void* stream);
+int gom_asso_ce_f32(const float* logits, int ld, const int* frame_offsets, int num_frames, const int* gt, long rows,
+                    float* loss, const float* grad_scale, float* dlogits, void* stream);
+int gom_sigmoid_focal_f32(const float* x, const float* target, float alpha, float gamma, long n, float* loss, float* dx,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,3 +73,40 @@ def test_allgather_records_world2():
         p.join(60)
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2], "ranks hold different gathered records"
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gomatching_amd.training import allreduce_gradients
+        g = torch.Generator().manual_seed(7)
+        params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in ((5, 3), (7,), (2, 2, 2))]
+        frozen = torch.nn.Parameter(torch.randn(4, generator=g))                     # no gradient: left alone
+        for i, p in enumerate(params):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        n = allreduce_gradients(params + [frozen])
+        ok = n == sum(p.numel() for p in params) and frozen.grad is None
+        for i, p in enumerate(params):
+            ok &= bool(torch.allclose(p.grad, torch.full_like(p, (1 + 2) / 2 * (i + 1))))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    """The data-parallel reduction of the head's gradients (gomatching_amd/training.py: one flattened bucket, averaged)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res), res

@@ -1,0 +1,111 @@
+"""GPU, slow: ONE full-size frame of every BASELINE configuration against the CPU oracle --
+C1 640x640 fed directly (GoMatching_ICDAR15), C4 1280x2276 / 300 queries / GoMatching++ (SHA_FFN_CRSATTN, no rescoring,
+NMS 0.3), C5 bilingual head (voc 5462) at 1000x1778: identical detections and characters, scores within 1e-5, boundary /
+control points within 1e-3 px, re-id embeddings within 1e-4.  Plus the f16x3 accuracy contract on weights with a
+trained-like dynamic range (per-layer scales spanning 1e-4 .. 1e2, LayerNorm gains != 1)."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from gomatching_amd.config import setup_cfg
+from gomatching_amd.weights import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _tc():
+    return {k: 0.0 for k in ("pre_process", "backbone", "detector", "rescore", "tracker", "short_match", "long_match")}
+
+
+def _frame(hw, seed):
+    from gomatching_amd.synth import make_clip
+    return torch.as_tensor(make_clip(1, hw[0], hw[1], clip_id=seed, num_rects=10)[0].astype("float32").transpose(2, 0, 1).copy())
+
+
+def _calibrated_sd(cfg, seed, image, frac=0.3):
+    """Random-init DeepSolo detects nothing (class bias -log 99): shift the class (and rescoring) bias so that ~30 % of the
+    queries pass the threshold on this frame -- the bench's calibration, done once on the GPU path."""
+    from gomatching_amd.modeling import GoMatching
+    sd = synth_state_dict(cfg, seed=seed)
+    model = GoMatching(cfg, sd, device=DEV, frames_per_step=1, use_graphs=False)
+    x, _ = model.preprocess_image([{"image": image}])
+    feats = model.backbone.forward(x)
+    out = model.detection_transformer.forward([feats[k] for k in model.feature_names])
+    T = cfg.MODEL.TRANSFORMER
+    thr = model.test_score_threshold
+    lt = float(np.log(thr / (1 - thr)))
+    m = out["pred_logits"].view(T.NUM_QUERIES, T.NUM_POINTS).mean(1)
+    k = "detection_transformer.ctrl_point_class.0.bias"
+    sd[k] = sd[k] + (lt - float(torch.quantile(m, 1 - frac)))
+    if model.with_rescore:
+        r = model.roi_heads.rescoring_head(out["query_features"]).view(T.NUM_QUERIES, T.NUM_POINTS).mean(1)
+        sd["roi_heads.rescoring_head.bias"] = sd["roi_heads.rescoring_head.bias"] + (lt - float(torch.quantile(r, 1 - frac * 0.6)))
+    del model
+    torch.cuda.empty_cache()
+    return sd
+
+
+def _compare(cfg, builtin, sd, image, px_tol=1e-3):
+    from gomatching_amd.modeling import GoMatching
+    from oracle import gom_oracle as O
+    model = GoMatching(cfg, sd, device=DEV, frames_per_step=1)
+    got = model.inference([{"image": image}], _tc())[0]
+    ocfg = setup_cfg(builtin=builtin)
+    ocfg.MODEL.DEVICE = "cpu"
+    torch.set_num_threads(min(32, torch.get_num_threads() or 32))
+    with torch.no_grad():
+        ref = O.detect_frames(sd, ocfg, [image])[0]
+    assert len(got) == len(ref) and len(ref) > 0, (len(got), len(ref))
+    assert torch.equal(got.recs.cpu(), ref["recs"])
+    assert float((got.scores.cpu() - ref["scores"]).abs().max()) <= 1e-5
+    assert float((got.bd.cpu() - ref["bd"]).abs().max()) <= px_tol
+    assert float((got.ctrl_points.cpu() - ref["ctrl_points"]).abs().max()) <= px_tol
+    assert float((got.pred_boxes.tensor.cpu() - ref["pred_boxes"]).abs().max()) <= px_tol
+    assert float((got.reid_features.cpu() - ref["reid_features"]).abs().max()) <= 1e-4
+    return len(ref)
+
+
+@pytest.mark.parametrize("builtin,hw", [("icdar15", (640, 640)), ("pp_dstext", (1280, 2276)), ("bovtext", (1000, 1778))])
+def test_one_full_size_frame_vs_oracle(builtin, hw):
+    cfg = setup_cfg(builtin=builtin)
+    cfg.MODEL.DEVICE = DEV
+    image = _frame(hw, seed=zlib.crc32(builtin.encode()) % 1000)
+    sd = _calibrated_sd(cfg, seed=2, image=image)
+    n = _compare(cfg, builtin, sd, image)
+    assert n >= 3
+
+
+def test_f16x3_contract_on_trained_like_weight_ranges():
+    """Every weight matrix of the detector rescaled by a per-layer factor spanning 1e-4 .. 1e2 (compensated in the next
+    layer's input scale where the architecture has a normalisation, so activations stay finite), LayerNorm / GroupNorm gains
+    drawn from [0.3, 3]: the f16x3 back-end must still match the fp32 oracle on the 640x640 frame."""
+    cfg = setup_cfg(builtin="icdar15")
+    cfg.MODEL.DEVICE = DEV
+    image = _frame((640, 640), seed=11)
+    sd = synth_state_dict(cfg, seed=5)
+    rng = np.random.default_rng(1)
+    for k in list(sd):
+        v = torch.as_tensor(sd[k]).float()
+        if k.endswith("norm1.weight") or k.endswith("norm2.weight") or k.endswith("norm3.weight") or \
+                k.endswith("norm_intra.weight") or k.endswith("norm_inter.weight") or k.endswith("norm_cross.weight") or \
+                (".input_proj." in k and k.endswith(".1.weight")):
+            sd[k] = v * torch.as_tensor(rng.uniform(0.3, 3.0, size=v.shape).astype(np.float32))
+        elif k.endswith("linear1.weight") and "detection_transformer" in k:
+            # FFN: scale linear1 by s and linear2 by 1/s (ReLU is positively homogeneous): same function, weights and hidden
+            # activations s times larger / smaller -- exercises both the row scaling of the planes and the activation range
+            s = float(10.0 ** rng.uniform(-4, 2))
+            sd[k] = v * s
+            b = k.replace("linear1.weight", "linear1.bias")
+            sd[b] = torch.as_tensor(sd[b]).float() * s
+            w2 = k.replace("linear1.weight", "linear2.weight")
+            sd[w2] = torch.as_tensor(sd[w2]).float() / s
+    from gomatching_amd import ops
+    assert ops.GEMM_MODE == "f16x3"
+    sd_cal = dict(sd)
+    base = _calibrated_sd(cfg, seed=5, image=image)                # only for the two bias shifts
+    for k in ("detection_transformer.ctrl_point_class.0.bias", "roi_heads.rescoring_head.bias"):
+        sd_cal[k] = torch.as_tensor(sd[k]).float() + (torch.as_tensor(base[k]).float() - torch.as_tensor(synth_state_dict(cfg, seed=5)[k]).float())
+    _compare(cfg, "icdar15", sd_cal, image, px_tol=2e-3)
