@@ -11,7 +11,7 @@ eval.py drive it unchanged.  What differs is the schedule:
     (`gom_detect_post`), so there is one host sync per step, not several per frame;
   * the tracker keeps the reference's strictly sequential control flow and host-side integer id
     bookkeeping + assignment; its float arithmetic runs in HIP kernels.
-Training (`forward` returning losses) is out of scope and raises.
+`forward` (training: the loss dict of the trainable head) goes through gomatching_amd/training.py.
 """
 import os
 import time
@@ -70,6 +70,7 @@ class GoMatching:
         self.training = False
 
         sd = normalize_state_dict(state_dict)
+        self._head_state = {k: v for k, v in sd.items() if k.startswith("roi_heads.")}
         if cfg.MODEL.BACKBONE.NAME == "build_swin_backbone":
             if cfg.MODEL.SWIN.TYPE != "tiny":
                 raise NotImplementedError("only Swin-T is built (detection_transformer_wobackbone.py:61-64)")
@@ -97,7 +98,20 @@ class GoMatching:
         return self.forward(batched_inputs)
 
     def forward(self, batched_inputs):
-        raise NotImplementedError("training forward (losses) is outside the MI355X inference path (SURVEY.md §8-f4)")
+        """The reference's training entry (gom_lstmatcher.py:213-266): {'loss_long_asso', 'loss_short_asso'[, 'loss_res']} with
+        autograd history onto `trainable_parameters()` (only `roi_heads` trains, freeze_layers.py:20-37).  The frozen detector
+        runs on the inference kernels, the head's forward / backward on the HIP training path (gomatching_amd/training.py).
+        Under Detectron2 use the nn.Module wrapper `compat.d2_register.GoMatchingMI355X`, whose parameters are the live ones."""
+        from .. import training
+        return training.forward_losses(self, batched_inputs)
+
+    def trainable_parameters(self):
+        """{state-dict key: leaf tensor with requires_grad} of the trainable head, created from the loaded weights on first use.
+        Inference keeps using the weights the model was built with; rebuild the model to run inference with updated ones."""
+        if getattr(self, "_train_params", None) is None:
+            self._train_params = {k: torch.as_tensor(v).detach().float().to(self.device).clone().requires_grad_(True)
+                                  for k, v in self._head_state.items()}
+        return self._train_params
 
     # ------------------------------------------------------------------------------------ detection
     def _raw_input(self, batched_inputs, out=None):

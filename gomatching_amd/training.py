@@ -335,10 +335,9 @@ def asso_losses(params, cfg, frames, targets, prefix="roi_heads."):
     boxes = [f["proposal_boxes"][k].detach().cpu().numpy() for f, k in zip(frames, keep)]
     n_t = [int(len(k)) for k in keep]
     sizes = [tuple(f["image_size"]) for f in frames]
-    qf = [f["query_features"][k].reshape(len(k), -1) for f, k in zip(frames, keep)]
-    x = torch.cat(qf) if sum(n_t) else torch.zeros((0, frames[0]["query_features"][0].numel() if len(frames[0]["query_features"])
-                                                    else 25 * 256), device=dev)
-    x = x.to(dev).float().contiguous()
+    width = int(np.prod(frames[0]["query_features"].shape[1:]))                 # 25 points x 256 channels
+    qf = [f["query_features"][k].reshape(len(k), width) for f, k in zip(frames, keep)]
+    x = torch.cat(qf).to(dev).float().contiguous()
     for i in range(A.NUM_FC):
         x = _linear(x, params, prefix + "asso_head.fc%d" % (i + 1), relu=True)
     reid = x
@@ -425,10 +424,14 @@ def forward_losses(model, batched_inputs):
     torch = _torch()
     from . import ops
     from .predictor import new_time_cost
-    impl = model.impl()
+    if hasattr(model, "impl"):                                   # the META_ARCH wrapper: live nn.Parameters
+        impl = model.impl()
+        params = {k: p for k, p in model.named_parameters() if k.startswith("roi_heads.")}
+    else:                                                        # the HIP model itself: its own trainable copies
+        impl = model
+        params = model.trainable_parameters()
     cfg = model.cfg
     T = cfg.MODEL.TRANSFORMER
-    params = {k: p for k, p in model.named_parameters() if k.startswith("roi_heads.")}
     B, nq, P = len(batched_inputs), T.NUM_QUERIES, T.NUM_POINTS
     with torch.no_grad():
         tc = new_time_cost()
@@ -451,9 +454,9 @@ def forward_losses(model, batched_inputs):
     frames, targets, res_targets = [], [], []
     for b, inp in enumerate(batched_inputs):
         n = int(counts[b])
-        rows = torch.from_numpy(keep[b, :n].astype(np.int64)).to(qf.device)
+        rows = torch.from_numpy(keep[b, :n].astype(np.int64)).to(qf.device)      # rows of the flattened [B*nq] query axis
         frames.append({"image_size": kind[1], "proposal_boxes": det["boxes"][b, :n], "objectness_logits": det["scores"][b, :n],
-                       "query_features": qf[b].index_select(0, rows)})
+                       "query_features": qf.view(B * nq, P, -1).index_select(0, rows)})
         gt = inp["instances"]
         get = (lambda k: gt.get(k)) if hasattr(gt, "get") else (lambda k: gt[k])
         boxes = get("gt_boxes")

@@ -18,10 +18,12 @@ def test_adet_C_module_on_the_reference_fixture(case):
     assert out.dtype == torch.float32 and out.is_cuda
     assert float((out.cpu() - t(g[case + "_out"])).abs().max()) <= 2e-5
     assert torch.equal(out, torch.ops.gomatching.ms_deform_attn_forward(*args, 64))
-    B = args[0].shape[0]
-    if B > 1:                                                     # batch % min(batch, im2col_step) != 0 (cuda.cu:50-52)
-        with pytest.raises(RuntimeError, match="im2col_step"):
-            adet_C.ms_deform_attn_forward(*args, B - 1 if B > 2 else 3)
+    # batch % min(batch, im2col_step) != 0 (ms_deform_attn_cuda.cu:50-52): three copies of the first image, step 2
+    three = [args[0][:1].repeat(3, 1, 1, 1).contiguous(), args[1], args[2],
+             args[3][:1].repeat(3, 1, 1, 1, 1, 1).contiguous(), args[4][:1].repeat(3, 1, 1, 1, 1).contiguous()]
+    with pytest.raises(RuntimeError, match="im2col_step"):
+        adet_C.ms_deform_attn_forward(*three, 2)
+    assert torch.equal(adet_C.ms_deform_attn_forward(*three, 3)[0], out[0])
     with pytest.raises(RuntimeError, match="float32"):
         adet_C.ms_deform_attn_forward(args[0].double(), args[1], args[2], args[3].double(), args[4].double(), 64)
 
