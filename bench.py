@@ -317,12 +317,15 @@ def main():
 
     total_frames = FRAMES_PER_GPU * world * args.steps
     fps = total_frames / elapsed
+    ffn_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("ffn")]       # the fused FFN block: its own kernel
+    all_prof = prof
+    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith("ffn"))]    # the dominant kernel: plain GEMM launches
     dur_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     flops = sum(p[2] for p in prof)
     alg_bytes = sum(p[3] for p in prof)
     achieved = flops / (dur_ms * 1e-3) / 1e12 if dur_ms > 0 else 0.0
     by_shape = {}
-    for p_ in prof:
+    for p_ in all_prof:
         if len(p_) > 4:
             d = by_shape.setdefault(p_[4], [0, 0.0, 0.0])
             d[0] += 1
@@ -364,6 +367,10 @@ def main():
                      "avg_launch_us": dur_ms * 1e3 / max(len(prof), 1),
                      "flops_per_launch_avg": flops / max(len(prof), 1),
                      "algorithmic_bytes_per_launch_avg": alg_bytes / max(len(prof), 1),
+                     "algorithmic_hbm_tb_per_s": alg_bytes / (dur_ms * 1e-3) / 1e12 if dur_ms > 0 else 0.0,
+                     "hbm_note": "the K = 256 shapes of this kernel (fp32 in, fp32 out) carry 44-105 FLOP per byte, below the "
+                                 "chip's balance of ~130: their HBM roofline (8 TB/s) caps them at 0.31-0.50 of the MFMA "
+                                 "peak whatever the kernel does (DESIGN.md §3)",
                      "share_of_step_time": (dur_ms / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
                      "by_shape_MxNxK": {k: {"launches_per_step": v[0] // PROFILE_STEPS, "avg_us": v[1] * 1e3 / v[0],
                                             "tflops": v[2] / (v[1] * 1e-3) / 1e12,
@@ -373,6 +380,16 @@ def main():
                      if graphed else "%d eager steps after the timed region" % PROFILE_STEPS},
         "stage_ms_per_step": {k: v / args.steps * 1e3 for k, v in tc.items() if isinstance(v, float) and v > 0},
     }
+    if ffn_prof:
+        fd = sum(p_[0].elapsed_time(p_[1]) for p_ in ffn_prof)
+        ff = sum(p_[2] for p_ in ffn_prof)
+        line["roofline_fused_ffn"] = {
+            "bound": "mfma", "kernel": "ffn_fused_kernel<0>", "achieved": ff / (fd * 1e-3) / 1e12, "peak": PEAKS["f16x3"][1],
+            "unit": "TFLOP/s", "frac": ff / (fd * 1e-3) / 1e12 / PEAKS["f16x3"][1], "traffic": pmc_traffic("ffn_fused_kernel<0>"),
+            "launches_per_step": len(ffn_prof) // PROFILE_STEPS, "avg_launch_us": fd * 1e3 / len(ffn_prof),
+            "share_of_step_time": (fd / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
+            "note": "linear1 + ReLU + linear2 + residual + LayerNorm of every encoder / decoder layer in one launch: 2 KB of HBM "
+                    "traffic per token instead of 13 (csrc/ffn_fused.hip)"}
     solo = rank == 0 and world == 1 and args.backbone == "r50" and args.emulate_world == 1
     if solo and not args.no_alt_backends:
         # the other two contraction back-ends on the same window, a few steps each (secondary figures, same process)

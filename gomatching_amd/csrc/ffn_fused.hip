@@ -25,8 +25,6 @@
 //   * epilogue: Y^T goes through the (now free) LDS ring to row-major, then one wave per row applies the weight scale, bias,
 //     residual and the LayerNorm of norm.hip (same two-pass arithmetic) and stores whole 1 KB rows.
 // MFMA work per 128 rows: 4 waves x 3072 v_mfma_f32_32x32x16_f16; LDS reads 2/3 KB per MFMA; L2 -> LDS 2 MB.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -104,7 +102,6 @@ __device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)byte_offset, 0, 0, 0);
 }
 
-template <int DIAG>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -149,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
 
     for (int c = 0; c < p.chunks; ++c) {
         const int st = c & 1;
-        if ((DIAG == 0 || DIAG == 2) && c + 1 < p.chunks) dma_stage(c + 1, st ^ 1);     // DIAG 1: timing without the weight stream
+        if (c + 1 < p.chunks) dma_stage(c + 1, st ^ 1);
         const unsigned char* base = smem + st * STAGE_BYTES + lane * 16;
 
         // The 64 weight fragments of the chunk are consumed in eight groups of eight (four k-steps); with ONE wave per SIMD
@@ -174,11 +171,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[1][s_], acc1, 0, 0, 0);                 \
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[0][s_], acc1, 0, 0, 0);                 \
     }
-        if (DIAG == 2) {                                         // DIAG 2: timing of the weight stream alone
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            continue;
-        }
         FFN_LOAD(fa, 0)
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // group 0's reads come first, then (reads, MFMAs) pairs
         FFN_LOAD(fb, 1) FFN_GEMM1(fa, 0) FFN_PIN()
@@ -199,12 +191,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
                 const f32x4 bi = *reinterpret_cast<const f32x4*>(aux + CH + 8 * q + 4 * fh);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (DIAG == 3) { v[qq][e] = acc1[0] + (float)e; continue; }
                     v[qq][e] = fmaxf(fmaf(acc1[4 * q + e], sc[e], bi[e]), 0.f);
                     range_bad |= !(v[qq][e] <= 65504.f);       // beyond fp16 (or NaN): flagged, never a silent wrong result
                 }
             }
-            if (DIAG == 3) { hf[0][u] = __builtin_bit_cast(half8, u32x4{__builtin_bit_cast(unsigned, v[0][0]), 1u, 2u, 3u}); hf[1][u] = hf[0][u]; continue; }
             split8(v[0], v[1], hf[0][u], hf[1][u]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -224,7 +214,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
 #undef FFN_PIN
 #undef FFN_GEMM1
 #undef FFN_GEMM2
-        if (DIAG == 5) continue;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of the next stage has landed
         __syncthreads();                                     // ... and everybody's; nobody still reads this stage
     }
@@ -259,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     }
     int bad = range_bad;
 #pragma unroll 2
-    for (int g = 0; g < (DIAG == 4 ? 1 : 8); ++g) {
+    for (int g = 0; g < 8; ++g) {
         const int lr = wave * 32 + 4 * g + rsel;               // row inside the workgroup's tile
         const long m = (long)blockIdx.x * BM + lr;
         const long mc = m < p.M ? m : p.M - 1;                  // tail rows recompute the last row, never stored
@@ -352,22 +341,12 @@ extern "C" int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, 
     FfnArgs a{};
     a.X = X; a.img = (const unsigned char*)image; a.s2 = w2_inv_scale; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = Y;
     a.flag = flag; a.eps = eps; a.ldx = ldx; a.ldy = ldy; a.M = M; a.chunks = d_hidden / CH;
-    static int diag = -1;
-    if (diag < 0) {
-        const char* e = getenv("GOM_FFN_DIAG");               // timing diagnostics only (results are wrong): 1 = no weight
-        diag = e ? atoi(e) : 0;                               // stream, 2 = weight stream alone
-        for (auto k : {(const void*)ffn_fused_kernel<0>, (const void*)ffn_fused_kernel<1>, (const void*)ffn_fused_kernel<2>,
-                       (const void*)ffn_fused_kernel<3>, (const void*)ffn_fused_kernel<4>, (const void*)ffn_fused_kernel<5>}) {
-            hipError_t er = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-            if (er != hipSuccess) return GOM_ERR_HIP_BASE + (int)er;
-        }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+        attr_set = true;
     }
-    auto kern = ffn_fused_kernel<0>;
-    if (diag == 1) kern = ffn_fused_kernel<1>;
-    if (diag == 2) kern = ffn_fused_kernel<2>;
-    if (diag == 3) kern = ffn_fused_kernel<3>;
-    if (diag == 4) kern = ffn_fused_kernel<4>;
-    if (diag == 5) kern = ffn_fused_kernel<5>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return gom_launch_status();
 }

@@ -19,8 +19,6 @@
 //     result.  Badly scaled data (the 12-decade rows of tests/test_ops_gpu.py) belongs on the bf16x6 kernel.
 // Same tiling, staging, epilogue, XCD-aware tile order, implicit-im2col addressing and split-K form as gemm_bf16x6.hip,
 // but THREE workgroups per CU (two planes -> 40 KB of LDS, 138-147 VGPRs with one k-tile of A in flight).
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -403,16 +401,11 @@ template <int BM, int BN, int KH, int KW>
 int launch(const Args& a, hipStream_t s, int splits = 1) {
     const long tiles = (long)cdiv(a.M, BM) * cdiv(a.N, BN);
     if (tiles <= 0) return GOM_OK;
-    const int lds = 2 * (BM + BN) * ROW_BYTES;
+    constexpr int lds_loop = 2 * (BM + BN) * ROW_BYTES, lds_epi = 4 * 32 * (BN / 2 + 4) * 4;   // k-loop planes | epilogue slabs
+    const int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     // three workgroups per CU (40 KB LDS, <= 168 VGPRs, one k-tile of A in flight) measured 9 % faster end to end than
     // two with a two-deep A prefetch (251 VGPRs): 224-299 vs 187-265 TFLOP/s on the encoder shapes
     auto kern = gemm_f16x3_kernel<BM, BN, KH, KW, 3>;
-    static int occ = -1;
-    if (occ < 0) {
-        const char* e = getenv("GOM_F16X3_OCC");             // diagnostic: the 2-workgroups-per-CU build (251 VGPRs)
-        occ = e ? atoi(e) : 3;
-    }
-    if (occ == 2) kern = gemm_f16x3_kernel<BM, BN, KH, KW, 2>;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, s, a);
     if (a.partial)
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv((long)a.M * a.N, 256)), dim3(256), 0, s, a, splits);

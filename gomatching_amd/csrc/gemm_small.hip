@@ -3,8 +3,6 @@
 // MFMA tile spends 16 blocks x K/2 exact-fp32 MFMAs on such a product whatever M is (90 us at M=5, N=55, K=1024);
 // and the skinny M <= 128 linear layers of the matcher transformers pay a two-kernel split-K (22 us) each.  Here one
 // wave owns one output column for 8 rows on the VALU: latency of a few us, deterministic, independent of M.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -14,7 +12,9 @@ constexpr int RM = 8;                                                  // rows o
 // One wave owns output column n for RM consecutive rows: the weight row streams once per wave (16-byte loads, 64
 // lanes stride the K axis), the RM activation rows come from L1/L2, RM fp32 fmaf chains, fixed-order butterflies.
 // An output's arithmetic depends only on (its row, its column, K): results do not change with M or N.
-template <int VAR>
+// NOTE (round 2): built WITHOUT packed-fp32 instructions like the whole library (build.py): as `v_pk_fma_f32` pairs these eight
+// fmaf chains returned wrong LOW halves (= even rows) in 11-25 % of launches whenever waves of the bf16x6 GEMM kernel shared
+// the SIMD -- the round-1 "tracker determinism" issue (tools/race_repro.py).
 __global__ __launch_bounds__(256) void gemm_small_kernel(const float* __restrict__ A, const int* __restrict__ a_rows,
                                                          int lda, const float* __restrict__ W, int ldw,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
@@ -37,32 +37,13 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float* __restrict
     for (int r = 0; r < RM; ++r) acc[r] = 0.f;
     for (int k = lane * 4; k < K; k += 256) {
         const f32x4 y = *reinterpret_cast<const f32x4*>(w + k);
-        if constexpr (VAR == 2) {                            // every load of the step landed before the first use
-            f32x4 xs[RM];
-#pragma unroll
-            for (int r = 0; r < RM; ++r) xs[r] = *reinterpret_cast<const f32x4*>(a[r] + k);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < RM; ++r) {
-                acc[r] = fmaf(xs[r][0], y[0], acc[r]);
-                acc[r] = fmaf(xs[r][1], y[1], acc[r]);
-                acc[r] = fmaf(xs[r][2], y[2], acc[r]);
-                acc[r] = fmaf(xs[r][3], y[3], acc[r]);
-            }
-            continue;
-        }
 #pragma unroll
         for (int r = 0; r < RM; ++r) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(a[r] + k);
-            if constexpr (VAR == 1) {                        // scalar fma instructions only (no packed fp32 math)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[r]) : "v"(x[e]), "v"(y[e]));
-            } else {
-                acc[r] = fmaf(x[0], y[0], acc[r]);
-                acc[r] = fmaf(x[1], y[1], acc[r]);
-                acc[r] = fmaf(x[2], y[2], acc[r]);
-                acc[r] = fmaf(x[3], y[3], acc[r]);
-            }
+            acc[r] = fmaf(x[0], y[0], acc[r]);
+            acc[r] = fmaf(x[1], y[1], acc[r]);
+            acc[r] = fmaf(x[2], y[2], acc[r]);
+            acc[r] = fmaf(x[3], y[3], acc[r]);
         }
     }
 #pragma unroll
@@ -92,13 +73,7 @@ extern "C" int gom_gemm_small_f32(const float* A, const int* a_rows, int lda, co
     if (M == 0) return GOM_OK;
     GOM_CHECK_ARG((long)M * N <= (1L << 22));
     const long waves = (long)cdiv(M, RM) * N;
-    static int var = -1;
-    if (var < 0) {
-        const char* e = getenv("GOM_SMALL_VARIANT");
-        var = e ? atoi(e) : 0;
-    }
-    auto kern = var == 1 ? gemm_small_kernel<1> : (var == 2 ? gemm_small_kernel<2> : gemm_small_kernel<0>);
-    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, A, a_rows, lda,
+    hipLaunchKernelGGL(gemm_small_kernel, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, A, a_rows, lda,
                        W, ldw, scale, shift, R, ldr, relu, C, ldc, M, N, K);
     return gom_launch_status();
 }

@@ -1,0 +1,68 @@
+"""Per-shape timing of every GEMM-class launch on the BASELINE workload's transformer (encoder shapes, the decoder's Q-side
+GEMMs north_star names, the fused FFN block), f16x3 back-end.  Stand-alone: HIP-event medians.  Under rocprofv3 the same run
+gives the per-shape kernel durations that tools/gemm_shapes_csv.py reduces to profiles/r02_gemm_shapes.csv:
+
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_shapes -- python3 tools/gemm_shapes.py
+    python tools/gemm_shapes_csv.py gpurun_out/prof_shapes/*/*kernel_trace.csv gpurun_out/gemm_shapes_order.json"""
+import json
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import torch
+from gomatching_amd import ops
+
+dev = "cuda"
+ops.GEMM_MODE = "f16x3"
+S8, Q = 37171 * 8, 8 * 100 * 25
+REP = int(os.environ.get("REP", 12))
+# (label, M, N, K, residual columns, A2)
+SHAPES = [("enc offsets|logits|value N=640 (+pos table on 384 cols)", S8, 640, 256, 384, False),
+          ("enc out_proj N=256 (+residual)", S8, 256, 256, 256, False),
+          ("enc/dec value_proj x6 N=1536", S8, 1536, 256, 0, False),
+          ("enc_output N=256", S8, 256, 256, 0, False),
+          ("dec Q-side N=256 K=256 (out_proj / qpos / v / MLP, +residual)", Q, 256, 256, 256, False),
+          ("dec Q-side N=384 K=256 (cross offsets|logits, A2 = qpos)", Q, 384, 256, 0, True),
+          ("dec Q-side N=512 K=256 (intra q|k, A2 = qpos)", Q, 512, 256, 0, True),
+          ("dec Q-side N=768 K=256 (inter q|k|v)", Q, 768, 256, 0, False),
+          ("dec Q-side N=1024 K=256 (linear1, three-launch path)", Q, 1024, 256, 0, False),
+          ("dec Q-side N=256 K=1024 (linear2, three-launch path)", Q, 256, 1024, 256, False)]
+g = torch.Generator().manual_seed(0)
+order = []
+
+
+def run(label, fn, flops, kernel):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(REP):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    us = ts[len(ts) // 2]
+    order.append({"label": label, "kernel": kernel, "launches": REP + 2, "flops": flops})
+    print("%-62s %9.1f us  %6.1f TFLOP/s  (%.3f of 833)" % (label, us, flops / us / 1e6, flops / us / 1e6 / 833.3), flush=True)
+
+
+for label, M, N, K, rc, a2 in SHAPES:
+    A = torch.randn((M, K), generator=g).to(dev)
+    W = ops.split_weight((torch.randn((N, K), generator=g) / K ** 0.5).to(dev), kind="f16x3")
+    b = torch.randn((N,), generator=g).to(dev)
+    R = torch.randn((M, rc), generator=g).to(dev) if rc else None
+    A2 = torch.randn((M, K), generator=g).to(dev) if a2 else None
+    out = torch.empty((M, N), device=dev)
+    kern = "gemm_f16x3_kernel"
+    run(label, lambda: ops.gemm(A, W, bias=b, R=R, r_cols=rc if rc else None, A2=A2, out=out), 2.0 * M * N * K, kern)
+    del A, W, R, A2, out
+for label, M in (("enc FFN block fused (linear1+ReLU+linear2+residual+LayerNorm)", S8), ("dec FFN block fused", Q)):
+    F = 1024
+    w1 = (torch.randn((F, 256), generator=g) * 0.05).to(dev); b1 = torch.randn((F,), generator=g).to(dev) * 0.1
+    w2 = (torch.randn((256, F), generator=g) * 0.05).to(dev); b2 = torch.randn((256,), generator=g).to(dev) * 0.1
+    ffn = ops.FusedFFN(w1, b1, w2, b2, torch.ones((256,), device=dev), torch.zeros((256,), device=dev))
+    x = torch.randn((M, 256), generator=g).to(dev)
+    y = torch.empty_like(x)
+    run(label, lambda: ops.ffn_fused_ln(x, ffn, out=y), 4.0 * M * 256 * F, "ffn_fused_kernel")
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(order, open("gpurun_out/gemm_shapes_order.json", "w"), indent=1)
