@@ -1,6 +1,6 @@
 """Reduce rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes to profiles/pmc_traffic.json.
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [round tag]
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [round tag] [gemm_api_grids.json]
 
 Per MI355X_MICROARCH.md (HBM): FETCH_SIZE (KB) under-reports wide coalesced streaming reads by exactly 2x on
 gfx950 -> doubled; WRITE_SIZE (KB) is exact for 16-byte streaming stores."""
@@ -11,19 +11,41 @@ import os
 import sys
 
 
-def per_kernel(path, counter):
+def per_kernel(path, counter, api_grids):
+    """{kernel name (+ ' [pointwise conv]' for launches of a GEMM instantiation whose grid is not a GEMM-API shape): values}"""
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0].replace(" ", "")
+            name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+            name = name.split("(")[0].replace(" ", "")
+            if name.startswith("gemm_f16x3_kernel<128,128,0,0") or name.startswith("gemm_bf16x6_kernel<128,128,0,0") or \
+                    name.startswith("gemm_f32_kernel<128,128,64,64,0,0"):
+                if api_grids and int(r["Grid_Size"]) not in api_grids:
+                    name += " [pointwise conv]"
             agg[name].append(float(r["Counter_Value"]))
     return agg
 
 
+def kernel_source_hash():
+    """Same hash as bench.py: ties the counters to the build of the GEMM kernels they were taken on."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha1()
+    for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "common.h"):
+        with open(os.path.join(root, "gomatching_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def main():
-    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-    tag = sys.argv[3] if len(sys.argv) > 3 else "r01"
-    out = {}
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    api_grids = set(json.load(open(sys.argv[4]))) if len(sys.argv) > 4 else set()      # work-items of the GEMM-API launches
+    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE", api_grids), per_kernel(sys.argv[2], "WRITE_SIZE", api_grids)
+    out = {"_meta": {"kernel_source_hash": kernel_source_hash(), "round": tag,
+                     "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/gemm_shapes.py-free bench.py steps; "
+                             "FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM).  The dominant GEMM instantiation is split by grid "
+                             "size: launches whose workgroup count equals a GEMM-API shape of bench.py's transformer vs the "
+                             "backbone's pointwise convolutions (key + ' [pointwise conv]')"}}
     for k in sorted(set(fetch) | set(write)):
         f = sum(fetch.get(k, [0])) / max(len(fetch.get(k, [0])), 1) * 1024.0
         w = sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1) * 1024.0
@@ -32,7 +54,7 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as fjs:
         json.dump(out, fjs, indent=1, sort_keys=True)
-    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]:
+    for k, v in sorted([kv for kv in out.items() if kv[0] != "_meta"], key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:10]:
         print("%-50s %8.1f MB/launch (fetch x2 %.1f + write %.1f)" % (k[:50], v["hbm_bytes_per_launch"] / 1e6,
                                                                       v["fetch_bytes_x2"] / 1e6, v["write_bytes"] / 1e6))
 
