@@ -34,8 +34,6 @@ SIGNATURES = {
     "gom_gemm_f32_bf16x6": (I, [P, P, I, P, L, I, P, P, P, I, I, I, P, I, I, I, I, P]),
     "gom_conv2d_nhwc_f32_bf16x6": (I, [P, P, L, I, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P]),
     "gom_gemm_small_f32": (I, [P, P, I, P, I, P, P, P, I, I, P, I, I, I, I, P]),
-    "gom_split_rows_bf16x3": (I, [P, L, L, I, P, I, L, P]),
-    "gom_gemm_planes_bf16x6": (I, [P, L, I, P, L, I, P, P, P, I, I, I, P, I, P, L, I, I, I, I, P]),
     "gom_conv_bf16x6_splits": (I, [I, I, I]),
     "gom_conv2d_nhwc_f32_bf16x6_splitk": (I, [P, P, L, I, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, L, I, P]),
     "gom_split_f16x2": (I, [P, I, I, I, P, I, P, P]),

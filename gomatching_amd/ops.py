@@ -172,82 +172,6 @@ SPLITK_MAX_ROWS = 1024
 SMALL_GEMM_OUTPUTS = 1 << 16         # M*N up to which gemm(..., small=True) runs one-wave-per-output (tracker logits)
 
 
-class Planes:
-    """An activation matrix [M, K] held as three bf16 planes [3, M, ld] (x = p0 + p1 + p2, the GEMM's own split)."""
-
-    def __init__(self, t, K):
-        assert t.dtype == torch.bfloat16 and t.dim() == 3 and t.shape[0] == 3 and t.stride(2) == 1
-        self.t, self.K = t, K
-
-    @property
-    def shape(self):
-        return (self.t.shape[1], self.K)
-
-    def rows(self, a, b):
-        return Planes(self.t[:, a:b], self.K)
-
-    def float(self):
-        return (self.t[0].float() + self.t[1].float() + self.t[2].float())[:, :self.K]
-
-
-def new_planes(M, K, device):
-    ld = (K + 31) // 32 * 32
-    return Planes(torch.empty((3, M, ld), dtype=torch.bfloat16, device=device), K)
-
-
-def split_rows(x, out=None):
-    """fp32 [M, K] (row-strided) -> Planes."""
-    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == _f32
-    M, K = x.shape
-    if out is None:
-        out = new_planes(M, K, x.device)
-    t = out.t
-    check(_L().gom_split_rows_bf16x3(_p(x), x.stride(0) if M > 1 else K, M, K, _p(t), t.stride(1), t.stride(0),
-                                     _stream()), "gom_split_rows_bf16x3")
-    return out
-
-
-def gemm_planes(A, W, bias=None, scale=None, R=None, relu=False, out=None, out_planes=None, r_cols=None,
-                want="f32"):
-    """C = act(A @ W^T * scale + bias + R) with A a `Planes` and W a `SplitWeight`; `want` in {"f32","planes","both"}
-    selects fp32 rows and/or bf16 planes of the result (returned in that order)."""
-    assert isinstance(A, Planes) and isinstance(W, SplitWeight) and W.kind == "bf16x6"
-    M, K = A.shape
-    N = W.N
-    assert W.K == K and K % 32 == 0 and N % 4 == 0
-    dev = A.t.device
-    if want in ("f32", "both") and out is None:
-        out = torch.empty((M, N), dtype=_f32, device=dev)
-    if want in ("planes", "both") and out_planes is None:
-        out_planes = new_planes(M, N, dev)
-    if want == "planes":
-        out = None
-    if want == "f32":
-        out_planes = None
-    ldc = (out.stride(0) if out.shape[0] > 1 else N) if out is not None else 0
-    ldr = (R.stride(0) if R.shape[0] > 1 else R.shape[1]) if R is not None else 0
-    rc = (r_cols if r_cols is not None else N) if R is not None else 0
-    pl, ap = W.planes, A.t
-    cp = out_planes.t if out_planes is not None else None
-    prof = _gemm_profile if (_gemm_profile is not None and M > 0) else None
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    check(_L().gom_gemm_planes_bf16x6(_p(ap), ap.stride(0), ap.stride(1), _p(pl), pl.stride(0), pl.stride(1),
-                                      _p(scale), _p(bias), _p(R), ldr, rc, 1 if relu else 0, _p(out), ldc,
-                                      _p(cp), cp.stride(0) if cp is not None else 0,
-                                      cp.stride(1) if cp is not None else 0, M, N, K, _stream()),
-          "gom_gemm_planes_bf16x6")
-    if prof is not None:
-        e1.record()
-        nbytes = 6.0 * M * K + 6.0 * N * pl.shape[2] + (4.0 * M * N if out is not None else 0.0) \
-            + (6.0 * M * N if cp is not None else 0.0) + (4.0 * M * rc if R is not None else 0.0)
-        prof.append((e0, e1, 2.0 * M * N * K, nbytes, "%dx%dx%d" % (M, N, K)))
-    if want == "both":
-        return out, out_planes
-    return out if want == "f32" else out_planes
-
-
 def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, out=None, M=None, splitk=None,
          r_cols=None, small=False):
     """C = act((A[+A2])[M,K] @ W[N,K]^T * scale + bias + R).  A may be a 2-D row-strided view

@@ -150,18 +150,6 @@ int gom_conv2d_nhwc_f32_bf16x6_splitk(const float* X, const void* Wplanes, long 
                                       int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                       void* workspace, long workspace_bytes, int splits, void* stream);
 
-/* Same product with the ACTIVATION operand already split: Aplanes [3][M][lda] bf16 written by a producer
- * (gom_split_rows_bf16x3, or the plane outputs of gom_gemm_planes_bf16x6 / gom_layernorm_planes_f32 /
- * gom_msda_fused_forward_planes).  Both operands stream HBM -> LDS by LDS-DMA, no in-loop VALU.  K % 32 == 0, N % 4 == 0.
- * Output: fp32 C and/or bf16 planes Cplanes [3][M][ldcp] of the same epilogue value (either may be NULL, not both).
- * Bit-identical to gom_gemm_f32_bf16x6 on the same values. */
-int gom_split_rows_bf16x3(const float* X, long ld_in, long M, int K, void* planes_out, int ld_out, long plane_stride,
-                          void* stream);
-int gom_gemm_planes_bf16x6(const void* Aplanes, long a_plane_stride, int lda, const void* Wplanes, long w_plane_stride,
-                           int ldw, const float* scale, const float* shift, const float* R, int ldr, int r_cols,
-                           int relu, float* C, int ldc, void* Cplanes, long c_plane_stride, int ldcp, int M, int N,
-                           int K, void* stream);
-
 /* ---- normalisation ---------------------------------------------------------------------------------*/
 /* out = LayerNorm(x + residual) * gamma + beta over rows of dim 256 or 1024 (residual may be NULL). */
 int gom_layernorm_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* out,

@@ -128,48 +128,6 @@ def test_gemm_split_epilogue_gather_and_extremes(kind):
         ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 64, 256), (300, 384, 256), (513, 132, 1024), (2000, 640, 64), (129, 1024, 32)])
-def test_gemm_planes_identical_to_bf16x6(M, N, K):
-    """Pre-split activation operand (LDS-DMA kernel): same bits as the in-loop-split kernel on the same values, for
-    fp32 output, plane output (p0+p1+p2 reproduces the fp32 result exactly) and both at once; ragged M and N."""
-    from gomatching_amd import ops
-    torch.manual_seed(M + N + K)
-    A = torch.randn(M, K, device=DEV) * (torch.rand(M, 1, device=DEV) * 8)
-    W = ops.split_weight(torch.randn(N, K, device=DEV), kind="bf16x6")
-    b, sc = torch.randn(N, device=DEV), torch.rand(N, device=DEV) + 0.5
-    R = torch.randn(M, N, device=DEV)
-    Ap = ops.split_rows(A)
-    assert torch.equal(Ap.float(), A)                                  # the three planes carry all 24 mantissa bits
-    rc = (N // 2) // 4 * 4 or None
-    for relu in (False, True):
-        ref = ops.gemm(A, W, bias=b, scale=sc, R=R, relu=relu, r_cols=rc)
-        got = ops.gemm_planes(Ap, W, bias=b, scale=sc, R=R, relu=relu, r_cols=rc)
-        assert torch.equal(got, ref)
-        both_f, both_p = ops.gemm_planes(Ap, W, bias=b, scale=sc, R=R, relu=relu, r_cols=rc, want="both")
-        only_p = ops.gemm_planes(Ap, W, bias=b, scale=sc, R=R, relu=relu, r_cols=rc, want="planes")
-        assert torch.equal(both_f, ref) and torch.equal(both_p.float(), ref) and torch.equal(only_p.float(), ref)
-
-
-def test_gemm_planes_chain_and_bad_args():
-    """FFN-style chain through plane outputs: relu(A W1^T) as planes feeds the next product without an fp32 round trip."""
-    from gomatching_amd import ops, lib
-    torch.manual_seed(5)
-    A = torch.randn(777, 256, device=DEV)
-    W1 = ops.split_weight(torch.randn(1024, 256, device=DEV) * 0.1, kind="bf16x6")
-    W2 = ops.split_weight(torch.randn(256, 1024, device=DEV) * 0.1, kind="bf16x6")
-    h_ref = ops.gemm(A, W1, relu=True)
-    y_ref = ops.gemm(h_ref, W2, R=A)
-    h = ops.gemm_planes(ops.split_rows(A), W1, relu=True, want="planes")
-    y = ops.gemm_planes(h, W2, R=A)
-    assert torch.equal(y, y_ref)
-    with pytest.raises(AssertionError):
-        ops.gemm_planes(ops.split_rows(torch.randn(8, 40, device=DEV)),
-                        ops.split_weight(torch.randn(64, 40, device=DEV), kind="bf16x6"))
-    L = lib.load()
-    assert L.gom_gemm_planes_bf16x6(None, 0, 0, None, 0, 0, None, None, None, 0, 0, 0, None, 0, None, 0, 0, 1, 4, 32,
-                                    None) == 1
-
-
 def test_gemm_epilogue_and_gather():
     ops = _ops()
     g = torch.Generator().manual_seed(3)
