@@ -865,22 +865,13 @@ class GoMatching:
                 chunks.append(np.ascontiguousarray(S, dtype=np.float32).reshape(-1))
                 so += chunks[-1].size
         S_all = np.concatenate(chunks) if chunks else np.zeros((1,), np.float32)
-        if getattr(self, "_ntrk", None) is None:
-            m = self.roi_heads._matcher(False)
-            self._ntrk = L.gom_tracker_create(self.test_len, float(self.overlap_thresh), 1 if self.not_mult_thresh else 0,
-                                              1 if self.decay_time > 0 else 0, 1 if self.with_iou else 0,
-                                              float(self.max_center_dist), m._enc_c, len(m.enc), m._dec_c, len(m.dec), m.d,
-                                              m.heads, m.ffn)
-            if not self._ntrk:
-                raise ops._lib_mod.GomError("gom_tracker_create failed")
-            self._decay_table = np.power(np.float32(self.decay_time if self.decay_time > 0 else 1.0),
-                                         np.arange(self.test_len + 1).astype(np.float32)).astype(np.float32)
+        trk = self._native_tracker()
         idc = ctypes.c_long(int(id_count) if id_count else 0)
         secs = (ctypes.c_double * 2)(0.0, 0.0)
         hw = dets[0].image_size
         ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         time_cost["short_match"] += time.time() - t0
-        ops.check(L.gom_tracker_run(self._ntrk, len(window), ptr(n), ptr(boxes), ptr(rows), ptr(ids), first_new, start,
+        ops.check(L.gom_tracker_run(trk, len(window), ptr(n), ptr(boxes), ptr(rows), ptr(ids), first_new, start,
                                     ptr(S_all), ptr(s_off), ctypes.c_void_p(self._pool.data_ptr()), self._pool.stride(0),
                                     float(hw[1]), float(hw[0]), ptr(self._decay_table), ctypes.byref(idc), secs,
                                     ops._stream()), "gom_tracker_run")
@@ -901,6 +892,42 @@ class GoMatching:
             self._defer_ids = False
         self._flush_ids(dets)
         return instances, int(idc.value)
+
+    def _native_tracker(self):
+        """The native tracker handle for the CURRENT thresholds and matcher weights.  The handle caches both at creation, so it
+        is keyed on them (a changed `overlap_thresh` / `decay_time` / ..., or re-created matcher tensors, make a new handle
+        and destroy the old one with its device and pinned buffers) and released by `close()`."""
+        m = self.roi_heads._matcher(False)
+        key = (int(self.test_len), float(self.overlap_thresh), bool(self.not_mult_thresh), float(self.decay_time),
+               bool(self.with_iou), float(self.max_center_dist), bytes(m._enc_c) if len(m.enc) else b"",
+               bytes(m._dec_c) if len(m.dec) else b"", m.d, m.heads, m.ffn)
+        if getattr(self, "_ntrk", None) is not None and self._ntrk_key == key:
+            return self._ntrk
+        self.close()
+        L = ops._L()
+        self._ntrk = L.gom_tracker_create(self.test_len, float(self.overlap_thresh), 1 if self.not_mult_thresh else 0,
+                                          1 if self.decay_time > 0 else 0, 1 if self.with_iou else 0,
+                                          float(self.max_center_dist), m._enc_c, len(m.enc), m._dec_c, len(m.dec), m.d,
+                                          m.heads, m.ffn)
+        if not self._ntrk:
+            raise ops._lib_mod.GomError("gom_tracker_create failed")
+        self._ntrk_key = key
+        self._decay_table = np.power(np.float32(self.decay_time if self.decay_time > 0 else 1.0),
+                                     np.arange(self.test_len + 1).astype(np.float32)).astype(np.float32)
+        return self._ntrk
+
+    def close(self):
+        """Release the native tracker handle (hipMalloc / hipHostMalloc buffers of csrc/tracker_rt.hip)."""
+        h, self._ntrk = getattr(self, "_ntrk", None), None
+        if h:
+            torch.cuda.synchronize(self.device)                  # its buffers may still be read by queued kernels
+            ops._L().gom_tracker_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                        # interpreter shutdown: the library may be gone already
+            pass
 
     def _remove_short_track(self, instances):
         """gom_lstmatcher.py:566-577.  The per-frame boolean indexing of the reference (seven index kernels and a
@@ -956,6 +983,10 @@ class GoMatching:
         bd to the original frame size; pred_boxes stay in network-input pixels.  Frames that share the scale factors
         (a whole video normally) are scaled by ONE kernel per field over their concatenated rows."""
         groups = {}
+        for r in instances:                                      # results leave the model here: they must not alias the pool
+            if r.has("reid_features") and self._in_pool(r) and len(r):
+                r._fields["reid_features"] = r.reid_features.clone()
+                self._host(r)["row0"] = None
         for i, (r, image_size) in enumerate(zip(instances, image_sizes)):
             sx, sy = image_size[1] / r.image_size[1], image_size[0] / r.image_size[0]
             if self.min_size_test and self.max_size_test:

@@ -429,3 +429,56 @@ def test_mixed_resolution_clip():
     for x in insts:
         ids = x.track_ids.cpu().tolist()
         assert len(ids) == len(set(ids))
+
+
+def test_results_survive_next_video_and_tracker_handle_follows_thresholds():
+    """(a) What `batch_postprocess` hands back must not alias the embedding pool: the next video's `begin_batch` re-uses
+    the pool from row 0 (in the reference every frame owns its tensor).  (b) The native tracker handle caches thresholds
+    and weight pointers at creation: changing a threshold makes a new handle (the old one is destroyed), the ids then
+    follow the NEW threshold exactly as the Python loop (which reads the attributes every call) does."""
+    from gomatching_amd import ops
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.structures import Instances, Boxes
+    from gomatching_amd.weights import synth_state_dict
+    cfg = mini_cfg("icdar15", device=DEV)
+    model = GoMatching(cfg, synth_state_dict(cfg, seed=7), device=DEV)
+    size = (96, 128)
+
+    def run(trace, native=True):
+        old, ops.NATIVE_TRACKER = ops.NATIVE_TRACKER, native
+        try:
+            dets = []
+            for f, b in trace:
+                inst = Instances(size)
+                inst.reid_features = torch.from_numpy(f).to(DEV)
+                inst.pred_boxes = Boxes(torch.from_numpy(b).to(DEV))
+                dets.append(inst)
+            it = iter(dets)
+            model.detect_launch = lambda batched_inputs, time_cost: list(batched_inputs)
+            model.detect_finish = lambda h, time_cost: [next(it) for _ in h]
+            insts, _ = model.batch_inference([{} for _ in trace], 0, 0, [], _time_cost())
+            return model.batch_postprocess(insts, [size] * len(insts))
+        finally:
+            ops.NATIVE_TRACKER = old
+
+    tr_a = _synthetic_trace(20, model.roi_heads.feature_dim, seed=5)
+    tr_b = _synthetic_trace(20, model.roi_heads.feature_dim, seed=6)
+    res_a = run(tr_a)
+    kept = [(i, r["instances"].reid_features.clone()) for i, r in enumerate(res_a) if r["instances"].has("reid_features")]
+    assert kept, "the last test_len frames carry their embeddings"
+    h0 = model._ntrk
+    run(tr_b)                                                          # second video: the pool is reused from row 0
+    torch.cuda.synchronize()
+    for i, f in kept:
+        assert torch.equal(res_a[i]["instances"].reid_features, f), i
+    assert model._ntrk == h0                                           # same settings: same handle
+    ids_default = [r["instances"].track_ids.cpu().tolist() for r in run(tr_a)]
+    model.overlap_thresh = 0.999                                       # nothing associates any more
+    ids_native = [r["instances"].track_ids.cpu().tolist() for r in run(tr_a)]
+    assert model._ntrk != h0 or model._ntrk_key[1] == 0.999
+    assert model._ntrk_key[1] == 0.999
+    ids_python = [r["instances"].track_ids.cpu().tolist() for r in run(tr_a, native=False)]
+    assert ids_native == ids_python and ids_native != ids_default
+    model.close()
+    assert model._ntrk is None
+    model.close()                                                      # idempotent
