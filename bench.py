@@ -318,8 +318,9 @@ def main():
     total_frames = FRAMES_PER_GPU * world * args.steps
     fps = total_frames / elapsed
     ffn_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("ffn")]       # the fused FFN block: its own kernel
+    k256_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("k256:")]    # the decoder's row-resident K = 256 kernel
     all_prof = prof
-    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith("ffn"))]    # the dominant kernel: plain GEMM launches
+    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:")))]   # the dominant kernel: plain GEMMs
     dur_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     flops = sum(p[2] for p in prof)
     alg_bytes = sum(p[3] for p in prof)
@@ -399,6 +400,18 @@ def main():
             "note": "linear1 + ReLU + linear2 + residual + LayerNorm of every encoder / decoder layer in one launch: 2 KB of HBM "
                     "traffic per token instead of 13 (csrc/ffn_fused.hip)"}
         both_ms, both_fl = dur_ms + fd, flops + ff
+        if k256_prof:
+            kd = sum(p_[0].elapsed_time(p_[1]) for p_ in k256_prof)
+            kf = sum(p_[2] for p_ in k256_prof)
+            line["roofline_decoder_k256"] = {
+                "bound": "mfma", "kernel": "gemm_k256_kernel", "achieved": kf / (kd * 1e-3) / 1e12, "peak": PEAKS["f16x3"][1],
+                "unit": "TFLOP/s", "frac": kf / (kd * 1e-3) / 1e12 / PEAKS["f16x3"][1], "traffic": pmc_traffic("gemm_k256_kernel"),
+                "launches_per_step": len(k256_prof) // PROFILE_STEPS, "avg_launch_us": kd * 1e3 / len(k256_prof),
+                "share_of_step_time": (kd / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
+                "note": "the decoder's Q-side nn.Linear layers (M = frames x queries x points = 20 000 rows, K = 256): rows "
+                        "resident in registers, weights streamed as MFMA fragments (csrc/gemm_k256.hip); bit-identical to the "
+                        "tile kernel, which is latency-bound at this M"}
+            both_ms, both_fl = both_ms + kd, both_fl + kf
         line["roofline"]["gemm_class_combined"] = {
             "what": "plain GEMM launches + fused FFN launches together (round 1 ran the FFN's two GEMMs on the plain kernel)",
             "achieved": both_fl / (both_ms * 1e-3) / 1e12, "frac": both_fl / (both_ms * 1e-3) / 1e12 / PEAKS[args.gemm][1],

@@ -94,28 +94,37 @@ class DeepSolo:
             p = t + "encoder.layers.%d." % i
             self.enc.append({"attn": msda(p + "self_attn"), "norm1": norm(p + "norm1"), "lin1": lin(p + "linear1"),
                              "lin2": lin(p + "linear2"), "norm2": norm(p + "norm2"), "ffn": ffn(p, "norm2")})
+        def qlin(pair):
+            """A Q-side layer of the decoder (M = frames x queries x points rows): the row-resident K = 256 kernel under
+            the f16x3 back-end (csrc/gemm_k256.hip), otherwise the pair as it is (ops.linear serves both)."""
+            return ops.k256_linear(*pair)
+
+        E = self.d
         self.dec = []
         for i in range(self.n_dec):
             p = t + "decoder.layers.%d." % i
+            wi, bi = ops.prep_weight(g(p + "attn_intra.in_proj_weight")), g(p + "attn_intra.in_proj_bias")
+            cross = msda(p + "attn_cross")
+            cross["raw"], cross["out"] = qlin(cross["raw"]), qlin(cross["out"])
             self.dec.append({
-                "intra_in": (ops.prep_weight(g(p + "attn_intra.in_proj_weight")), g(p + "attn_intra.in_proj_bias")),
-                "intra_out": lin(p + "attn_intra.out_proj"), "norm_intra": norm(p + "norm_intra"),
-                "inter_in": (ops.prep_weight(g(p + "attn_inter.in_proj_weight")), g(p + "attn_inter.in_proj_bias")),
-                "inter_out": lin(p + "attn_inter.out_proj"), "norm_inter": norm(p + "norm_inter"),
-                "cross": msda(p + "attn_cross"), "norm_cross": norm(p + "norm_cross"),
+                "intra_qk": qlin((wi[:2 * E], bi[:2 * E])), "intra_v": qlin((wi[2 * E:], bi[2 * E:])),
+                "intra_out": qlin(lin(p + "attn_intra.out_proj")), "norm_intra": norm(p + "norm_intra"),
+                "inter_in": qlin((ops.prep_weight(g(p + "attn_inter.in_proj_weight")), g(p + "attn_inter.in_proj_bias"))),
+                "inter_out": qlin(lin(p + "attn_inter.out_proj")), "norm_inter": norm(p + "norm_inter"),
+                "cross": cross, "norm_cross": norm(p + "norm_cross"),
                 "lin1": lin(p + "linear1"), "lin2": lin(p + "linear2"), "norm3": norm(p + "norm3"),
                 "ffn": ffn(p, "norm3")})
         # all six cross-attention value projections as one [6*256, 256] weight
         vp = [t + "decoder.layers.%d.attn_cross.value_proj" % i for i in range(self.n_dec)]
-        self.dec_value_w = ops.prep_weight(torch.cat([g(n + ".weight") for n in vp], 0).contiguous())
-        self.dec_value_b = torch.cat([g(n + ".bias") for n in vp], 0).contiguous()
-        self.ref_point_head = [lin(t + "decoder.ref_point_head.layers.%d" % i) for i in range(2)]
+        self.dec_value = qlin((ops.prep_weight(torch.cat([g(n + ".weight") for n in vp], 0).contiguous()),
+                               torch.cat([g(n + ".bias") for n in vp], 0).contiguous()))
+        self.ref_point_head = [qlin(lin(t + "decoder.ref_point_head.layers.%d" % i)) for i in range(2)]
         self.bezier_coord = [lin("bezier_proposal_coord.layers.%d" % i) for i in range(3)]
         self.bezier_class = lin("bezier_proposal_class")
-        self.ctrl_coord = [lin("ctrl_point_coord.0.layers.%d" % i) for i in range(3)]
+        self.ctrl_coord = [qlin(lin("ctrl_point_coord.0.layers.%d" % i)) for i in range(3)]      # last layer (N = 2): a pair
         self.ctrl_class = lin("ctrl_point_class.0")
         self.ctrl_text = lin("ctrl_point_text.0")
-        self.boundary = [lin("boundary_offset.0.layers.%d" % i) for i in range(3)]
+        self.boundary = [qlin(lin("boundary_offset.0.layers.%d" % i)) for i in range(3)]
 
         dim_t = torch.arange(128, dtype=_f32)
         dim_t = T.TEMPERATURE ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / 128)
@@ -264,7 +273,7 @@ class DeepSolo:
         nq, P, S = self.nq, self.P, geo["S"]
         Q = B * nq * P
         tgt = ops.broadcast_rows(self.point_embed, B).view(Q, 256)
-        values = ops.gemm(memory, self.dec_value_w, bias=self.dec_value_b)                    # [B*S, 1536]
+        values = ops.linear(memory, self.dec_value)                                           # [B*S, 1536]
         vr = geo["vr"]
         if vr is not None:
             ops.zero_padded_tokens_(values, 0, values.shape[1], geo["shapes"], geo["lsi"], geo["vshapes"], B, S)
@@ -275,32 +284,30 @@ class DeepSolo:
             # reference_points_input = reference_points * valid_ratios; the query position comes from level 0's (:470-473)
             qref = refs if vr is None else ops.scale_xy_(refs.clone(), *geo["vr0"])
             qpos = ops.point_pos_embed(qref, self.dim_t)
-            qpos = ops.gemm(qpos, self.ref_point_head[0][0], bias=self.ref_point_head[0][1], relu=True)
-            qpos = ops.gemm(qpos, self.ref_point_head[1][0], bias=self.ref_point_head[1][1])
+            qpos = ops.linear(qpos, self.ref_point_head[0], relu=True)
+            qpos = ops.linear(qpos, self.ref_point_head[1])
             # intra-instance attention over the 25 points of each query (deformable_transformer.py:386-394)
-            w, b = L["intra_in"]
-            qk = ops.gemm(tgt, w[:2 * E], bias=b[:2 * E], A2=qpos)                             # [Q, 512]
-            v = ops.gemm(tgt, w[2 * E:], bias=b[2 * E:])
+            qk = ops.linear(tgt, L["intra_qk"], A2=qpos)                                       # [Q, 512]
+            v = ops.linear(tgt, L["intra_v"])
             attn = torch.empty((Q, E), dtype=_f32, device=self.device)
             qkf = qk.view(-1)
             ops.mha_core(qkf, qkf[E:], v, attn, B * nq, 1, 8, 32, P, P,
                          [P * 2 * E, 0, 2 * E, P * 2 * E, 0, 2 * E, P * E, 0, E, P * E, 0, E])
-            x = ops.gemm(attn, L["intra_out"][0], bias=L["intra_out"][1], R=tgt)
+            x = ops.linear(attn, L["intra_out"], R=tgt)
             tgt = ops.layernorm(x, *L["norm_intra"])
             # inter-instance attention over the nq queries, batched over (frame, point) (:396-404)
-            w, b = L["inter_in"]
-            qkv = ops.gemm(tgt, w, bias=b)                                                     # [Q, 768]
+            qkv = ops.linear(tgt, L["inter_in"])                                               # [Q, 768]
             f = qkv.view(-1)
             ld = 3 * E
             ops.mha_core(f, f[E:], f[2 * E:], attn, B, P, 8, 32, nq, nq,
                          [nq * P * ld, ld, P * ld] * 3 + [nq * P * E, E, P * E])
-            x = ops.gemm(attn, L["inter_out"][0], bias=L["inter_out"][1], R=tgt)
+            x = ops.linear(attn, L["inter_out"], R=tgt)
             tgt = ops.layernorm(x, *L["norm_inter"])
             # deformable cross attention into the encoder memory (:406-422)
             value = values[:, lid * E:(lid + 1) * E]
             samp = self._msda_strided(L["cross"], tgt, qpos, refs.view(Q, 1, 2), value, values.stride(0), geo, B,
                                       nq * P, vr)
-            x = ops.gemm(samp, L["cross"]["out"][0], bias=L["cross"]["out"][1], R=tgt)
+            x = ops.linear(samp, L["cross"]["out"], R=tgt)
             tgt = ops.layernorm(x, *L["norm_cross"])
             if L["ffn"] is not None:
                 tgt = ops.ffn_fused_ln(tgt, L["ffn"])
@@ -316,13 +323,13 @@ class DeepSolo:
 
     def _msda_strided(self, W, query, query_pos, ref, value_view, ld_value, geo, B, Lq, vr=None):
         """Cross-attention sampling straight out of the fused [B*S, 1536] value buffer (no compaction copy)."""
-        raw = ops.gemm(query, W["raw"][0], bias=W["raw"][1], A2=query_pos)
+        raw = ops.linear(query, W["raw"], A2=query_pos)
         return ops.msda_fused(raw, ref, value_view, geo["S"] * ld_value, geo["shapes"], geo["lsi"], B, Lq, vr)
 
     def _mlp3(self, x, layers):
-        h = ops.gemm(x, layers[0][0], bias=layers[0][1], relu=True)
-        h = ops.gemm(h, layers[1][0], bias=layers[1][1], relu=True)
-        return ops.gemm(h, layers[2][0], bias=layers[2][1])
+        h = ops.linear(x, layers[0], relu=True)
+        h = ops.linear(h, layers[1], relu=True)
+        return ops.linear(h, layers[2])
 
     def heads(self, hs, inter_refs):
         """A10: last-layer heads with inter_references[last-1] (detection_transformer_wobackbone.py:209-253)."""

@@ -301,6 +301,77 @@ def groupnorm32_into(x, gamma, beta, out_view, out_batch_stride, eps=1e-5):
                                         eps, _stream()), "gom_groupnorm32_nhwc_f32")
 
 
+K256_GEMM = True         # f16x3 back-end: K = 256 products on the row-resident kernel where it measures faster (below)
+K256_MAX_ROWS = 1 << 16  # "short" problems (the decoder's Q side: M = frames x queries x points)
+
+
+def k256_wins(M, N, has_a2):
+    """Kernel choice from tools/gemm_k256_bench.py (interleaved A/B on MI355X).  Both kernels return the same
+    bits, so this is a pure speed rule.  Short problems: N = 256 (21 vs 24 us at M = 20 000) and everything with a second
+    addend (the tile kernel needs an `add` launch first: 23-54 vs 32-56 us); long problems: wide outputs (N = 1536:
+    811 vs 972 us at M = 297 368; the tile kernel wins at N = 256 / 640 there)."""
+    if M <= K256_MAX_ROWS:
+        return N == 256 or has_a2
+    return N >= 1024
+
+
+class K256Linear:
+    """An nn.Linear with in_features 256 prepared for gom_gemm_k256_f32: fragment-linear image of the f16x3 planes + inverse
+    row scales + bias (csrc/gemm_k256.hip).  `W` (SplitWeight, possibly a row slice) and `bias` stay available for the tile
+    kernel, which serves long problems."""
+
+    def __init__(self, W, bias=None):
+        assert isinstance(W, SplitWeight) and W.kind == "f16x3"
+        nbytes = _L().gom_gemm_k256_image_bytes(W.N, W.K)
+        if nbytes < 0:
+            raise _lib_mod.GomError("row-resident GEMM kernel does not serve N %d / K %d" % (W.N, W.K))
+        pl = W.planes
+        self.image = torch.empty((nbytes,), dtype=torch.uint8, device=pl.device)
+        check(_L().gom_gemm_k256_image(_p(pl), pl.stride(0), pl.stride(1), _p(W.inv_scale), _p(bias), W.N, W.K,
+                                       _p(self.image), nbytes, _stream()), "gom_gemm_k256_image")
+        self.W, self.bias, self.N, self.K = W, bias, W.N, W.K
+
+
+def k256_linear(w, bias=None):
+    """(weight, bias) of a K = 256 layer -> K256Linear when the back-end and shape allow, else the pair for ops.gemm."""
+    if K256_GEMM and GEMM_MODE == "f16x3" and isinstance(w, SplitWeight) and w.kind == "f16x3" and w.K == 256 and w.N % 32 == 0:
+        return K256Linear(w, bias)
+    return (w, bias)
+
+
+def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0):
+    """act((x [+ A2]) @ W^T + b [+ R]) for `lin` = K256Linear or a (weight, bias) pair."""
+    if not isinstance(lin, K256Linear):
+        return gemm(x, lin[0], bias=lin[1], A2=A2, R=R, relu=relu, r_cols=r_cols, out=out)
+    M = x.shape[0]
+    if M == 0 or not (groups or k256_wins(M, lin.N, A2 is not None)):       # an explicit `groups` forces the kernel (tests, tools)
+        return gemm(x, lin.W, bias=lin.bias, A2=A2, R=R, relu=relu, r_cols=r_cols, out=out)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == lin.K and x.dtype == _f32
+    lda = x.stride(0) if M > 1 else lin.K
+    if A2 is not None:
+        assert A2.shape == x.shape and A2.stride() == x.stride() and A2.dtype == _f32
+    N = lin.N
+    if out is None:
+        out = torch.empty((M, N), dtype=_f32, device=x.device)
+    assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] == N
+    ldr, rc = 0, 0
+    if R is not None:
+        assert R.dim() == 2 and R.stride(1) == 1 and R.dtype == _f32
+        ldr, rc = (R.stride(0) if R.shape[0] > 1 else R.shape[1]), (r_cols if r_cols is not None else N)
+    prof = _gemm_profile if _gemm_profile is not None else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().gom_gemm_k256_f32(_p(x), _p(A2), lda, _p(lin.image), _p(R), ldr, rc, 1 if relu else 0, _p(out),
+                                 out.stride(0) if out.shape[0] > 1 else N, M, N, lin.K, groups or 1, _p(range_flag(x.device)),
+                                 _stream()), "gom_gemm_k256_f32")
+    if prof is not None:
+        e1.record()
+        nbytes = 4.0 * M * lin.K * (2 if A2 is not None else 1) + lin.image.numel() + 4.0 * M * N + 4.0 * M * rc
+        prof.append((e0, e1, 2.0 * M * N * lin.K, nbytes, "k256:%dx%dx%d" % (M, N, lin.K)))
+    return out
+
+
 FUSED_FFN = True         # f16x3 back-end: FFN blocks as one fused launch (False: GEMM, GEMM, LayerNorm)
 
 

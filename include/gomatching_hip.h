@@ -123,6 +123,19 @@ int gom_conv2d_nhwc_f32_f16x3(const float* X, const void* Wplanes, long w_plane_
                               int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
                               long workspace_bytes, int splits, int* flag, void* stream);
 
+/* Row-resident K = 256 form of gom_gemm_f32_f16x3 for SHORT problems (the decoder's Q-side nn.Linear layers at
+ * M = frames x queries x points rows: deformable_transformer.py:386-422,470-488), csrc/gemm_k256.hip:
+ *     C[M, N] = act( (A [+ A2])[M, 256] . W[N, 256]^T + bias [+ R on columns < r_cols] ),   N, r_cols multiples of 32.
+ * Same split scheme, plane-product order and epilogue arithmetic as gom_gemm_f32_f16x3: bit-identical results, same range
+ * contract and *flag.  gom_gemm_k256_image: one-time weight preparation from the gom_split_f16x2 planes, their inverse row
+ * scales and the bias (may be NULL) into the kernel's fragment-linear stream (gom_gemm_k256_image_bytes bytes; -1 = shape
+ * not served).  col_groups: workgroups along N (0 = chosen from M: about two workgroups per CU). */
+long gom_gemm_k256_image_bytes(int N, int K);
+int gom_gemm_k256_image(const void* w_planes, long w_plane_stride, int ldw, const float* w_inv_scale, const float* bias,
+                        int N, int K, void* image, long image_bytes, void* stream);
+int gom_gemm_k256_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr, int r_cols,
+                      int relu, float* C, int ldc, int M, int N, int K, int col_groups, int* flag, void* stream);
+
 /* Fused FFN block of a DeepSolo transformer layer (deformable_transformer.py:250-251,266-273 encoder linear1/ReLU/linear2 +
  * residual + norm2; :352-354,368-369 decoder + norm3):
  *     Y = LayerNorm(X + relu(X W1^T + b1) W2^T + b2) * gamma + beta,   X, Y [M, d_model] fp32 (row strides ldx / ldy; Y may

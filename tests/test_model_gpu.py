@@ -452,6 +452,8 @@ def test_results_survive_next_video_and_tracker_handle_follows_thresholds():
                 inst = Instances(size)
                 inst.reid_features = torch.from_numpy(f).to(DEV)
                 inst.pred_boxes = Boxes(torch.from_numpy(b).to(DEV))
+                inst.bd = torch.zeros((len(b), 4), device=DEV)            # batch_postprocess scales these two fields
+                inst.ctrl_points = torch.zeros((len(b), 2), device=DEV)
                 dets.append(inst)
             it = iter(dets)
             model.detect_launch = lambda batched_inputs, time_cost: list(batched_inputs)
