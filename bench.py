@@ -155,6 +155,9 @@ def main():
                     help="diagnostic: long-term matches through the persistent one-kernel matcher with this many workgroups")
     ap.add_argument("--h2d", default=None, choices=["kernel", "dma", "sync"],
                     help="diagnostic: how the tracker uploads its per-match descriptors (GoMatching.h2d_mode)")
+    ap.add_argument("--tracker-cus", type=int, default=-1,
+                    help="compute units reserved for the tracker stream (CU-masked streams); -1 = 32 when the tracker handles "
+                         "more than one GPU's frames (world size or --emulate-world > 1), else 0")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="N=1 diagnostic: run the replicated tracker over W copies of this GPU's records per step, i.e. "
                          "the tracker load of a W-GPU run, beside one GPU's detection (value still counts 8 frames/step)")
@@ -224,6 +227,9 @@ def main():
             ops.FUSED_MATCHER = True
         if args.h2d:
             model.h2d_mode = args.h2d
+        cus = args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world > 1 else 0)
+        if cus > 0 and device.type == "cuda":
+            model.reserve_tracker_cus(cus)
         if not shifts:
             shifts["s"], shifts["r"] = calibrate(model, cal_inputs, frac=args.detect_frac)
         else:
@@ -231,26 +237,42 @@ def main():
             if shifts["r"] is not None:
                 model.roi_heads._rescoring[1].add_(shifts["r"])
         tc_box = [new_time_cost()]
+        last_rec = [None]
+        model._bench_last_rec = last_rec
 
         def finish(h):
             """Tracker half of a step (runs on the tracker stream, overlapping the next step's detection)."""
             tc = tc_box[0]
+            w0 = time.time()
             model.begin_batch([], FRAMES_PER_GPU * world * args.emulate_world)
+            h["event"].synchronize()
+            w1 = time.time()
             dets = model.detect_finish(h, tc)
+            w2 = time.time()
             if args.emulate_world > 1 and world == 1:
                 from gomatching_amd.dist import pack_records, unpack_records
                 T = cfg.MODEL.TRANSFORMER
                 rec = pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, device)
+                last_rec[0] = (rec, dets[0].image_size)
                 dets = unpack_records(torch.cat([rec] * args.emulate_world), dets[0].image_size,
                                       model.roi_heads.feature_dim, T.NUM_POINTS)
+                w3 = time.time()
                 insts, id_count = model.track_frames(dets, 0, 0, [], tc)
             elif world > 1:
+                w3 = time.time()
                 insts, id_count = exchange_and_track(model, dets, 0, 0, [], tc)
             else:
+                w3 = time.time()
                 insts, id_count = model.track_frames(dets, 0, 0, [], tc)
+            w4 = time.time()
             if model.min_track_len > 0:
                 insts = model._remove_short_track(insts)
-            return model.batch_postprocess(insts, [hw] * len(insts)), id_count
+            out = model.batch_postprocess(insts, [hw] * len(insts)), id_count
+            w5 = time.time()
+            for key, dt in (("finish_wait_detector", w1 - w0), ("finish_embed", w2 - w1), ("finish_exchange", w3 - w2),
+                            ("finish_track", w4 - w3), ("finish_post", w5 - w4)):
+                tc[key] = tc.get(key, 0.0) + dt
+            return out
 
         return model, sd, ClipPipeline(model, finish), tc_box
 
@@ -297,6 +319,25 @@ def main():
     elapsed_hbm = elapsed
     if args.inputs == "host":                                  # secondary: the same K steps with the frames already in HBM
         elapsed_hbm, _, _ = timed(pipe, tc_box, hbm_inputs, args.steps, 1)
+
+    tracker_alone_ms = None
+    if args.emulate_world > 1 and world == 1 and model._bench_last_rec[0] is not None:
+        # the SAME tracker work with the GPU otherwise idle: what the chain of small dependent kernels costs without the
+        # detector's workgroups in its way
+        from gomatching_amd.dist import unpack_records
+        T_ = cfg.MODEL.TRANSFORMER
+        rec, isz = model._bench_last_rec[0]
+        times = []
+        for _ in range(4):
+            model.begin_batch([], FRAMES_PER_GPU * args.emulate_world)
+            dets = unpack_records(torch.cat([rec] * args.emulate_world), isz, model.roi_heads.feature_dim, T_.NUM_POINTS)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            with torch.cuda.stream(model._tracker_stream()):    # the tracker's own lane when CUs are reserved for it
+                model.track_frames(dets, 0, 0, [], new_time_cost())
+            torch.cuda.synchronize()
+            times.append((time.time() - t0) * 1e3)
+        tracker_alone_ms = sorted(times)[len(times) // 2]
 
     # Roofline leg.  The timed steps replay the detector as a hipGraph, which hides individual launches from HIP
     # events; the dominant kernel is therefore bracketed with events in PROFILE_STEPS eager steps of the same
@@ -359,6 +400,8 @@ def main():
                               "frames already in HBM" % (FRAMES_PER_GPU * 3 * net_hw[0] * net_hw[1] * 4 / 1e6))
                    if args.inputs == "host" else "frames resident in HBM when the timed window starts",
                    "frames_per_step": FRAMES_PER_GPU * world, "emulated_world": args.emulate_world,
+                   "tracker_alone_ms_per_step": tracker_alone_ms,
+                   "tracker_cus": args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world > 1 else 0),
                    "pipelining": "upload(step i+1) and detector(step i+1) overlap tracker(step i)",
                    "detector_hipgraph": graphed,
                    "parallelism": "frame-sharded dp%d + 1 all-gather/step"

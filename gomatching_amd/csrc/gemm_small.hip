@@ -8,57 +8,75 @@
 namespace {
 
 constexpr int RM = 8;                                                  // rows of A per wave
+constexpr int CN = 8;                                                  // output columns per wave
 
-// One wave owns output column n for RM consecutive rows: the weight row streams once per wave (16-byte loads, 64
-// lanes stride the K axis), the RM activation rows come from L1/L2, RM fp32 fmaf chains, fixed-order butterflies.
+// One wave owns an RM x CN patch of outputs: per 256-wide k-step CN weight quads and RM activation quads feed RM x CN fmaf
+// chains (1 KB of loads per output instead of 4.5 with one column per wave: the kernel was bound by re-reading A through
+// L1), 64 lanes stride the K axis.  The 64 per-lane partial sums are reduced by a TRANSPOSING butterfly: at offset o a lane
+// keeps the half of its values whose index has bit o equal to its own lane bit and adds the partner's copy of that half --
+// 63 exchanges instead of 64 x 6, the same (own + partner) tree at offsets 32, 16, ..., 1 as a per-value wave_sum, so every
+// output has exactly the bits the one-column kernel gave it; lane l ends up with output (column l >> 3, row l & 7).
 // An output's arithmetic depends only on (its row, its column, K): results do not change with M or N.
-// NOTE (round 2): built WITHOUT packed-fp32 instructions like the whole library (build.py): as `v_pk_fma_f32` pairs these eight
-// fmaf chains returned wrong LOW halves (= even rows) in 11-25 % of launches whenever waves of the bf16x6 GEMM kernel shared
-// the SIMD -- the round-1 "tracker determinism" issue (tools/race_repro.py).
+// NOTE (round 2): built WITHOUT packed-fp32 instructions like the whole library (build.py): as `v_pk_fma_f32` pairs such
+// adjacent fmaf chains returned wrong LOW halves (= even rows) in 11-25 % of launches whenever waves of the bf16x6 GEMM kernel
+// shared the SIMD -- the round-1 "tracker determinism" issue (tools/race_repro.py).
 __global__ __launch_bounds__(256) void gemm_small_kernel(const float* __restrict__ A, const int* __restrict__ a_rows,
                                                          int lda, const float* __restrict__ W, int ldw,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ R, int ldr, int relu,
                                                          float* __restrict__ C, int ldc, int M, int N, int K) {
     const int lane = threadIdx.x & 63;
-    const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (row group, column), column fastest
-    const int groups = (M + RM - 1) / RM;
-    if (o >= (long)groups * N) return;
-    const int n = (int)(o % N), m0 = (int)(o / N) * RM;
-    const float* w = W + (size_t)n * ldw;
+    const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (row group, column group), column group fastest
+    const int row_groups = (M + RM - 1) / RM, col_groups = (N + CN - 1) / CN;
+    if (o >= (long)row_groups * col_groups) return;
+    const int n0 = (int)(o % col_groups) * CN, m0 = (int)(o / col_groups) * RM;
+    const float* w[CN];
     const float* a[RM];
 #pragma unroll
+    for (int c = 0; c < CN; ++c) w[c] = W + (size_t)(n0 + c < N ? n0 + c : N - 1) * ldw;   // clamp: tail patches recompute
+#pragma unroll
     for (int r = 0; r < RM; ++r) {
-        const int m = m0 + r < M ? m0 + r : M - 1;                     // clamp: tail rows recompute the last row
+        const int m = m0 + r < M ? m0 + r : M - 1;
         a[r] = A + (size_t)(a_rows ? a_rows[m] : m) * lda;
     }
-    float acc[RM];
+    float v[CN * RM];                                                  // index c * RM + r
 #pragma unroll
-    for (int r = 0; r < RM; ++r) acc[r] = 0.f;
+    for (int j = 0; j < CN * RM; ++j) v[j] = 0.f;
+#pragma unroll 2
     for (int k = lane * 4; k < K; k += 256) {
-        const f32x4 y = *reinterpret_cast<const f32x4*>(w + k);
+        f32x4 y[CN], x[RM];
 #pragma unroll
-        for (int r = 0; r < RM; ++r) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(a[r] + k);
-            acc[r] = fmaf(x[0], y[0], acc[r]);
-            acc[r] = fmaf(x[1], y[1], acc[r]);
-            acc[r] = fmaf(x[2], y[2], acc[r]);
-            acc[r] = fmaf(x[3], y[3], acc[r]);
-        }
+        for (int c = 0; c < CN; ++c) y[c] = *reinterpret_cast<const f32x4*>(w[c] + k);
+#pragma unroll
+        for (int r = 0; r < RM; ++r) x[r] = *reinterpret_cast<const f32x4*>(a[r] + k);
+#pragma unroll
+        for (int c = 0; c < CN; ++c)
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                float t = v[c * RM + r];
+                t = fmaf(x[r][0], y[c][0], t);
+                t = fmaf(x[r][1], y[c][1], t);
+                t = fmaf(x[r][2], y[c][2], t);
+                t = fmaf(x[r][3], y[c][3], t);
+                v[c * RM + r] = t;
+            }
     }
 #pragma unroll
-    for (int r = 0; r < RM; ++r) acc[r] = wave_sum(acc[r]);
-    if (lane == 0) {
-        const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+    for (int half = CN * RM / 2; half > 0; half >>= 1) {
+        const bool up = (lane & half) != 0;
 #pragma unroll
-        for (int r = 0; r < RM; ++r) {
-            const int m = m0 + r;
-            if (m < M) {
-                float v = acc[r] * sc + sh;
-                if (R) v += R[(size_t)m * ldr + n];
-                C[(size_t)m * ldc + n] = relu ? fmaxf(v, 0.f) : v;
-            }
+        for (int j = 0; j < half; ++j) {
+            const float send = up ? v[j] : v[j + half];
+            const float keep = up ? v[j + half] : v[j];
+            v[j] = keep + __shfl_xor(send, half, 64);
         }
+    }
+    const int n = n0 + (lane >> 3), m = m0 + (lane & 7);
+    if (n < N && m < M) {
+        const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+        float y = v[0] * sc + sh;
+        if (R) y += R[(size_t)m * ldr + n];
+        C[(size_t)m * ldc + n] = relu ? fmaxf(y, 0.f) : y;
     }
 }
 
@@ -72,7 +90,7 @@ extern "C" int gom_gemm_small_f32(const float* A, const int* a_rows, int lda, co
     GOM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
     if (M == 0) return GOM_OK;
     GOM_CHECK_ARG((long)M * N <= (1L << 22));
-    const long waves = (long)cdiv(M, RM) * N;
+    const long waves = (long)cdiv(M, RM) * cdiv(N, CN);
     hipLaunchKernelGGL(gemm_small_kernel, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, A, a_rows, lda,
                        W, ldw, scale, shift, R, ldr, relu, C, ldc, M, N, K);
     return gom_launch_status();

@@ -18,7 +18,8 @@ struct Lin {
     const float* b;
 };
 
-// Same rule as ops.gemm(..., small=True): <= 2^16 outputs -> one-wave-per-column VALU kernel, otherwise the deterministic
+// Same rule as ops.gemm(..., small=True): <= 64 rows or <= 2^16 outputs -> the patch-per-wave VALU kernel (a long-term match
+// of the bench's clips has 9-53 rows: weight streaming, ~5 us per layer), otherwise the deterministic
 // split-K exact-fp32 MFMA GEMM up to 1024 rows (tools/skinny_bench.py: 20-50 us against 85-95 us for the whole-K
 // loop), the plain exact-fp32 MFMA GEMM beyond.
 struct Ctx {
@@ -30,7 +31,7 @@ struct Ctx {
 int linear(const Ctx& c, const float* A, int lda, int M, Lin l, int N, int K, const float* R, int ldr, int relu, float* C,
            int ldc) {
     if (M <= 0) return GOM_OK;
-    if ((long)M * N <= (1L << 16))
+    if (M <= 64 || (long)M * N <= (1L << 16))
         return gom_gemm_small_f32(A, nullptr, lda, l.w, K, nullptr, l.b, R, ldr, relu, C, ldc, M, N, K, c.stream);
     if (M <= 1024)
         return gom_gemm_f32_splitk(A, nullptr, lda, l.w, K, nullptr, l.b, R, ldr, relu, C, ldc, M, N, K, c.splitk_ws,

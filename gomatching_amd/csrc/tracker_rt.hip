@@ -88,6 +88,7 @@ std::vector<long> sorted_unique(std::vector<long> v) {
     return v;
 }
 
+int g_sizes = -1;                    // GOM_TRACKER_SIZES=1: one stderr line per long-term match (sizes of the problem)
 int g_double_check = -1;             // GOM_TRACKER_DOUBLE_CHECK=1: run every long-term chain twice and compare (diagnostic)
 int g_tracker_fused = 0;             // long-term matches through the persistent one-kernel matcher when it takes the problem
 
@@ -218,6 +219,11 @@ extern "C" int gom_tracker_run(void* handle, int F, const int* n, const float* b
         uniq = sorted_unique(ids_nonk);
         const int M = (int)uniq.size();
         std::vector<long> new_ids(n_k, -1);
+        if (g_sizes < 0) {
+            const char* e = getenv("GOM_TRACKER_SIZES");
+            g_sizes = (e && e[0] == '1') ? 1 : 0;
+        }
+        if (g_sizes) fprintf(stderr, "MATCH frame %ld T %d N %d n_k %d tracks %d\n", real, T, N, n_k, M);
         if (n_k > 0 && M > 0) {
             // descriptors: rows[N] | offs[T+1] | nonk[Np] col_of[Np] last[M] k_inds[n_k] | boxes[4N] | decay[Np]
             const long words = (long)N + (T + 1) + (2L * Np + M + n_k) + 4L * N + (t->use_decay ? Np : 0);

@@ -108,6 +108,8 @@ SIGNATURES = {
     "gom_tracker_create": (P, [I, F, I, I, I, F, P, I, P, I, I, I, I]),
     "gom_tracker_destroy": (None, [P]),
     "gom_tracker_set_fused": (I, [I]),
+    "gom_stream_create_cu_mask": (I, [P, I, P]),
+    "gom_stream_destroy": (I, [P]),
     "gom_tracker_run": (I, [P, I, P, P, P, P, I, L, P, P, P, I, F, F, P, P, P, P]),
     "gom_match_fused_set_grid": (I, [I]),
     "gom_linear_sum_assignment": (I, [ctypes.POINTER(ctypes.c_double), L, L, ctypes.POINTER(c_long),

@@ -299,6 +299,11 @@ class GoMatching:
         with a non-blocking D2H copy of the nq-padded detection summary and an event.  No host sync, no tracker
         state touched -- a caller may queue the next step's detection before finishing this one."""
         assert not self.training
+        lane = getattr(self, "_det_stream", None)
+        if lane is not None and torch.cuda.current_stream() != lane:     # CU-partitioned step: the detector's own lane
+            lane.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(lane):
+                return self.detect_launch(batched_inputs, time_cost)
         B = len(batched_inputs)
         graphed = self._detect_graphed(batched_inputs, time_cost) if self.use_graphs else None
         if graphed is not None:
@@ -739,6 +744,29 @@ class GoMatching:
             self._trk_stream = torch.cuda.Stream(device=self.device, priority=-1)
         return self._trk_stream
 
+    def reserve_tracker_cus(self, n_cus=32):
+        """Multi-GPU steps (the replicated tracker handles world_size x 8 frames per step): give the tracker stream `n_cus`
+        compute units of its own (for its per-frame recurrence) and the detector stream the rest (csrc/stream.hip).  The tracker is a recurrence of small
+        dependent kernels; beside the detector each of them waits for resident workgroups to drain (0.7 ms per frame against
+        0.19 ms on an idle GPU) and bounds the step from 4 GPUs on.  The first 32 mask bits are one CU per (XCD, shader engine),
+        so both lanes stay symmetric over the eight XCDs (the XCD-aware tile orders of the detector's kernels keep working).
+        n_cus = 0 undoes the reservation.  Not worth it on one GPU, where the tracker of 8 frames is 2 ms of a 36 ms step."""
+        torch.cuda.synchronize(self.device)
+        self._lane_stream = self._det_stream = None
+        if n_cus <= 0:
+            return
+        total = torch.cuda.get_device_properties(self.device).multi_processor_count
+        assert 0 < n_cus < total
+        words = (total + 31) // 32
+        trk, det = [0] * words, [0] * words
+        for i in range(total):
+            (trk if i < n_cus else det)[i // 32] |= 1 << (i % 32)
+        # the per-frame recurrence (gom_tracker_run's chain of small dependent launches) gets the lane; the tracker's few BIG
+        # launches (embedding GEMMs of detect_finish, the batched short-term precompute) stay on the ordinary high-priority
+        # tracker stream: on 32 CUs they took twice as long (bench --emulate-world 8: short-term 6.1 -> 12.7 ms per step)
+        self._lane_stream = ops.masked_stream(trk, self.device)
+        self._det_stream = ops.masked_stream(det, self.device)
+
     def begin_batch(self, instances, num_new_frames):
         """Keep the carried-over window's embeddings addressable, drop everything older, size the pool."""
         carried = [x for x in instances[-self.test_len:] if x.has("reid_features")]
@@ -871,10 +899,17 @@ class GoMatching:
         hw = dets[0].image_size
         ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         time_cost["short_match"] += time.time() - t0
+        run_stream = ops._stream()
+        lane = getattr(self, "_lane_stream", None)
+        if lane is not None:                                     # CU-partitioned step: the recurrence runs on its own CUs
+            lane.wait_stream(torch.cuda.current_stream())        # ... after the embeddings it gathers from the pool
+            run_stream = lane.cuda_stream
         ops.check(L.gom_tracker_run(trk, len(window), ptr(n), ptr(boxes), ptr(rows), ptr(ids), first_new, start,
                                     ptr(S_all), ptr(s_off), ctypes.c_void_p(self._pool.data_ptr()), self._pool.stride(0),
                                     float(hw[1]), float(hw[0]), ptr(self._decay_table), ctypes.byref(idc), secs,
-                                    ops._stream()), "gom_tracker_run")
+                                    run_stream), "gom_tracker_run")
+        if lane is not None:
+            torch.cuda.current_stream().wait_stream(lane)        # the pool may be rewritten by later work on this stream
         time_cost["short_match"] += secs[0]
         time_cost["long_match"] += secs[1]
         self._defer_ids = True

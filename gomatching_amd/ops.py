@@ -169,7 +169,8 @@ def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols=None):
 
 
 SPLITK_MAX_ROWS = 1024
-SMALL_GEMM_OUTPUTS = 1 << 16         # M*N up to which gemm(..., small=True) runs one-wave-per-output (tracker logits)
+SMALL_GEMM_OUTPUTS = 1 << 16         # M*N up to which gemm(..., small=True) runs the patch-per-wave VALU kernel (tracker logits)
+SMALL_GEMM_ROWS = 64                 # ... and any N up to this many rows (csrc/matcher_rt.cpp `linear` applies the same rule)
 
 
 def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, out=None, M=None, splitk=None,
@@ -217,7 +218,7 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
     # VALU (7-20 us); larger ones take the deterministic split-K (20-50 us) instead of looping the whole K in few
     # workgroups (85-95 us whatever M is; tools/skinny_bench.py)
     if small and A2 is None and M > 0:
-        if M * N <= SMALL_GEMM_OUTPUTS and K % 4 == 0 and lda % 4 == 0 and ldw % 4 == 0:
+        if (M <= SMALL_GEMM_ROWS or M * N <= SMALL_GEMM_OUTPUTS) and K % 4 == 0 and lda % 4 == 0 and ldw % 4 == 0:
             check(_L().gom_gemm_small_f32(_p(A), _p(rows), lda, _p(W), ldw, _p(scale), _p(bias), _p(R), ldr,
                                           1 if relu else 0, _p(out), ldc, M, N, K, _stream()), "gom_gemm_small_f32")
             return out
@@ -299,6 +300,16 @@ def groupnorm32_into(x, gamma, beta, out_view, out_batch_stride, eps=1e-5):
     ws = torch.empty((B * 64,), dtype=torch.float64, device=x.device)
     check(_L().gom_groupnorm32_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(ws), _p(out_view), out_batch_stride, B, HW, C,
                                         eps, _stream()), "gom_groupnorm32_nhwc_f32")
+
+
+def masked_stream(mask_words, device):
+    """A torch stream (ExternalStream over gom_stream_create_cu_mask) restricted to the CUs of `mask_words` (list of uint32)."""
+    import ctypes
+    arr = (ctypes.c_uint32 * len(mask_words))(*[int(w) & 0xFFFFFFFF for w in mask_words])
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        check(_L().gom_stream_create_cu_mask(arr, len(mask_words), ctypes.byref(out)), "gom_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(out.value, device=device)
 
 
 K256_GEMM = True         # f16x3 back-end: K = 256 products on the row-resident kernel where it measures faster (below)

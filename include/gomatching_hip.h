@@ -382,9 +382,17 @@ void* gom_tracker_create(int test_len, float overlap_thresh, int not_mult_thresh
                          int n_dec, int d, int heads, int ffn);
 void gom_tracker_destroy(void* tracker);
 int gom_tracker_set_fused(int on);      /* [host] long-term matches through gom_match_scores_fused_f32 when supported (default off) */
+
 int gom_tracker_run(void* tracker, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
                     long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool, float img_w,
                     float img_h, const float* decay_table, long* id_count_io, double* secs, void* stream);
+/* ---- CU-partitioned streams (csrc/stream.hip): the tracker's lane of a multi-GPU step ------------------------------------
+ * [host] A HIP stream whose kernels run only on the compute units of cu_mask (`words` x 32 bits, bit i = CU i of the driver's
+ * enumeration).  GoMatching.reserve_tracker_cus() gives the tracker stream a few CUs of every XCD and the detector stream the
+ * rest, so that the tracker's small dependent launches never queue behind the detector's resident workgroups. */
+int gom_stream_create_cu_mask(const unsigned* cu_mask, int words, void** stream_out);
+int gom_stream_destroy(void* stream);
+
 /* [host] rectangular assignment, SciPy-compatible tie-breaking (gom_lstmatcher.py:447,549).  Returns the number
  * of assigned pairs (min(nr,nc)) or a negative error. */
 int gom_linear_sum_assignment(const double* cost, long nr, long nc, long* row_ind, long* col_ind);
