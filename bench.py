@@ -151,8 +151,6 @@ def main():
     ap.add_argument("--detect-frac", type=float, default=0.3,
                     help="fraction of the queries the calibrated biases let through the score threshold (SURVEY.md §8-d: "
                          "0.3 for the BASELINE workload; 1.0 = the tracker-stress variant, every query a detection before NMS)")
-    ap.add_argument("--fused-matcher", type=int, default=0,
-                    help="diagnostic: long-term matches through the persistent one-kernel matcher with this many workgroups")
     ap.add_argument("--h2d", default=None, choices=["kernel", "dma", "sync"],
                     help="diagnostic: how the tracker uploads its per-match descriptors (GoMatching.h2d_mode)")
     ap.add_argument("--tracker-cus", type=int, default=-1,
@@ -220,11 +218,6 @@ def main():
         clip, the default back-end's shifts being reused so that all of them hold identical weights."""
         ops.GEMM_MODE = mode
         model, sd = build_model(cfg, device)
-        if args.fused_matcher:
-            from gomatching_amd import lib as _lib
-            _lib.load().gom_tracker_set_fused(1)
-            _lib.load().gom_match_fused_set_grid(args.fused_matcher)
-            ops.FUSED_MATCHER = True
         if args.h2d:
             model.h2d_mode = args.h2d
         cus = args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world > 1 else 0)

@@ -90,7 +90,6 @@ std::vector<long> sorted_unique(std::vector<long> v) {
 
 int g_sizes = -1;                    // GOM_TRACKER_SIZES=1: one stderr line per long-term match (sizes of the problem)
 int g_double_check = -1;             // GOM_TRACKER_DOUBLE_CHECK=1: run every long-term chain twice and compare (diagnostic)
-int g_tracker_fused = 0;             // long-term matches through the persistent one-kernel matcher when it takes the problem
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -107,11 +106,6 @@ extern "C" void* gom_tracker_create(int test_len, float overlap_thresh, int not_
     for (int i = 0; i < n_enc; ++i) t->enc[i] = enc[i];
     for (int i = 0; i < n_dec; ++i) t->dec[i] = dec[i];
     return t;
-}
-
-extern "C" int gom_tracker_set_fused(int on) {
-    g_tracker_fused = on ? 1 : 0;
-    return GOM_OK;
 }
 
 extern "C" void gom_tracker_destroy(void* h) {
@@ -271,8 +265,7 @@ extern "C" int gom_tracker_run(void* handle, int F, const int* n, const float* b
             const float* d_boxes = (const float*)(d_meta + (2L * Np + M + n_k));
             const float* d_decay = t->use_decay ? d_boxes + 4L * N : nullptr;
             const int lo = p_offs[k];
-            auto chain = (g_tracker_fused && gom_match_fused_supported(N, n_k, t->d, t->heads, t->n_enc, t->n_dec))
-                             ? gom_match_scores_fused_f32 : gom_match_scores_f32;
+            auto chain = gom_match_scores_f32;
             rc = chain(pool_dev, ld_pool, d_rows, d_offs, d_meta, d_boxes, d_decay, N, T, lo, lo + n_k, M, t->enc, t->n_enc, t->dec,
                        t->n_dec, t->d, t->heads, t->ffn, img_w, img_h, t->with_iou, t->max_center_dist, t->ws_dev, nws,
                        t->traj_dev, stream);

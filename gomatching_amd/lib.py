@@ -103,15 +103,11 @@ SIGNATURES = {
     "gom_flash_attention_f32": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
     "gom_match_workspace_floats": (L, [I, I, I, I]),
     "gom_match_scores_f32": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
-    "gom_match_scores_fused_f32": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
-    "gom_match_fused_supported": (I, [I, I, I, I, I, I]),
     "gom_tracker_create": (P, [I, F, I, I, I, F, P, I, P, I, I, I, I]),
     "gom_tracker_destroy": (None, [P]),
-    "gom_tracker_set_fused": (I, [I]),
     "gom_stream_create_cu_mask": (I, [P, I, P]),
     "gom_stream_destroy": (I, [P]),
     "gom_tracker_run": (I, [P, I, P, P, P, P, I, L, P, P, P, I, F, F, P, P, P, P]),
-    "gom_match_fused_set_grid": (I, [I]),
     "gom_linear_sum_assignment": (I, [ctypes.POINTER(ctypes.c_double), L, L, ctypes.POINTER(c_long),
                                       ctypes.POINTER(c_long)]),
 }

@@ -956,11 +956,6 @@ def short_term_pairs(tgt, memory, pairs, row_pair, boxes, img_w, img_h, with_iou
     return S
 
 
-# True: matches of <= 256 rows as ONE persistent kernel with grid-wide phases (match_fused.hip).  Correct (same tests as the
-# chain) but measured SLOWER beside a saturated GPU -- 620 us per match at 64 workgroups (840 before four columns per wave)
-# against 430 us for the 18-kernel chain, whose kernels each spread over every free wave slot of the chip -- so it stays
-# off.
-FUSED_MATCHER = False
 NATIVE_TRACKER = True      # the per-frame id recurrence of a track_frames call in native code (tracker_rt.hip); False: Python loop
 NATIVE_MATCHER = True      # False: compose the match from per-kernel calls in Python (kept for the A/B parity test)
 
@@ -991,13 +986,6 @@ def match_scores(pool, rows, frame_offsets, meta, boxes, decay, N, T, lo, hi, nu
     nws = _L().gom_match_workspace_floats(N, n_k, d, ffn)
     ws = torch.empty((nws,), dtype=_f32, device=pool.device)
     traj = torch.empty((n_k, num_tracks), dtype=_f32, device=pool.device)
-    if FUSED_MATCHER and _L().gom_match_fused_supported(N, n_k, d, heads, n_enc, n_dec):
-        # one persistent kernel with grid-wide phases instead of ~18 dependent launches (match_fused.hip)
-        check(_L().gom_match_scores_fused_f32(_p(pool), pool.stride(0), _p(rows), _p(frame_offsets), _p(meta), _p(boxes),
-                                              _p(decay), N, T, lo, hi, num_tracks, enc, n_enc, dec, n_dec, d, heads, ffn,
-                                              float(img_w), float(img_h), 1 if with_iou else 0, float(max_center_dist),
-                                              _p(ws), nws, _p(traj), _stream()), "gom_match_scores_fused_f32")
-        return traj
     check(_L().gom_match_scores_f32(_p(pool), pool.stride(0), _p(rows), _p(frame_offsets), _p(meta), _p(boxes),
                                     _p(decay), N, T, lo, hi, num_tracks, enc, n_enc, dec, n_dec, d, heads, ffn,
                                     float(img_w), float(img_h), 1 if with_iou else 0, float(max_center_dist), _p(ws),

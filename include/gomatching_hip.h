@@ -361,18 +361,6 @@ int gom_match_scores_f32(const float* pool, int ld_pool, const int* rows, const 
                          const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec, int n_dec, int d,
                          int heads, int ffn, float img_w, float img_h, int with_iou, float max_center_dist,
                          float* workspace, long workspace_floats, float* traj, void* stream);
-/* The same match as ONE persistent kernel (match_fused.hip): phases separated by grid-wide barriers instead of kernel
- * boundaries -- a match then costs one launch instead of ~18 dependent ones.  Same arguments and workspace as
- * gom_match_scores_f32 (the last 64 workspace floats hold the barrier word).  gom_match_fused_supported() tells whether a
- * problem is inside its range (N <= 256 rows, head_dim 128, at most one encoder layer); outside it returns
- * GOM_ERR_UNSUPPORTED and the caller uses gom_match_scores_f32. */
-int gom_match_fused_supported(int N, int n_k, int d, int heads, int n_enc, int n_dec);
-int gom_match_fused_set_grid(int workgroups);           /* [host] size of the persistent grid (default 16), 1..256 */
-int gom_match_scores_fused_f32(const float* pool, int ld_pool, const int* rows, const int* frame_offsets, const int* meta,
-                               const float* boxes, const float* decay, int N, int T, int lo, int hi, int num_tracks,
-                               const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec, int n_dec, int d,
-                               int heads, int ffn, float img_w, float img_h, int with_iou, float max_center_dist,
-                               float* workspace, long workspace_floats, float* traj, void* stream);
 /* [host + device] The per-frame id recurrence of GoMatching.track_frames for all frames of a call behind ONE crossing
  * (tracker_rt.hip; gom_lstmatcher.py:366-564): short-term assignment from precomputed score matrices, long-term match
  * (selection, descriptors, gom_match_scores_f32, LSA, thresholds, id allocation).  Host arrays in, ids out; see the
@@ -381,7 +369,6 @@ void* gom_tracker_create(int test_len, float overlap_thresh, int not_mult_thresh
                          float max_center_dist, const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec,
                          int n_dec, int d, int heads, int ffn);
 void gom_tracker_destroy(void* tracker);
-int gom_tracker_set_fused(int on);      /* [host] long-term matches through gom_match_scores_fused_f32 when supported (default off) */
 
 int gom_tracker_run(void* tracker, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
                     long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool, float img_w,

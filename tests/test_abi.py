@@ -66,9 +66,6 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.gom_softmax_rows_scaled_f32(p, 4, 9000, 9000, 1.0, None) == INVALID                         # > 8192 columns
     assert L.gom_transpose_f32(p, p, 8, 8, 4, 8, None) == INVALID                                        # ld < cols
     assert L.gom_copy_words(None, p, 4, None) == INVALID
-    assert L.gom_match_fused_supported(300, 10, 1024, 8, 1, 1) == 0 and L.gom_match_fused_supported(64, 10, 1024, 8, 1, 1) == 1
-    assert L.gom_match_fused_supported(64, 10, 1024, 16, 1, 1) == 0                                      # head_dim 64
-    assert L.gom_match_fused_set_grid(0) == INVALID and L.gom_match_fused_set_grid(64) == 0
     assert L.gom_tracker_create(0, 0.2, 1, 1, 1, 1.0, None, 0, None, 0, 1024, 8, 1024) is None           # test_len < 1
     assert L.gom_tracker_create(6, 0.2, 1, 1, 1, 1.0, None, 1, None, 0, 1024, 8, 1024) is None           # layers without weights
 

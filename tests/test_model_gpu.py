@@ -126,17 +126,17 @@ def test_matcher_heads_golden(builtin, tag):
         _close(rh._activate_asso(logits, n_t), g["asso%d_out" % ci], 1e-4, "asso act")
 
 
-@pytest.fixture(params=["tracker_rt", "fused", "native", "python"])
+@pytest.fixture(params=["tracker_rt", "native", "python"])
 def matcher_runtime(request):
     """tracker_rt: the whole per-frame recurrence in native code (default).  Otherwise the Python loop of `track_frames`
-    with the per-match device chain as ONE persistent kernel (fused), issued kernel by kernel by the native runtime (one
-    FFI call per match), or composed kernel by kernel in Python."""
+    with the per-match device chain issued kernel by kernel by the native runtime (one FFI call per match), or composed kernel
+    by kernel in Python."""
     from gomatching_amd import ops
-    old = ops.NATIVE_MATCHER, ops.FUSED_MATCHER, ops.NATIVE_TRACKER
+    old = ops.NATIVE_MATCHER, ops.NATIVE_TRACKER
     ops.NATIVE_TRACKER = request.param == "tracker_rt"
-    ops.NATIVE_MATCHER, ops.FUSED_MATCHER = request.param != "python", request.param == "fused"
+    ops.NATIVE_MATCHER = request.param != "python"
     yield request.param
-    ops.NATIVE_MATCHER, ops.FUSED_MATCHER, ops.NATIVE_TRACKER = old
+    ops.NATIVE_MATCHER, ops.NATIVE_TRACKER = old
 
 
 @pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
@@ -236,7 +236,7 @@ def test_tracker_across_100_frame_batches_vs_oracle(builtin, matcher_runtime):
 @pytest.mark.parametrize("n_t,k", [([7, 0, 12, 5], 3), ([60, 70, 90], 2), ([1, 1], 1), ([3, 140], 1)])
 def test_native_match_runtime_equals_python_composition(builtin, n_t, k):
     """gom_match_scores_f32 (matcher_rt.cpp) returns the same bits as the per-kernel Python composition, for the
-    long- and the short-term matcher, rows below and above the 128-row kernel switch, an empty frame in the window."""
+    long- and the short-term matcher, rows below and above the 64-row kernel switch, an empty frame in the window."""
     from gomatching_amd import ops
     from gomatching_amd.modeling.roi_heads import build_roi_heads
     from gomatching_amd.weights import synth_state_dict
@@ -259,19 +259,15 @@ def test_native_match_runtime_equals_python_composition(builtin, n_t, k):
     decay = (0.9 ** torch.arange(Np).float()).to(DEV)
     out = {}
     for short_term in (False, True):
-        for mode in ("fused", "native", "python"):
-            ops.NATIVE_MATCHER, ops.FUSED_MATCHER = mode != "python", mode == "fused"
+        for mode in ("native", "python"):
+            ops.NATIVE_MATCHER = mode != "python"
             try:
                 out[mode] = heads.match_scores(pool, rows, offs, meta, boxes, None if short_term else decay, n_t, k,
                                                short_term, (96, 128), M, True, 0.0 if short_term else 50.0)
             finally:
-                ops.NATIVE_MATCHER, ops.FUSED_MATCHER = True, False
+                ops.NATIVE_MATCHER = True
         assert out["native"].shape == (n_k, M) and torch.isfinite(out["native"]).all()
         assert torch.equal(out["native"], out["python"])
-        # the persistent one-kernel form (match_fused.hip, <= 256 rows) runs every linear layer on the fp32 FMA scheme:
-        # same values up to the summation order of the MFMA split-K kernel the chain uses for its larger products
-        assert out["fused"].shape == (n_k, M)
-        assert float((out["fused"] - out["native"]).abs().max()) <= 2e-5, float((out["fused"] - out["native"]).abs().max())
 
 
 @pytest.mark.parametrize("builtin", ["icdar15", "pp_dstext"])

@@ -31,13 +31,6 @@ for name, key in (("_assign", "assign"), ("precompute_short_term", "short"), ("t
 import bench
 from gomatching_amd import ops as _ops0
 _ops0.NATIVE_TRACKER = False          # these tools dissect the PYTHON loop of track_frames (the native runtime is one opaque call)
-if len(sys.argv) > 2:
-    from gomatching_amd import lib as _lib, ops as _ops
-    if sys.argv[2] == "chain":
-        _ops.FUSED_MATCHER = False
-    else:                                                        # the persistent one-kernel form with this many workgroups
-        _ops.FUSED_MATCHER = True
-        _lib.load().gom_match_fused_set_grid(int(sys.argv[2]))
 sys.argv = ["bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--emulate-world", sys.argv[1] if len(sys.argv) > 1 else "8"]
 bench.main()
 m = max(prof["matches"], 1)
