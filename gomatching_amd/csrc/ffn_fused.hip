@@ -144,9 +144,20 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    constexpr unsigned OOB = 0x7FFF0000u;                    // beyond num_records: such a DMA writes zeros (into an unused stage)
     for (int c = 0; c < p.chunks; ++c) {
         const int st = c & 1;
-        if (c + 1 < p.chunks) dma_stage(c + 1, st ^ 1);
+        // The next stage's 65 fragments: fragment 64 (scale | bias) by wave 0 here, fragments wave, wave + 4, ..., wave + 60 --
+        // sixteen per wave -- ONE PER SIX MFMAs inside the products below.  An LDS-DMA instruction costs its wave 100-140
+        // cycles of issue (s_memtime stamps, gemm_k256.hip); issued in a block in front of the MFMAs that was ~2200 cycles per
+        // chunk with the matrix pipe idle (one wave per SIMD), beside running MFMAs it is hidden.
+        const bool more = c + 1 < p.chunks;
+        if (more && wave == 0)
+            dma_fragment(rs_img, (unsigned)(c + 1) * STAGE_BYTES + (W1_FRAGS + W2_FRAGS) * FRAG + lane * 16,
+                         smem + (st ^ 1) * STAGE_BYTES + (W1_FRAGS + W2_FRAGS) * FRAG);
+        const unsigned nsrc = more ? (unsigned)(c + 1) * STAGE_BYTES + wave * FRAG + lane * 16 : OOB;
+        unsigned char* ndst = smem + (st ^ 1) * STAGE_BYTES + wave * FRAG;
+#define FFN_DMA(i) dma_fragment(rs_img, nsrc + (i) * 4 * FRAG, ndst + (i) * 4 * FRAG);
         const unsigned char* base = smem + st * STAGE_BYTES + lane * 16;
 
         // The 64 weight fragments of the chunk are consumed in eight groups of eight (four k-steps); with ONE wave per SIMD
@@ -157,9 +168,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
 #define FFN_LOAD(dst, g)                                                                                      \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                          \
         dst[i_] = *reinterpret_cast<const half8*>(base + ((g) * 8 + i_) * FRAG);
-#define FFN_PIN() \
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+#define FFN_PIN()                                         \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         // ---- H^T chunk = W1c . X^T : one accumulator, 16 k-steps x 3 plane products (smallest terms first) ----
         f32x16 acc1;
 #pragma unroll
@@ -173,10 +187,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     }
         FFN_LOAD(fa, 0)
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // group 0's reads come first, then (reads, MFMAs) pairs
-        FFN_LOAD(fb, 1) FFN_GEMM1(fa, 0) FFN_PIN()
-        FFN_LOAD(fa, 2) FFN_GEMM1(fb, 1) FFN_PIN()
-        FFN_LOAD(fb, 3) FFN_GEMM1(fa, 2) FFN_PIN()
-        FFN_LOAD(fa, 4) FFN_GEMM1(fb, 3) FFN_PIN()               // fa <- first group of W2 fragments
+        FFN_LOAD(fb, 1) FFN_GEMM1(fa, 0) FFN_DMA(0) FFN_DMA(1) FFN_PIN()
+        FFN_LOAD(fa, 2) FFN_GEMM1(fb, 1) FFN_DMA(2) FFN_DMA(3) FFN_PIN()
+        FFN_LOAD(fb, 3) FFN_GEMM1(fa, 2) FFN_DMA(4) FFN_DMA(5) FFN_PIN()
+        FFN_LOAD(fa, 4) FFN_GEMM1(fb, 3) FFN_DMA(6) FFN_DMA(7) FFN_PIN()   // fa <- first group of W2 fragments
         __builtin_amdgcn_sched_barrier(0);
         // ---- relu(acc / row scale + bias), split into two fp16 planes: registers 8u..8u+7 are the B fragment of k-step u ----
         const float* aux = reinterpret_cast<const float*>(smem + st * STAGE_BYTES + (W1_FRAGS + W2_FRAGS) * FRAG);
@@ -206,10 +220,15 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         acc2[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], hf[1][u_], acc2[t_], 0, 0, 0);         \
         acc2[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], hf[0][u_], acc2[t_], 0, 0, 0);         \
     }
-        FFN_LOAD(fb, 5) FFN_GEMM2(fa, 0) FFN_PIN()
-        FFN_LOAD(fa, 6) FFN_GEMM2(fb, 1) FFN_PIN()
-        FFN_LOAD(fb, 7) FFN_GEMM2(fa, 2) FFN_PIN()
-        FFN_GEMM2(fb, 3)
+        FFN_LOAD(fb, 5) FFN_GEMM2(fa, 0) FFN_DMA(8) FFN_DMA(9) FFN_PIN()
+        FFN_LOAD(fa, 6) FFN_GEMM2(fb, 1) FFN_DMA(10) FFN_DMA(11) FFN_PIN()
+        FFN_LOAD(fb, 7) FFN_GEMM2(fa, 2) FFN_DMA(12) FFN_DMA(13) FFN_PIN()
+        FFN_GEMM2(fb, 3) FFN_DMA(14) FFN_DMA(15)
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+#undef FFN_DMA
 #undef FFN_LOAD
 #undef FFN_PIN
 #undef FFN_GEMM1
