@@ -42,7 +42,7 @@ def kernel_source_hash():
     on (tools/pmc_traffic.py), and `roofline.traffic` is only printed while that build is still the current one."""
     import hashlib
     h = hashlib.sha1()
-    for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "common.h"):
+    for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "msda.hip", "common.h"):
         with open(os.path.join(ROOT, "gomatching_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -46,6 +46,7 @@ struct Args {
     int lda, ldw, ldc, ldr;
     int relu;
     int r_cols;                                  // residual applies to columns < r_cols
+    int r_period;                                // > 0: row m reads residual row m % r_period (a table shared by the frames)
     int H, Wd, cin_log2, OH, OW, stride, pad;
     // split-K (few output tiles, long K): blockIdx.y owns k-tiles [y*kt_per_split, ...) and stores raw partial sums
     int kt_per_split;
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const Args p) {
             for (int t = 0; t < 32 / RPI; ++t) {
                 const int m = m0 + wr * WM + i * 32 + t * RPI + lane / C4;
                 rv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (use_r && n_ok && m < p.M) rv[t] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + n);
+                if (use_r && n_ok && m < p.M)
+                    rv[t] = *reinterpret_cast<const f32x4*>(p.R + (size_t)(p.r_period > 0 ? m % p.r_period : m) * p.ldr + n);
             }
 #pragma unroll
             for (int t = 0; t < 32 / RPI; ++t) {
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const Args p) {
                 const int m = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (n_ok && m < p.M) {
                     float v = acc[i][j][r] * sc + sh;
-                    if (use_r) v += p.R[(size_t)m * p.ldr + n];
+                    if (use_r) v += p.R[(size_t)(p.r_period > 0 ? m % p.r_period : m) * p.ldr + n];
                     v = p.relu == 2 ? 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)) : fmaxf(v, relu_lo);
                     bad |= !(fabsf(v) <= 3.4e38f);
                     p.C[(size_t)m * p.ldc + n] = v;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Args p, int sp
     float v = 0.f;
     for (int s = 0; s < splits; ++s) v += p.partial[(size_t)s * p.M * p.N + i];
     v = v * ((p.scale ? p.scale[n] : 1.f) * (p.wscale ? p.wscale[n] : 1.f)) + (p.shift ? p.shift[n] : 0.f);
-    if (p.R && n < p.r_cols) v += p.R[(size_t)m * p.ldr + n];
+    if (p.R && n < p.r_cols) v += p.R[(size_t)(p.r_period > 0 ? m % p.r_period : m) * p.ldr + n];
     if (p.relu == 1) v = fmaxf(v, 0.f);
     if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     if (!(fabsf(v) <= 3.4e38f) && p.flag) atomicOr(p.flag, 1);
@@ -465,7 +467,15 @@ extern "C" int gom_gemm_f32_f16x3(const float* A, const int* a_rows, int lda, co
                                   int ldw, const float* wscale, const float* scale, const float* shift, const float* R,
                                   int ldr, int r_cols, int relu, float* C, int ldc, int M, int N, int K, int* flag,
                                   void* stream) {
-    GOM_CHECK_ARG(A && Wplanes && C);
+    return gom_gemm_f32_f16x3_rp(A, a_rows, lda, Wplanes, w_plane_stride, ldw, wscale, scale, shift, R, ldr, r_cols, 0, relu, C,
+                                 ldc, M, N, K, flag, stream);
+}
+
+extern "C" int gom_gemm_f32_f16x3_rp(const float* A, const int* a_rows, int lda, const void* Wplanes, long w_plane_stride,
+                                     int ldw, const float* wscale, const float* scale, const float* shift, const float* R,
+                                     int ldr, int r_cols, int r_period, int relu, float* C, int ldc, int M, int N, int K,
+                                     int* flag, void* stream) {
+    GOM_CHECK_ARG(A && Wplanes && C && r_period >= 0);
     GOM_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % 4) == 0);
     GOM_CHECK_ARG((lda % 4) == 0 && lda >= K && (ldw % 32) == 0 && ldw >= K && ldc >= N && (w_plane_stride % 8) == 0);
     GOM_CHECK_ARG(!R || (r_cols > 0 && r_cols <= N && ldr >= r_cols));
@@ -473,7 +483,7 @@ extern "C" int gom_gemm_f32_f16x3(const float* A, const int* a_rows, int lda, co
     GOM_CHECK_ARG((long)M * lda < (1L << 29) || a_rows);        // 32-bit byte offsets with a 2 GiB range check
     if (M == 0) return GOM_OK;
     Args a{};
-    a.A = A; a.r_cols = r_cols; a.Wp = (const unsigned short*)Wplanes; a.w_plane_stride = w_plane_stride; a.C = C;
+    a.A = A; a.r_cols = r_cols; a.r_period = R ? r_period : 0; a.Wp = (const unsigned short*)Wplanes; a.w_plane_stride = w_plane_stride; a.C = C;
     a.wscale = wscale; a.flag = flag;
     a.scale = scale; a.shift = shift; a.R = R; a.a_rows = a_rows;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.relu = relu;

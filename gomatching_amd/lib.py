@@ -38,6 +38,7 @@ SIGNATURES = {
     "gom_conv2d_nhwc_f32_bf16x6_splitk": (I, [P, P, L, I, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, L, I, P]),
     "gom_split_f16x2": (I, [P, I, I, I, P, I, P, P]),
     "gom_gemm_f32_f16x3": (I, [P, P, I, P, L, I, P, P, P, P, I, I, I, P, I, I, I, I, P, P]),
+    "gom_gemm_f32_f16x3_rp": (I, [P, P, I, P, L, I, P, P, P, P, I, I, I, I, P, I, I, I, I, P, P]),
     "gom_conv2d_nhwc_f32_f16x3": (I, [P, P, L, I, P, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, L, I, P, P]),
     "gom_gemm_k256_image_bytes": (L, [I, I]),
     "gom_gemm_k256_image": (I, [P, L, I, P, P, I, I, P, L, P]),

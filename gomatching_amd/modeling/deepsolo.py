@@ -193,9 +193,15 @@ class DeepSolo:
                                   None if vshapes is None else vshapes[l])
         # (src + pos) @ W = src @ W + pos @ W, and pos is a per-resolution constant: the position term of every encoder
         # layer's offsets/logits GEMM is a cached residual table instead of a second operand stream
-        pos_w = [ops.broadcast_rows(ops.gemm(lvl_pos, L["attn"]["raw"][0]), B).view(B * S, 384) for L in self.enc]
+        # (src + pos) W^T = src W^T + (pos W^T): the second term is a [S, 384] table per layer.  The f16x3 kernel reads it
+        # periodically (row m -> table row m % S: 57 MB per call instead of a 457 MB broadcast copy at 8 x 37 171 tokens)
+        self._pos_periodic = ops.GEMM_MODE == "f16x3"
+        pos_w = [ops.gemm(lvl_pos, L["attn"]["raw"][0]) for L in self.enc]
+        if not self._pos_periodic:
+            pos_w = [ops.broadcast_rows(t_, B).view(B * S, 384) for t_ in pos_w]
         geo = {
             "S": S, "shapes": ss_d, "lsi": lsi_d, "lsi_host": [int(v) for v in lsi], "pos_w": pos_w,
+            "pos_periodic": self._pos_periodic,
             "lvl_pos": ops.broadcast_rows(lvl_pos, B).view(B * S, 256),
             "enc_ref": ops.broadcast_rows(ops.encoder_reference_points(ss_d, lsi_d, S, vs_d), B).view(B * S, 1, 2),
             "valid": ops.proposal_valid(ss_d, lsi_d, S, vs_d),
@@ -239,7 +245,8 @@ class DeepSolo:
         S = geo["S"]
         for li, L in enumerate(self.enc):
             w, b = L["attn"]["raw_value"]
-            rv = ops.gemm(src, w, bias=b, R=geo["pos_w"][li], r_cols=384)             # [B*S, 384 | 256]
+            rv = ops.gemm(src, w, bias=b, R=geo["pos_w"][li], r_cols=384,
+                          r_period=S if geo["pos_periodic"] else 0)                       # [B*S, 384 | 256]
             if geo["vr"] is not None:                      # padded batch: value.masked_fill(padding_mask, 0)
                 ops.zero_padded_tokens_(rv, 384, 256, geo["shapes"], geo["lsi"], geo["vshapes"], B, S)
             samp = ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, geo["vr"])

@@ -134,7 +134,7 @@ def prep_conv_weight(w_ohwi):
     return w_ohwi
 
 
-def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols=None):
+def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols=None, r_period=0):
     if A2 is not None:                                       # the bf16x6 kernel has one A operand: add first
         assert rows is None
         A = add(A.contiguous(), A2.contiguous())
@@ -152,18 +152,20 @@ def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols=None):
         e0.record()
     rc = (r_cols if r_cols is not None else N) if R is not None else 0
     if W.kind == "f16x3":
-        check(_L().gom_gemm_f32_f16x3(_p(A), _p(rows), lda, _p(pl), pl.stride(0), pl.stride(1), _p(W.inv_scale),
-                                      _p(scale), _p(bias), _p(R), ldr, rc, 2 if relu == "gelu" else (1 if relu else 0),
-                                      _p(out), ldc, M, N, K,
-                                      _p(range_flag(A.device)), _stream()), "gom_gemm_f32_f16x3")
+        check(_L().gom_gemm_f32_f16x3_rp(_p(A), _p(rows), lda, _p(pl), pl.stride(0), pl.stride(1), _p(W.inv_scale),
+                                         _p(scale), _p(bias), _p(R), ldr, rc, int(r_period),
+                                         2 if relu == "gelu" else (1 if relu else 0), _p(out), ldc, M, N, K,
+                                         _p(range_flag(A.device)), _stream()), "gom_gemm_f32_f16x3_rp")
     else:
+        assert not r_period, "a periodic residual is served by the f16x3 kernel only"
         assert relu in (False, True, 0, 1), "only the f16x3 kernel has a GELU epilogue (use gemm_gelu)"
         check(_L().gom_gemm_f32_bf16x6(_p(A), _p(rows), lda, _p(pl), pl.stride(0), pl.stride(1), _p(scale),
                                        _p(bias), _p(R), ldr, rc, 1 if relu else 0, _p(out), ldc, M, N, K, _stream()),
               "gom_gemm_f32_bf16x6")
     if prof is not None:
         e1.record()
-        nbytes = 4.0 * M * K + 2.0 * pl.shape[0] * N * pl.shape[2] + 4.0 * M * N + (4.0 * M * rc if R is not None else 0.0)
+        nbytes = 4.0 * M * K + 2.0 * pl.shape[0] * N * pl.shape[2] + 4.0 * M * N \
+            + (4.0 * (r_period or M) * rc if R is not None else 0.0)
         prof.append((e0, e1, 2.0 * M * N * K, nbytes, "%dx%dx%d" % (M, N, K)))
     return out
 
@@ -174,7 +176,7 @@ SMALL_GEMM_ROWS = 64                 # ... and any N up to this many rows (csrc/
 
 
 def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, out=None, M=None, splitk=None,
-         r_cols=None, small=False):
+         r_cols=None, small=False, r_period=0):
     """C = act((A[+A2])[M,K] @ W[N,K]^T * scale + bias + R).  A may be a 2-D row-strided view
     (stride(1) == 1); W likewise (row slices of a weight matrix)."""
     if isinstance(W, SplitWeight):
@@ -183,7 +185,8 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
             M = A.shape[0] if rows is None else rows.numel()
         if A2 is not None:
             assert A2.shape == A.shape and A2.stride() == A.stride()
-        return _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols)
+        return _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols, r_period)
+    assert not r_period, "a periodic residual (r_period) is served by the f16x3 split-weight kernel only"
     assert A.dim() == 2 and W.dim() == 2 and A.stride(1) == 1 and W.stride(1) == 1
     if R is not None and r_cols is not None and r_cols < W.shape[0]:
         # exact-fp32 kernel has no column-limited residual: run the two column blocks as two launches

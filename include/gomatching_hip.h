@@ -118,6 +118,12 @@ int gom_split_f16x2(const float* W, int ldw, int N, int K, void* planes_out, int
 int gom_gemm_f32_f16x3(const float* A, const int* a_rows, int lda, const void* Wplanes, long w_plane_stride, int ldw,
                        const float* wscale, const float* scale, const float* shift, const float* R, int ldr, int r_cols,
                        int relu, float* C, int ldc, int M, int N, int K, int* flag, void* stream);
+/* ... with a PERIODIC residual: row m adds R[m % r_period] (r_period = 0: R[m]).  The encoder's position term
+ * (src + pos) W^T = src W^T + (pos W^T) is such a table -- S rows shared by the frames of a step (57 MB instead of 457 MB
+ * per layer call at 8 frames of 1000x1778). */
+int gom_gemm_f32_f16x3_rp(const float* A, const int* a_rows, int lda, const void* Wplanes, long w_plane_stride, int ldw,
+                          const float* wscale, const float* scale, const float* shift, const float* R, int ldr, int r_cols,
+                          int r_period, int relu, float* C, int ldc, int M, int N, int K, int* flag, void* stream);
 int gom_conv2d_nhwc_f32_f16x3(const float* X, const void* Wplanes, long w_plane_stride, int ldw, const float* wscale,
                               const float* scale, const float* shift, const float* R, int relu, float* Y, int B, int H,
                               int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,

@@ -517,3 +517,24 @@ def test_asso_activate_and_track_score():
     rows = torch.tensor([5, 0, 3, 3], dtype=torch.int32)
     src = torch.randn(9, 1024, generator=g)
     assert torch.equal(ops.gather_rows(src.to(DEV), rows.to(DEV)).cpu(), src[rows.long()])
+
+
+def test_gemm_periodic_residual_equals_broadcast_table():
+    """gom_gemm_f32_f16x3_rp: residual row m % period (the encoder's [S, 384] position table shared by the frames of a step)
+    gives the bits of the same GEMM fed with the table broadcast to every frame; columns beyond r_cols untouched."""
+    ops = _ops()
+    old, ops.GEMM_MODE = ops.GEMM_MODE, "f16x3"
+    try:
+        g = torch.Generator().manual_seed(21)
+        S, B, N = 1237, 3, 640
+        A = torch.randn((B * S, 256), generator=g).to(DEV)
+        W = ops.split_weight(torch.randn((N, 256), generator=g).to(DEV) * 0.1, kind="f16x3")
+        b = torch.randn((N,), generator=g).to(DEV)
+        table = torch.randn((S, 384), generator=g).to(DEV)
+        ref = ops.gemm(A, W, bias=b, R=table.repeat(B, 1), r_cols=384)
+        got = ops.gemm(A, W, bias=b, R=table, r_cols=384, r_period=S)
+        assert torch.equal(got, ref)
+        with pytest.raises(AssertionError):
+            ops.gemm(A, torch.randn((N, 256), device=DEV), R=table, r_period=S)
+    finally:
+        ops.GEMM_MODE = old
