@@ -23,6 +23,6 @@ with open(out, "w", newline="") as f:
         sel = sel[2:]                                            # the two warm-up launches
         avg = sum(sel) / max(len(sel), 1)
         tf = o["flops"] / avg / 1e6 if avg else 0.0
-        name = [r["Kernel_Name"] for r in launches[max(pos - 1, 0):pos]][0].split("(")[0].replace("void (anonymous namespace)::", "")
+        name = o["kernel"]
         w.writerow([o["label"], name, len(sel), "%.1f" % avg, "%.1f" % min(sel), "%.1f" % tf, "%.3f" % (tf / 833.3)])
         print("%-64s %-36s %8.1f us %6.1f TFLOP/s %.3f" % (o["label"], name[:36], avg, tf, tf / 833.3))
