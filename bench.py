@@ -42,7 +42,8 @@ def kernel_source_hash():
     on (tools/pmc_traffic.py), and `roofline.traffic` is only printed while that build is still the current one."""
     import hashlib
     h = hashlib.sha1()
-    for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "msda.hip", "common.h"):
+    for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "proj_ln.hip", "msda.hip",
+                 "common.h"):
         with open(os.path.join(ROOT, "gomatching_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -354,8 +355,9 @@ def main():
     fps = total_frames / elapsed
     ffn_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("ffn")]       # the fused FFN block: its own kernel
     k256_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("k256:")]    # the decoder's row-resident K = 256 kernel
+    pl_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("projln:")]    # out_proj + residual + LayerNorm launches
     all_prof = prof
-    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:")))]   # the dominant kernel: plain GEMMs
+    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:")))]   # the dominant kernel: plain GEMMs
     dur_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     flops = sum(p[2] for p in prof)
     alg_bytes = sum(p[3] for p in prof)
@@ -457,6 +459,17 @@ def main():
                         "resident in registers, weights streamed as MFMA fragments (csrc/gemm_k256.hip); bit-identical to the "
                         "tile kernel, which is latency-bound at this M"}
             both_ms, both_fl = both_ms + kd, both_fl + kf
+        if pl_prof:
+            pd = sum(p_[0].elapsed_time(p_[1]) for p_ in pl_prof)
+            pb = sum(p_[3] for p_ in pl_prof)
+            line["roofline_proj_ln"] = {
+                "bound": "hbm", "kernel": "proj_ln_kernel", "achieved": pb / (pd * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
+                "frac": pb / (pd * 1e-3) / 1e12 / 8.0, "traffic": pmc_traffic("proj_ln_kernel"),
+                "launches_per_step": len(pl_prof) // PROFILE_STEPS, "avg_launch_us": pd * 1e3 / len(pl_prof),
+                "share_of_step_time": (pd / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
+                "note": "out_proj + residual + LayerNorm of every attention block in one launch (csrc/proj_ln.hip): 3 KB of "
+                        "HBM traffic per token (X, R in; Y out) instead of 5; 26 FLOP per byte, i.e. an HBM-stream kernel"}
+            both_ms, both_fl = both_ms + pd, both_fl + sum(p_[2] for p_ in pl_prof)
         line["roofline"]["gemm_class_combined"] = {
             "what": "plain GEMM launches + fused FFN launches together (round 1 ran the FFN's two GEMMs on the plain kernel)",
             "achieved": both_fl / (both_ms * 1e-3) / 1e12, "frac": both_fl / (both_ms * 1e-3) / 1e12 / PEAKS[args.gemm][1],

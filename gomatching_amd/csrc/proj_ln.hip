@@ -1,0 +1,288 @@
+// Output projection + residual + LayerNorm of an attention block in ONE launch (f16x3 split, fp32-class accuracy):
+//
+//   Y = LayerNorm( X W^T + b + R ) * gamma + beta            X, R, Y [M, 256] fp32, W [256, 256]
+//
+// = `src = norm1(src + self_attn_out_proj(...))` of a DeepSolo encoder layer and the three `tgt = norm_*(tgt + out_proj(...))`
+// of a decoder layer (/root/reference/third_party/adet/layers/deformable_transformer.py:258-264 encoder, :386-422 decoder
+// intra / inter / cross blocks).  As two launches (GEMM with the residual in its epilogue, then LayerNorm) the pair moves
+// 1 + 1 + 1 | 1 + 1 = 5 KB per token through HBM for 131 kFLOP -- 26 FLOP/B, a pure HBM stream; fused it is 3 KB.
+//
+// Structure: the second half of the fused FFN kernel (ffn_fused.hip) with the input rows as the B operand.  One workgroup = 4
+// waves = 128 rows, one wave per SIMD with the whole register file: each wave splits its 32 rows once into MFMA operand
+// fragments (128 VGPRs, whole K), the EIGHT 32-column accumulators stay in AGPRs, and the product is computed transposed
+// (row of X = lane), Y^T[256 x 32 rows] += W[:, 16-wide k-step] . X^T, so that the LayerNorm's row statistics are in-lane sums.
+// The weights stream through a two-stage LDS ring by MUBUF LDS-DMA from a fragment-linear, k-major image: 4 stages of 64 KB =
+// 4 k-steps x 8 column tiles x 2 planes each; one DMA per six MFMAs inside the product.  The loop over the 4 stages is unrolled
+// (the B operand of k-step s is a fixed register set).  Per output element the plane products run in the tile kernel's order
+// (X-lo W-hi, X-hi W-lo, X-hi W-hi per 16-wide k-step, k ascending): the pre-norm values are gom_gemm_f32_f16x3's bits.
+// Epilogue = the fused FFN kernel's: Y^T through the (now free) ring to row-major, then 16 lanes per row apply the weight
+// scale, bias, residual and norm.hip's two-pass LayerNorm and store whole rows.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int D = 256;                                   // model width = K = N (fixed: every shipped config)
+constexpr int FRAG = 1024;                               // bytes of one MFMA operand fragment
+constexpr int STAGE_FRAGS = 4 * (D / 32) * 2;            // 4 k-steps x 8 column tiles x 2 planes
+constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG;          // 64 KB
+constexpr int STAGES = (D / 16) / 4;                     // 4
+constexpr int BM = 128;
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;               // = BM * D * 4: the epilogue's row-major staging fits the ring exactly
+
+struct ProjArgs {
+    const float* X;
+    const unsigned char* img;
+    const float* inv;                                        // [256] 1 / row scale of the split weight
+    const float* bias;
+    const float* R;
+    const float* gamma;
+    const float* beta;
+    float* Y;
+    int* flag;
+    float eps;
+    int ldx, ldr, ldy, M;
+};
+
+__device__ __forceinline__ float row16_sum(float v) {        // sum over the 16 lanes of a DPP row, result in every lane
+    auto dpp = [](float x, int ctrl_tag) {
+        const int xi = __builtin_bit_cast(int, x);
+        int r;
+        if (ctrl_tag == 0) r = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+        else if (ctrl_tag == 1) r = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        else if (ctrl_tag == 2) r = __builtin_amdgcn_update_dpp(0, xi, 0x141, 0xF, 0xF, true);  // row_half_mirror
+        else r = __builtin_amdgcn_update_dpp(0, xi, 0x140, 0xF, 0xF, true);                     // row_mirror
+        return __builtin_bit_cast(float, r);
+    };
+    v += dpp(v, 0);
+    v += dpp(v, 1);
+    v += dpp(v, 2);
+    v += dpp(v, 3);
+    return v;
+}
+
+__device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) {
+    const f32x2 v = {x, y};
+    const half2_t h0 = __builtin_convertvector(v, half2_t);
+    const f32x2 b = __builtin_convertvector(h0, f32x2);
+    const f32x2 r = {x - b[0], y - b[1]};
+    const half2_t h1 = __builtin_convertvector(r, half2_t);
+    q0 = __builtin_bit_cast(unsigned int, h0);
+    q1 = __builtin_bit_cast(unsigned int, h1);
+}
+
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8& p0, half8& p1) {
+    unsigned int l0, l1, l2, l3, h0, h1, h2, h3;
+    split2(a[0], a[1], l0, h0);
+    split2(a[2], a[3], l1, h1);
+    split2(b[0], b[1], l2, h2);
+    split2(b[2], b[3], l3, h3);
+    p0 = __builtin_bit_cast(half8, (u32x4{l0, l1, l2, l3}));
+    p1 = __builtin_bit_cast(half8, (u32x4{h0, h1, h2, h3}));
+}
+
+__device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned byte_offset, unsigned char* lds_frag) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)byte_offset, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void proj_ln_kernel(const ProjArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const long row0 = (long)blockIdx.x * BM + wave * 32;
+
+    const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, STAGES * STAGE_BYTES, 0x00020000);
+    // stage 0: 64 fragments, sixteen per wave (fragments wave, wave + 4, ...)
+    for (int f = wave; f < STAGE_FRAGS; f += 4) dma_fragment(rs_img, f * FRAG + lane * 16, smem + f * FRAG);
+
+    int range_bad = 0;
+    half8 xf[2][D / 16];
+    {
+        long r = row0 + fr;
+        if (r > p.M - 1) r = p.M - 1;                         // tail rows recompute the last row (never stored)
+        const float* xr = p.X + (size_t)r * p.ldx + fh * 8;
+#pragma unroll
+        for (int s = 0; s < D / 16; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) range_bad |= !(fabsf(a[e]) <= 65504.f) | !(fabsf(b[e]) <= 65504.f);
+            split8(a, b, xf[0][s], xf[1][s]);
+        }
+    }
+
+    f32x16 acc[D / 32];
+#pragma unroll
+    for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    constexpr unsigned OOB = 0x7FFF0000u;                    // beyond num_records: such a DMA writes zeros (into an unused stage)
+#pragma unroll
+    for (int c = 0; c < STAGES; ++c) {
+        const int st = c & 1;
+        const unsigned nsrc = c + 1 < STAGES ? (unsigned)(c + 1) * STAGE_BYTES + wave * FRAG + lane * 16 : OOB;
+        unsigned char* ndst = smem + (st ^ 1) * STAGE_BYTES + wave * FRAG;
+        const unsigned char* base = smem + st * STAGE_BYTES + lane * 16;
+        half8 fa[8], fb[8];
+#define PLN_DMA(i) dma_fragment(rs_img, nsrc + (i) * 4 * FRAG, ndst + (i) * 4 * FRAG);
+#define PLN_LOAD(dst, g)                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                          \
+        dst[i_] = *reinterpret_cast<const half8*>(base + ((g) * 8 + i_) * FRAG);
+#define PLN_PIN()                                         \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        // group g of a stage (8 fragments): k-step pair g >> 2, column tiles 2 (g & 3), 2 (g & 3) + 1; fragment 2 i + p of the
+        // group = plane p of (tile 2 (g & 3) + (i >> 1), k-step 4 c + 2 (g >> 2) + (i & 1))
+#define PLN_MFMA(src, g)                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+        const int t_ = ((g) & 3) * 2 + (i_ >> 1), s_ = 4 * c + 2 * ((g) >> 2) + (i_ & 1);                     \
+        acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[1][s_], acc[t_], 0, 0, 0);           \
+        acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_ + 1], xf[0][s_], acc[t_], 0, 0, 0);       \
+        acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[0][s_], acc[t_], 0, 0, 0);           \
+    }
+        PLN_LOAD(fa, 0)
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        PLN_LOAD(fb, 1) PLN_MFMA(fa, 0) PLN_DMA(0) PLN_DMA(1) PLN_PIN()
+        PLN_LOAD(fa, 2) PLN_MFMA(fb, 1) PLN_DMA(2) PLN_DMA(3) PLN_PIN()
+        PLN_LOAD(fb, 3) PLN_MFMA(fa, 2) PLN_DMA(4) PLN_DMA(5) PLN_PIN()
+        PLN_LOAD(fa, 4) PLN_MFMA(fb, 3) PLN_DMA(6) PLN_DMA(7) PLN_PIN()
+        PLN_LOAD(fb, 5) PLN_MFMA(fa, 4) PLN_DMA(8) PLN_DMA(9) PLN_PIN()
+        PLN_LOAD(fa, 6) PLN_MFMA(fb, 5) PLN_DMA(10) PLN_DMA(11) PLN_PIN()
+        PLN_LOAD(fb, 7) PLN_MFMA(fa, 6) PLN_DMA(12) PLN_DMA(13) PLN_PIN()
+        PLN_MFMA(fb, 7) PLN_DMA(14) PLN_DMA(15)
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+#undef PLN_DMA
+#undef PLN_LOAD
+#undef PLN_PIN
+#undef PLN_MFMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of the next stage has landed
+        __syncthreads();                                     // ... and everybody's; nobody still reads this stage
+    }
+
+    // ---- epilogue: Y^T (row of X on the lane, output feature in the registers) -> row-major through LDS ----
+    float* stg = reinterpret_cast<float*>(smem);             // [128][256] fp32; 16-byte chunk c of row r at chunk c ^ (r & 7)
+    {
+        float* mine = stg + (wave * 32 + fr) * D;
+#pragma unroll
+        for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                const int chunk = 8 * t + 2 * q + fh;        // features 32 t + 8 q + 4 h .. + 3
+                *reinterpret_cast<f32x4*>(mine + ((chunk ^ (fr & 7)) << 2)) = v;
+            }
+    }
+    __syncthreads();
+    // row pass: FOUR rows per wave-instruction, 16 lanes per row, each lane four 16-byte column chunks (sub, sub + 16, ...)
+    const int sub = lane & 15, rsel = lane >> 4;
+    f32x4 sc[4], bi[4], ga[4], be[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int col = (sub + 16 * k) * 4;
+        sc[k] = *reinterpret_cast<const f32x4*>(p.inv + col);
+        bi[k] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ga[k] = *reinterpret_cast<const f32x4*>(p.gamma + col);
+        be[k] = *reinterpret_cast<const f32x4*>(p.beta + col);
+    }
+    int bad = range_bad;
+#pragma unroll 2
+    for (int g = 0; g < 8; ++g) {
+        const int lr = wave * 32 + 4 * g + rsel;               // row inside the workgroup's tile
+        const long m = (long)blockIdx.x * BM + lr;
+        const long mc = m < p.M ? m : p.M - 1;                  // tail rows recompute the last row, never stored
+        f32x4 v[4];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = sub + 16 * k;
+            const f32x4 y = *reinterpret_cast<const f32x4*>(stg + lr * D + ((ch ^ (lr & 7)) << 2));
+            const f32x4 r = *reinterpret_cast<const f32x4*>(p.R + (size_t)mc * p.ldr + ch * 4);
+            v[k] = y * sc[k] + bi[k] + r;                       // the tile kernel's epilogue: fma(acc, scale, bias) + residual
+            sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        }
+        const float mean = row16_sum(sum) * (1.f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = v[k] - mean;
+            q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+        }
+        const float rstd = rsqrtf(row16_sum(q) * (1.f / D) + p.eps);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 o = v[k] * rstd * ga[k] + be[k];
+            bad |= !(fabsf(o[0]) <= 3.4e38f) | !(fabsf(o[1]) <= 3.4e38f) | !(fabsf(o[2]) <= 3.4e38f) | !(fabsf(o[3]) <= 3.4e38f);
+            if (m < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + (sub + 16 * k) * 4) = o;
+        }
+    }
+    if (bad && p.flag) atomicOr(p.flag, 1);                  // an operand left fp16's range (gemm_f16x3.hip contract)
+}
+
+// k-major fragment-linear image of W[256, 256] (row-scaled planes of gom_split_f16x2).  Stage c (k-steps 4c .. 4c + 3), group g
+// (0..7), fragment 2 i + p of the group (i = 0..3): element j of lane (r, h) =
+//     plane p of Ws[32 (2 (g & 3) + (i >> 1)) + r][16 (4 c + 2 (g >> 2) + (i & 1)) + 8 h + j]
+__global__ __launch_bounds__(256) void proj_ln_image_kernel(const unsigned short* __restrict__ planes, long plane_stride, int ldw,
+                                                            unsigned short* __restrict__ img) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)STAGES * STAGE_FRAGS * 512;
+    if (idx >= total) return;
+    const int e = (int)(idx % 512), f = (int)((idx / 512) % STAGE_FRAGS), c = (int)(idx / (512L * STAGE_FRAGS));
+    const int l = e >> 3, j = e & 7, r = l & 31, h = l >> 5;
+    const int g = f >> 3, i = (f >> 1) & 3, pl = f & 1;
+    const int t = 2 * (g & 3) + (i >> 1), s = 4 * c + 2 * (g >> 2) + (i & 1);
+    img[idx] = planes[pl * plane_stride + (size_t)(32 * t + r) * ldw + 16 * s + 8 * h + j];
+}
+
+}  // namespace
+
+extern "C" long gom_proj_ln_image_bytes(int n, int k) {
+    if (n != D || k != D) return -1;
+    return (long)STAGES * STAGE_BYTES;
+}
+
+extern "C" int gom_proj_ln_image(const void* w_planes, long w_plane_stride, int ldw, int n, int k, void* image,
+                                 long image_bytes, void* stream) {
+    GOM_CHECK_ARG(w_planes && image && n == D && k == D && ldw >= D);
+    GOM_CHECK_ARG(image_bytes >= gom_proj_ln_image_bytes(n, k));
+    const long total = (long)STAGES * STAGE_FRAGS * 512;
+    hipLaunchKernelGGL(proj_ln_image_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)w_planes, w_plane_stride, ldw, (unsigned short*)image);
+    return gom_launch_status();
+}
+
+extern "C" int gom_proj_ln_f32(const float* X, int ldx, const void* image, const float* w_inv_scale, const float* bias,
+                               const float* R, int ldr, const float* gamma, const float* beta, float eps, float* Y, int ldy,
+                               int M, int* flag, void* stream) {
+    GOM_CHECK_ARG(X && image && w_inv_scale && R && gamma && beta && Y && M >= 0);
+    GOM_CHECK_ARG(ldx >= D && ldr >= D && ldy >= D && (ldx % 4) == 0 && (ldr % 4) == 0 && (ldy % 4) == 0);
+    GOM_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)R % 16) == 0 && ((uintptr_t)Y % 16) == 0 &&
+                  ((uintptr_t)image % 16) == 0 && ((uintptr_t)w_inv_scale % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) &&
+                  ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0);
+    if (M == 0) return GOM_OK;
+    ProjArgs a{};
+    a.X = X; a.img = (const unsigned char*)image; a.inv = w_inv_scale; a.bias = bias; a.R = R; a.gamma = gamma; a.beta = beta;
+    a.Y = Y; a.flag = flag; a.eps = eps; a.ldx = ldx; a.ldr = ldr; a.ldy = ldy; a.M = M;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)proj_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(proj_ln_kernel, dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    return gom_launch_status();
+}

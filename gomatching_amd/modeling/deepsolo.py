@@ -92,8 +92,11 @@ class DeepSolo:
         self.enc = []
         for i in range(self.n_enc):
             p = t + "encoder.layers.%d." % i
-            self.enc.append({"attn": msda(p + "self_attn"), "norm1": norm(p + "norm1"), "lin1": lin(p + "linear1"),
-                             "lin2": lin(p + "linear2"), "norm2": norm(p + "norm2"), "ffn": ffn(p, "norm2")})
+            attn, n1 = msda(p + "self_attn"), norm(p + "norm1")
+            self.enc.append({"attn": attn, "norm1": n1, "lin1": lin(p + "linear1"),
+                             "lin2": lin(p + "linear2"), "norm2": norm(p + "norm2"), "ffn": ffn(p, "norm2"),
+                             # out_proj + residual + norm1 as one launch (csrc/proj_ln.hip) under the f16x3 back-end, else None
+                             "out_ln": ops.proj_ln_block(attn["out"], n1)})
         def qlin(pair):
             """A Q-side layer of the decoder (M = frames x queries x points rows): the row-resident K = 256 kernel under
             the f16x3 back-end (csrc/gemm_k256.hip), otherwise the pair as it is (ops.linear serves both)."""
@@ -106,12 +109,14 @@ class DeepSolo:
             wi, bi = ops.prep_weight(g(p + "attn_intra.in_proj_weight")), g(p + "attn_intra.in_proj_bias")
             cross = msda(p + "attn_cross")
             cross["raw"], cross["out"] = qlin(cross["raw"]), qlin(cross["out"])
+            intra_out, inter_out = lin(p + "attn_intra.out_proj"), lin(p + "attn_inter.out_proj")
+            n_intra, n_inter, n_cross = norm(p + "norm_intra"), norm(p + "norm_inter"), norm(p + "norm_cross")
             self.dec.append({
                 "intra_qk": qlin((wi[:2 * E], bi[:2 * E])), "intra_v": qlin((wi[2 * E:], bi[2 * E:])),
-                "intra_out": qlin(lin(p + "attn_intra.out_proj")), "norm_intra": norm(p + "norm_intra"),
+                "intra_out": qlin(intra_out), "norm_intra": n_intra, "intra_out_ln": ops.proj_ln_block(intra_out, n_intra),
                 "inter_in": qlin((ops.prep_weight(g(p + "attn_inter.in_proj_weight")), g(p + "attn_inter.in_proj_bias"))),
-                "inter_out": qlin(lin(p + "attn_inter.out_proj")), "norm_inter": norm(p + "norm_inter"),
-                "cross": cross, "norm_cross": norm(p + "norm_cross"),
+                "inter_out": qlin(inter_out), "norm_inter": n_inter, "inter_out_ln": ops.proj_ln_block(inter_out, n_inter),
+                "cross": cross, "norm_cross": n_cross, "cross_out_ln": ops.proj_ln_block(cross["out"], n_cross),
                 "lin1": lin(p + "linear1"), "lin2": lin(p + "linear2"), "norm3": norm(p + "norm3"),
                 "ffn": ffn(p, "norm3")})
         # all six cross-attention value projections as one [6*256, 256] weight
@@ -250,8 +255,11 @@ class DeepSolo:
             if geo["vr"] is not None:                      # padded batch: value.masked_fill(padding_mask, 0)
                 ops.zero_padded_tokens_(rv, 384, 256, geo["shapes"], geo["lsi"], geo["vshapes"], B, S)
             samp = ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, geo["vr"])
-            x = ops.gemm(samp, L["attn"]["out"][0], bias=L["attn"]["out"][1], R=src)
-            src = ops.layernorm(x, *L["norm1"])
+            if L["out_ln"] is not None:
+                src = ops.proj_ln(samp, L["out_ln"], src)
+            else:
+                x = ops.gemm(samp, L["attn"]["out"][0], bias=L["attn"]["out"][1], R=src)
+                src = ops.layernorm(x, *L["norm1"])
             if L["ffn"] is not None:
                 src = ops.ffn_fused_ln(src, L["ffn"])
                 continue
@@ -300,22 +308,19 @@ class DeepSolo:
             qkf = qk.view(-1)
             ops.mha_core(qkf, qkf[E:], v, attn, B * nq, 1, 8, 32, P, P,
                          [P * 2 * E, 0, 2 * E, P * 2 * E, 0, 2 * E, P * E, 0, E, P * E, 0, E])
-            x = ops.linear(attn, L["intra_out"], R=tgt)
-            tgt = ops.layernorm(x, *L["norm_intra"])
+            tgt = self._out_norm(attn, L, "intra", tgt)
             # inter-instance attention over the nq queries, batched over (frame, point) (:396-404)
             qkv = ops.linear(tgt, L["inter_in"])                                               # [Q, 768]
             f = qkv.view(-1)
             ld = 3 * E
             ops.mha_core(f, f[E:], f[2 * E:], attn, B, P, 8, 32, nq, nq,
                          [nq * P * ld, ld, P * ld] * 3 + [nq * P * E, E, P * E])
-            x = ops.linear(attn, L["inter_out"], R=tgt)
-            tgt = ops.layernorm(x, *L["norm_inter"])
+            tgt = self._out_norm(attn, L, "inter", tgt)
             # deformable cross attention into the encoder memory (:406-422)
             value = values[:, lid * E:(lid + 1) * E]
             samp = self._msda_strided(L["cross"], tgt, qpos, refs.view(Q, 1, 2), value, values.stride(0), geo, B,
                                       nq * P, vr)
-            x = ops.linear(samp, L["cross"]["out"], R=tgt)
-            tgt = ops.layernorm(x, *L["norm_cross"])
+            tgt = self._out_norm(samp, L, "cross", tgt)
             if L["ffn"] is not None:
                 tgt = ops.ffn_fused_ln(tgt, L["ffn"])
             else:
@@ -327,6 +332,15 @@ class DeepSolo:
             refs = ops.ref_sigmoid(d, refs, 2)
             inter_refs.append(refs)
         return tgt, inter_refs
+
+    @staticmethod
+    def _out_norm(x, L, name, tgt):
+        """norm_<name>(tgt + out_proj(x)) of a decoder attention block: one launch under the f16x3 back-end."""
+        blk = L[name + "_out_ln"]
+        if blk is not None:
+            return ops.proj_ln(x, blk, tgt)
+        out = L["cross"]["out"] if name == "cross" else L[name + "_out"]
+        return ops.layernorm(ops.linear(x, out, R=tgt), *L["norm_" + name])
 
     def _msda_strided(self, W, query, query_pos, ref, value_view, ld_value, geo, B, Lq, vr=None):
         """Cross-attention sampling straight out of the fused [B*S, 1536] value buffer (no compaction copy)."""

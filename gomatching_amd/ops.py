@@ -386,6 +386,55 @@ def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0)
     return out
 
 
+PROJ_LN = True           # f16x3 back-end: out_proj + residual + LayerNorm of every attention block as one launch
+
+
+class ProjLN:
+    """`LayerNorm(x W^T + b + R)` prepared for gom_proj_ln_f32 (csrc/proj_ln.hip): k-major fragment image of the f16x3 planes of
+    W [256, 256] + inverse row scales + bias + the norm's gain / bias.  `pair` / `norm` stay available for the two-launch path."""
+
+    def __init__(self, W, bias, gamma, beta, eps=1e-5):
+        assert isinstance(W, SplitWeight) and W.kind == "f16x3"
+        nbytes = _L().gom_proj_ln_image_bytes(W.N, W.K)
+        if nbytes < 0:
+            raise _lib_mod.GomError("projection + LayerNorm kernel does not serve N %d / K %d" % (W.N, W.K))
+        _chk_f32(bias, gamma, beta)
+        pl = W.planes
+        self.image = torch.empty((nbytes,), dtype=torch.uint8, device=pl.device)
+        check(_L().gom_proj_ln_image(_p(pl), pl.stride(0), pl.stride(1), W.N, W.K, _p(self.image), nbytes, _stream()),
+              "gom_proj_ln_image")
+        self.W, self.bias, self.gamma, self.beta, self.eps = W, bias, gamma, beta, eps
+
+
+def proj_ln_block(pair, norm):
+    """(weight, bias) of an attention block's out_proj + (gamma, beta) of the norm behind it -> ProjLN when the back-end and
+    shape allow, else None (callers keep the two-launch path)."""
+    w, b = pair if not isinstance(pair, K256Linear) else (pair.W, pair.bias)
+    if PROJ_LN and GEMM_MODE == "f16x3" and isinstance(w, SplitWeight) and w.kind == "f16x3" and w.N == 256 and w.K == 256:
+        return ProjLN(w, b, norm[0], norm[1])
+    return None
+
+
+def proj_ln(x, blk, R, out=None):
+    """LayerNorm(x @ W^T + b + R) * gamma + beta in one launch; x, R [M, 256] row-strided."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == 256 and x.dtype == _f32
+    assert R.shape == x.shape and R.stride(1) == 1 and R.dtype == _f32
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty((M, 256), dtype=_f32, device=x.device)
+    prof = _gemm_profile if (_gemm_profile is not None and M > 0) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().gom_proj_ln_f32(_p(x), x.stride(0) if M > 1 else 256, _p(blk.image), _p(blk.W.inv_scale), _p(blk.bias), _p(R),
+                               R.stride(0) if M > 1 else 256, _p(blk.gamma), _p(blk.beta), blk.eps, _p(out),
+                               out.stride(0) if M > 1 else 256, M, _p(range_flag(x.device)), _stream()), "gom_proj_ln_f32")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * 256 * 256, 12.0 * M * 256 + blk.image.numel(), "projln:%dx256x256" % M))
+    return out
+
+
 FUSED_FFN = True         # f16x3 back-end: FFN blocks as one fused launch (False: GEMM, GEMM, LayerNorm)
 
 

@@ -129,6 +129,20 @@ int gom_conv2d_nhwc_f32_f16x3(const float* X, const void* Wplanes, long w_plane_
                               int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
                               long workspace_bytes, int splits, int* flag, void* stream);
 
+/* Output projection + residual + LayerNorm of an attention block in ONE launch (csrc/proj_ln.hip):
+ *     Y = LayerNorm(X W^T + b + R) * gamma + beta,   X, R, Y [M, 256] fp32 (row strides ldx / ldr / ldy; Y may alias R), W [256, 256]
+ * = `norm1(src + out_proj(...))` of an encoder layer and the three `norm_*(tgt + out_proj(...))` of a decoder layer
+ * (deformable_transformer.py:258-264, 386-422): 3 KB of HBM traffic per token instead of the 5 KB of GEMM + LayerNorm.  f16x3
+ * scheme, range contract and *flag of gom_gemm_f32_f16x3; the pre-norm values are that kernel's bits.  gom_proj_ln_image:
+ * one-time weight preparation from the gom_split_f16x2 planes (gom_proj_ln_image_bytes bytes; -1 = shape not served);
+ * w_inv_scale = the split's inverse row scales, bias may be NULL. */
+long gom_proj_ln_image_bytes(int n, int k);
+int gom_proj_ln_image(const void* w_planes, long w_plane_stride, int ldw, int n, int k, void* image, long image_bytes,
+                      void* stream);
+int gom_proj_ln_f32(const float* X, int ldx, const void* image, const float* w_inv_scale, const float* bias, const float* R,
+                    int ldr, const float* gamma, const float* beta, float eps, float* Y, int ldy, int M, int* flag,
+                    void* stream);
+
 /* Row-resident K = 256 form of gom_gemm_f32_f16x3 for SHORT problems (the decoder's Q-side nn.Linear layers at
  * M = frames x queries x points rows: deformable_transformer.py:386-422,470-488), csrc/gemm_k256.hip:
  *     C[M, N] = act( (A [+ A2])[M, 256] . W[N, 256]^T + bias [+ R on columns < r_cols] ),   N, r_cols multiples of 32.

@@ -63,6 +63,15 @@ for label, M, N, K, rc, a2 in SHAPES:
     else:
         run(label, lambda: ops.linear(A, lin, R=R, r_cols=rc if rc else None, A2=A2, out=out), 2.0 * M * N * K, kern)
     del A, W, R, A2, out
+for label, M in (("enc out_proj + residual + LayerNorm fused (proj_ln)", S8), ("dec out_proj + residual + LayerNorm fused", Q)):
+    w = (torch.randn((256, 256), generator=g) * 0.06).to(dev)
+    blk = ops.ProjLN(ops.split_weight(w, kind="f16x3"), torch.randn((256,), generator=g).to(dev),
+                     torch.ones((256,), device=dev), torch.zeros((256,), device=dev))
+    x = torch.randn((M, 256), generator=g).to(dev)
+    r = torch.randn((M, 256), generator=g).to(dev)
+    y = torch.empty_like(x)
+    run(label, lambda: ops.proj_ln(x, blk, r, out=y), 2.0 * M * 256 * 256, "proj_ln_kernel")
+    del x, r, y
 for label, M in (("enc FFN block fused (linear1+ReLU+linear2+residual+LayerNorm)", S8), ("dec FFN block fused", Q)):
     F = 1024
     w1 = (torch.randn((F, 256), generator=g) * 0.05).to(dev); b1 = torch.randn((F,), generator=g).to(dev) * 0.1

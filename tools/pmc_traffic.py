@@ -31,7 +31,8 @@ def kernel_source_hash():
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha1()
-    for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "msda.hip", "common.h"):
+    for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "proj_ln.hip", "msda.hip",
+                 "common.h"):
         with open(os.path.join(root, "gomatching_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
