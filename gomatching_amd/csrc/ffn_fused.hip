@@ -54,7 +54,7 @@ struct FfnArgs {
     float* Y;
     int* flag;
     float eps;
-    int ldx, ldy, M, chunks;
+    int ldx, ldy, M, chunks, stagger;
 };
 
 // sum over the 16 lanes of a DPP row, result in every lane: quad swaps (xor 1, xor 2), then the two mirrors
@@ -109,6 +109,14 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     const int fr = lane & 31, fh = lane >> 5;
     const long row0 = (long)blockIdx.x * BM + wave * 32;
 
+    // Long launches (>= 4 rounds of workgroups): the first round starts STAGGERED, by up to 7 x stagger sleeps of ~0.4 us over
+    // the CUs of an XCD.  With one workgroup per CU and equal durations every CU otherwise reaches its prologue, its weight
+    // stream and its epilogue at the same moment, round after round, and HBM / L2 see bursts with idle time between them;
+    // desynchronised, the memory phases of one CU run under the MFMA phases of the others.  Measured in the step (same box,
+    // alternating runs): this kernel 575 -> 572 us per launch on average, proj_ln.hip 96 -> 92 us; in a loop of its own launches
+    // the kernel gains 10 % (1046 -> 944 us at M = 297k), which the step does not see.
+    if (p.stagger > 0 && blockIdx.x < 256)
+        for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     const __amdgpu_buffer_rsrc_t rs_img =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, p.chunks * STAGE_BYTES, 0x00020000);
     auto dma_stage = [&](int c, int stage) {                 // 65 fragments, dealt to the four waves
@@ -360,6 +368,7 @@ extern "C" int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, 
     FfnArgs a{};
     a.X = X; a.img = (const unsigned char*)image; a.s2 = w2_inv_scale; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = Y;
     a.flag = flag; a.eps = eps; a.ldx = ldx; a.ldy = ldy; a.M = M; a.chunks = d_hidden / CH;
+    a.stagger = cdiv(M, BM) >= 1024 ? 8 : 0;                 // >= 4 rounds of workgroups
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
