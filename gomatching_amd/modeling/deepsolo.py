@@ -200,7 +200,7 @@ class DeepSolo:
         # layer's offsets/logits GEMM is a cached residual table instead of a second operand stream
         # (src + pos) W^T = src W^T + (pos W^T): the second term is a [S, 384] table per layer.  The f16x3 kernel reads it
         # periodically (row m -> table row m % S: 57 MB per call instead of a 457 MB broadcast copy at 8 x 37 171 tokens)
-        self._pos_periodic = ops.GEMM_MODE == "f16x3"
+        self._pos_periodic = ops.GEMM_MODE == "f16x3" and ops.POS_PERIODIC
         pos_w = [ops.gemm(lvl_pos, L["attn"]["raw"][0]) for L in self.enc]
         if not self._pos_periodic:
             pos_w = [ops.broadcast_rows(t_, B).view(B * S, 384) for t_ in pos_w]

@@ -98,6 +98,13 @@ def split_weight(w, conv_shape=None, kind=None):
 _range_flags = {}
 
 
+def _switch(name, default=True):
+    """Build-time switches of the f16x3 path; the environment (GOM_<NAME>=0/1) overrides the default for same-box A/B runs."""
+    import os
+    v = os.environ.get("GOM_" + name)
+    return default if v is None else v not in ("0", "false", "False", "")
+
+
 def _dev_index(device):
     d = torch.device(device)
     return d.index if d.index is not None else torch.cuda.current_device()
@@ -315,7 +322,7 @@ def masked_stream(mask_words, device):
     return torch.cuda.ExternalStream(out.value, device=device)
 
 
-K256_GEMM = True         # f16x3 back-end: K = 256 products on the row-resident kernel where it measures faster (below)
+K256_GEMM = _switch("K256_GEMM")   # f16x3 back-end: K = 256 products on the row-resident kernel where it measures faster (below)
 K256_MAX_ROWS = 1 << 16  # "short" problems (the decoder's Q side: M = frames x queries x points)
 
 
@@ -386,7 +393,8 @@ def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0)
     return out
 
 
-PROJ_LN = True           # f16x3 back-end: out_proj + residual + LayerNorm of every attention block as one launch
+PROJ_LN = _switch("PROJ_LN")         # f16x3 back-end: out_proj + residual + LayerNorm of every attention block as one launch
+POS_PERIODIC = _switch("POS_PERIODIC")   # f16x3 back-end: the encoder's position table read as row m % S (no broadcast copy)
 
 
 class ProjLN:
@@ -435,7 +443,7 @@ def proj_ln(x, blk, R, out=None):
     return out
 
 
-FUSED_FFN = True         # f16x3 back-end: FFN blocks as one fused launch (False: GEMM, GEMM, LayerNorm)
+FUSED_FFN = _switch("FUSED_FFN")     # f16x3 back-end: FFN blocks as one fused launch (False: GEMM, GEMM, LayerNorm)
 
 
 class FusedFFN:
