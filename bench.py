@@ -225,6 +225,7 @@ def main():
         cus = args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world >= 8 else 0)
         if cus > 0 and device.type == "cuda":
             model.reserve_tracker_cus(cus)
+            model._lane_all = os.environ.get("GOM_LANE_ALL") == "1"
         if not shifts:
             shifts["s"], shifts["r"] = calibrate(model, cal_inputs, frac=args.detect_frac)
         else:

@@ -81,6 +81,22 @@ extern "C" int gom_match_scores_f32(const float* pool, int ld_pool, const int* r
                                     const gom_matcher_layer* dec, int n_dec, int d, int heads, int ffn, float img_w,
                                     float img_h, int with_iou, float max_center_dist, float* workspace,
                                     long workspace_floats, float* traj, void* stream) {
+    return gom_match_scores_proj_f32(pool, ld_pool, nullptr, 0, rows, frame_offsets, meta, boxes, decay, N, T, lo, hi, num_tracks,
+                                     enc, n_enc, dec, n_dec, d, heads, ffn, img_w, img_h, with_iou, max_center_dist, workspace,
+                                     workspace_floats, traj, stream);
+}
+
+/* The same chain with the two per-row projections of the RAW embeddings hoisted out of it: proj [pool rows, ld_proj >= 4d] holds
+ * for every pool row its encoder-layer-0 in-projection (columns [0, 3d): x in_w^T + in_b) and its decoder-layer-0 query
+ * projection (columns [3d, 4d)), computed once per detection by the same small-GEMM kernel the chain would use (an output of
+ * that kernel depends only on its row, its column and K: the bits are the same).  They are the largest product of a match and
+ * one more, i.e. two of its dependent launches -- per frame, 64 times per 8-GPU step.  proj == NULL: everything in the chain. */
+extern "C" int gom_match_scores_proj_f32(const float* pool, int ld_pool, const float* proj, int ld_proj, const int* rows,
+                                         const int* frame_offsets, const int* meta, const float* boxes, const float* decay,
+                                         int N, int T, int lo, int hi, int num_tracks, const gom_matcher_layer* enc,
+                                         int n_enc, const gom_matcher_layer* dec, int n_dec, int d, int heads, int ffn,
+                                         float img_w, float img_h, int with_iou, float max_center_dist, float* workspace,
+                                         long workspace_floats, float* traj, void* stream) {
     if (!pool || !rows || !frame_offsets || !meta || !boxes || !workspace || !traj) return GOM_ERR_INVALID_ARG;
     if (N <= 0 || T <= 0 || lo < 0 || hi <= lo || hi > N || num_tracks <= 0 || d <= 0 || heads <= 0 || d % heads)
         return GOM_ERR_INVALID_ARG;
@@ -104,14 +120,20 @@ extern "C" int gom_match_scores_f32(const float* pool, int ld_pool, const int* r
     p += (64 - ((p - workspace) & 63)) & 63;                 // 256-byte aligned
     const Ctx ctx{p, 4 * splitk_floats(N, n_k, d, ffn), stream};
 
-    RT_TRY(gom_gather_rows_f32(pool, rows, src, N, d, stream));
-    (void)ld_pool;
+    if (proj) {
+        if (ld_proj < 4 * d || ld_pool < d) return GOM_ERR_INVALID_ARG;
+        RT_TRY(gom_gather_match_f32(pool, ld_pool, proj, ld_proj, rows, N, lo, n_k, d, src, big, qbuf, stream));
+    } else {
+        if (ld_pool != d) return GOM_ERR_INVALID_ARG;        // gom_gather_rows_f32 reads dense rows
+        RT_TRY(gom_gather_rows_f32(pool, rows, src, N, d, stream));
+    }
     const float* memory = src;                               // src itself stays intact: the decoder's tgt is a slice of it
     for (int l = 0; l < n_enc; ++l) {                        // post-norm layer with Identity norms (transformer.py:180-195)
         const gom_matcher_layer& L = enc[l];
         if (!L.in_w || !L.out_w || !L.lin1_w || !L.lin2_w) return GOM_ERR_INVALID_ARG;
         float* out = (memory == mem_b) ? mem_c : mem_b;      // never the buffer this layer reads
-        RT_TRY(linear(ctx, memory, d, N, Lin{L.in_w, L.in_b}, 3 * d, d, nullptr, 0, 0, big, 3 * d));
+        if (!(proj && l == 0))                                // layer 0's q | k | v of the raw embeddings: gathered above
+            RT_TRY(linear(ctx, memory, d, N, Lin{L.in_w, L.in_b}, 3 * d, d, nullptr, 0, 0, big, 3 * d));
         RT_TRY(attend(big, 3 * d, big + d, big + 2 * d, 3 * d, att, d, heads, N, N, stream));
         RT_TRY(linear(ctx, att, d, N, Lin{L.out_w, L.out_b}, d, d, memory, d, 0, mem_a, d));
         RT_TRY(linear(ctx, mem_a, d, N, Lin{L.lin1_w, L.lin1_b}, ffn, d, nullptr, 0, 1, big, ffn));
@@ -122,7 +144,8 @@ extern "C" int gom_match_scores_f32(const float* pool, int ld_pool, const int* r
     for (int l = 0; l < n_dec; ++l) {                        // cross-attention only (transformer.py:270-294)
         const gom_matcher_layer& L = dec[l];
         if (!L.in_w || !L.out_w) return GOM_ERR_INVALID_ARG;
-        RT_TRY(linear(ctx, tgt, d, n_k, Lin{L.in_w, L.in_b}, d, d, nullptr, 0, 0, qbuf, d));
+        if (!(proj && l == 0))                                // layer 0's query projection of the raw embeddings: gathered above
+            RT_TRY(linear(ctx, tgt, d, n_k, Lin{L.in_w, L.in_b}, d, d, nullptr, 0, 0, qbuf, d));
         RT_TRY(linear(ctx, memory, d, N, Lin{L.in_w + (size_t)d * d, L.in_b ? L.in_b + d : nullptr}, 2 * d, d, nullptr, 0, 0,
                       big, 2 * d));
         RT_TRY(attend(qbuf, d, big, big + d, 2 * d, att, d, heads, n_k, N, stream));
@@ -139,6 +162,9 @@ extern "C" int gom_match_scores_f32(const float* pool, int ld_pool, const int* r
     }
     // ATTWeightHead with 0 layers: q . k^T (lstmatcher.py:360-371)
     RT_TRY(linear(ctx, tgt, d, n_k, Lin{memory, nullptr}, N, d, nullptr, 0, 0, logits, N));
+    if (N <= 16384)                                          // activation + trajectory score as one launch (same values)
+        return gom_asso_score_f32(logits, N, frame_offsets, T, meta, decay, boxes, img_w, img_h, n_k, N - n_k, num_tracks,
+                                  with_iou, max_center_dist, traj, stream);
     RT_TRY(gom_asso_activate_f32(logits, N, frame_offsets, T, n_k, act, N, stream));
     return gom_track_score_f32(act, N, meta, decay, boxes, img_w, img_h, n_k, N - n_k, num_tracks, with_iou,
                                max_center_dist, traj, stream);

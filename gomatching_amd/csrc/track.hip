@@ -15,6 +15,30 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(src + ((size_t)rows[r] * d4 + c) * 4);
 }
 
+// A match with hoisted projections (matcher_rt.cpp): one launch gathers the window's embeddings [N, d], their precomputed encoder
+// in-projections [N, 3d] and the current frame's precomputed decoder query projections [n_k, d] (rows lo..hi-1 of the window).
+__global__ __launch_bounds__(256) void gather_match_kernel(const float* __restrict__ pool, int ld_pool,
+                                                           const float* __restrict__ proj, int ld_proj,
+                                                           const int* __restrict__ rows, int N, int lo, int n_k, int d4,
+                                                           float* __restrict__ src, float* __restrict__ qkv,
+                                                           float* __restrict__ qdec) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n_src = (long)N * d4, n_qkv = (long)N * 3 * d4, n_q = (long)n_k * d4;
+    if (i < n_src) {
+        const int r = (int)(i / d4), c = (int)(i % d4);
+        *reinterpret_cast<f32x4*>(src + i * 4) = *reinterpret_cast<const f32x4*>(pool + (size_t)rows[r] * ld_pool + c * 4);
+    } else if (i < n_src + n_qkv) {
+        const long k = i - n_src;
+        const int r = (int)(k / (3 * d4)), c = (int)(k % (3 * d4));
+        *reinterpret_cast<f32x4*>(qkv + k * 4) = *reinterpret_cast<const f32x4*>(proj + (size_t)rows[r] * ld_proj + c * 4);
+    } else if (i < n_src + n_qkv + n_q) {
+        const long k = i - n_src - n_qkv;
+        const int r = (int)(k / d4), c = (int)(k % d4);
+        *reinterpret_cast<f32x4*>(qdec + k * 4) =
+            *reinterpret_cast<const f32x4*>(proj + (size_t)rows[lo + r] * ld_proj + (3 * d4 + c) * 4);
+    }
+}
+
 // one wave per (query row, frame segment)
 __global__ __launch_bounds__(256) void asso_activate_kernel(const float* __restrict__ logits, int ld,
                                                             const int* __restrict__ offs, int T, int n_k,
@@ -35,14 +59,12 @@ __global__ __launch_bounds__(256) void asso_activate_kernel(const float* __restr
 }
 
 // meta layout (int32): nonk[Np] | col_of[Np] | last_idx[M] | k_inds[n_k]
-__global__ __launch_bounds__(256) void track_score_kernel(const float* __restrict__ act, int ld,
-                                                          const int* __restrict__ meta, const float* __restrict__ decay,
-                                                          const float* __restrict__ boxes, float img_w, float img_h,
-                                                          int n_k, int Np, int M, int with_iou, float max_center_dist,
-                                                          float* __restrict__ traj) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_k * M) return;
-    const int i = idx / M, m = idx % M;
+// Trajectory score of (current detection i, track m) from the activation row of i (global memory or LDS: generic pointer).
+// NOT inlined on purpose: the two-launch and the one-launch form call the same machine code, so they agree bit for bit
+// whatever the compiler would hoist, contract or reassociate in either caller.
+__device__ __noinline__ float track_score_one(const float* act_row, const int* __restrict__ meta, const float* __restrict__ decay,
+                                               const float* __restrict__ boxes, float img_w, float img_h, int i, int m, int Np,
+                                               int M, int with_iou, float max_center_dist) {
     const int* nonk = meta;
     const int* col_of = meta + Np;
     const int* last_idx = meta + 2 * Np;
@@ -55,7 +77,7 @@ __global__ __launch_bounds__(256) void track_score_kernel(const float* __restric
     const float ks = (kx1 - kx0) * (kx1 - kx0) + (ky1 - ky0) * (ky1 - ky0);
     for (int j = 0; j < Np; ++j) {
         if (col_of[j] != m) continue;
-        float a = act[(size_t)i * ld + nonk[j]];
+        float a = act_row[nonk[j]];
         if (decay) a *= decay[j];
         s += a;
         if (max_center_dist > 0.f) {
@@ -76,7 +98,45 @@ __global__ __launch_bounds__(256) void track_score_kernel(const float* __restric
         s = fmaxf(s, iou);
     }
     if (max_center_dist > 0.f && !any_valid) s = 0.f;
-    traj[idx] = s;
+    return s;
+}
+
+__global__ __launch_bounds__(256) void track_score_kernel(const float* __restrict__ act, int ld,
+                                                          const int* __restrict__ meta, const float* __restrict__ decay,
+                                                          const float* __restrict__ boxes, float img_w, float img_h,
+                                                          int n_k, int Np, int M, int with_iou, float max_center_dist,
+                                                          float* __restrict__ traj) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_k * M) return;
+    const int i = idx / M, m = idx % M;
+    traj[idx] = track_score_one(act + (size_t)i * ld, meta, decay, boxes, img_w, img_h, i, m, Np, M, with_iou, max_center_dist);
+}
+
+// asso_activate + track_score of ONE match in one launch (the two kernels above back to back cost two dependent launches per
+// frame; beside the detector every tracker launch also delays the detector's next kernel).  One workgroup per
+// current detection i: the waves run `asso_activate_kernel`'s code over the frame segments into an LDS row, then the threads
+// call `track_score_one` over the tracks on that row -- the same arithmetic, value for value.
+__global__ __launch_bounds__(256) void asso_score_kernel(const float* __restrict__ logits, int ld,
+                                                         const int* __restrict__ offs, int T, const int* __restrict__ meta,
+                                                         const float* __restrict__ decay, const float* __restrict__ boxes,
+                                                         float img_w, float img_h, int n_k, int Np, int M, int with_iou,
+                                                         float max_center_dist, float* __restrict__ traj) {
+    extern __shared__ float act[];                           // [N] activations of detection i
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* row = logits + (size_t)i * ld;
+    for (int t = wave; t < T; t += 4) {
+        const int lo = offs[t], hi = offs[t + 1];
+        float mx = 0.f;                                      // the appended background logit
+        for (int j = lo + lane; j < hi; j += 64) mx = fmaxf(mx, row[j]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lo + lane; j < hi; j += 64) sum += expf(row[j] - mx);
+        sum = wave_sum(sum) + expf(0.f - mx);
+        for (int j = lo + lane; j < hi; j += 64) act[j] = expf(row[j] - mx) / sum;
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += 256)
+        traj[(size_t)i * M + m] = track_score_one(act, meta, decay, boxes, img_w, img_h, i, m, Np, M, with_iou, max_center_dist);
 }
 
 // Short-term matching, all (previous, current) frame pairs of a clip in one launch (gom_lstmatcher.py:405-445 with the
@@ -160,6 +220,16 @@ extern "C" int gom_gather_rows_f32(const float* src, const int* rows, float* out
     return gom_launch_status();
 }
 
+extern "C" int gom_gather_match_f32(const float* pool, int ld_pool, const float* proj, int ld_proj, const int* rows, int N,
+                                    int lo, int n_k, int dim, float* src, float* qkv, float* qdec, void* stream) {
+    GOM_CHECK_ARG(pool && proj && rows && src && qkv && qdec && N > 0 && lo >= 0 && n_k >= 0 && lo + n_k <= N);
+    GOM_CHECK_ARG(dim > 0 && (dim % 4) == 0 && ld_pool >= dim && ld_proj >= 4 * dim && (ld_pool % 4) == 0 && (ld_proj % 4) == 0);
+    const long quads = ((long)N * 4 + n_k) * (dim / 4);
+    hipLaunchKernelGGL(gather_match_kernel, dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, (hipStream_t)stream, pool, ld_pool,
+                       proj, ld_proj, rows, N, lo, n_k, dim / 4, src, qkv, qdec);
+    return gom_launch_status();
+}
+
 extern "C" int gom_asso_activate_f32(const float* logits, int ld, const int* frame_offsets, int num_frames, int n_k,
                                      float* out, int ld_out, void* stream) {
     GOM_CHECK_ARG(logits && frame_offsets && out && num_frames > 0 && n_k >= 0);
@@ -176,6 +246,20 @@ extern "C" int gom_track_score_f32(const float* act, int ld, const int* meta, co
     if (n_k == 0 || M == 0) return GOM_OK;
     hipLaunchKernelGGL(track_score_kernel, dim3((unsigned)cdiv((long)n_k * M, 256)), dim3(256), 0, (hipStream_t)stream,
                        act, ld, meta, decay, boxes, img_w, img_h, n_k, Np, M, with_iou, max_center_dist, traj);
+    return gom_launch_status();
+}
+
+/* gom_asso_activate_f32 followed by gom_track_score_f32 as one launch (same values); logits [n_k, ld] over the N = Np + n_k
+ * selected detections of the window.  N is bounded by the LDS row: N <= 16 384. */
+extern "C" int gom_asso_score_f32(const float* logits, int ld, const int* frame_offsets, int num_frames, const int* meta,
+                                  const float* decay, const float* boxes, float img_w, float img_h, int n_k, int Np, int M,
+                                  int with_iou, float max_center_dist, float* traj, void* stream) {
+    GOM_CHECK_ARG(logits && frame_offsets && meta && boxes && traj && num_frames > 0 && n_k >= 0 && Np >= 0 && M >= 0);
+    GOM_CHECK_ARG(ld >= Np + n_k && Np + n_k <= 16384);
+    if (n_k == 0 || M == 0) return GOM_OK;
+    hipLaunchKernelGGL(asso_score_kernel, dim3((unsigned)n_k), dim3(256), sizeof(float) * (size_t)(Np + n_k), (hipStream_t)stream,
+                       logits, ld, frame_offsets, num_frames, meta, decay, boxes, img_w, img_h, n_k, Np, M, with_iou,
+                       max_center_dist, traj);
     return gom_launch_status();
 }
 

@@ -30,8 +30,8 @@ struct Tracker {
     int* desc_dev = nullptr;     long desc_cap = 0;        // 32-bit words
     int* desc_pin = nullptr;     long desc_pin_cap = 0;
     float* ws_dev = nullptr;     long ws_cap = 0;          // floats
-    float* traj_dev = nullptr;   long traj_cap = 0;
     float* traj_pin = nullptr;   long traj_pin_cap = 0;
+    const float* proj = nullptr; int ld_proj = 0;          // hoisted projections for the next run (gom_tracker_set_projections)
 };
 
 template <typename T>
@@ -108,12 +108,21 @@ extern "C" void* gom_tracker_create(int test_len, float overlap_thresh, int not_
     return t;
 }
 
+/* Hoisted projections for the NEXT gom_tracker_run call (gom_match_scores_proj_f32): device [pool rows, ld_proj >= 4d], valid
+ * for every pool row that call's `rows` name.  NULL (the state after every run) = the chain computes them per match. */
+extern "C" int gom_tracker_set_projections(void* h, const float* proj_dev, int ld_proj) {
+    Tracker* t = (Tracker*)h;
+    if (!t || (proj_dev && ld_proj < 4 * t->d)) return GOM_ERR_INVALID_ARG;
+    t->proj = proj_dev;
+    t->ld_proj = ld_proj;
+    return GOM_OK;
+}
+
 extern "C" void gom_tracker_destroy(void* h) {
     Tracker* t = (Tracker*)h;
     if (!t) return;
     if (t->desc_dev) (void)hipFree(t->desc_dev);
     if (t->ws_dev) (void)hipFree(t->ws_dev);
-    if (t->traj_dev) (void)hipFree(t->traj_dev);
     if (t->desc_pin) (void)hipHostFree(t->desc_pin);
     if (t->traj_pin) (void)hipHostFree(t->traj_pin);
     delete t;
@@ -126,10 +135,10 @@ extern "C" void gom_tracker_destroy(void* h) {
  *   `first_new`; frames before index 0 of the window do not exist for the long-term window (the caller passes at least
  *   test_len - 1 carried frames when the video has them).  decay_table[e] = decay_time ** e as numpy computed it.
  *   secs[0] / secs[1] accumulate the short- / long-term seconds. */
-extern "C" int gom_tracker_run(void* handle, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
-                               long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool,
-                               float img_w, float img_h, const float* decay_table, long* id_count_io, double* secs,
-                               void* stream) {
+static int tracker_run_impl(void* handle, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
+                            long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool,
+                            float img_w, float img_h, const float* decay_table, long* id_count_io, double* secs,
+                            void* stream) {
     Tracker* t = (Tracker*)handle;
     if (!t || F <= 0 || !n || !ids || first_new < 0 || first_new >= F || !id_count_io || !s_off) return GOM_ERR_INVALID_ARG;
     std::vector<long> off(F + 1, 0);
@@ -225,7 +234,6 @@ extern "C" int gom_tracker_run(void* handle, int F, const int* n, const float* b
             if (rc == GOM_OK) rc = grow_dev(t->desc_dev, t->desc_cap, words);
             const long nws = gom_match_workspace_floats(N, n_k, t->d, t->ffn);
             if (rc == GOM_OK) rc = grow_dev(t->ws_dev, t->ws_cap, nws);
-            if (rc == GOM_OK) rc = grow_dev(t->traj_dev, t->traj_cap, (long)n_k * M);
             if (rc == GOM_OK) rc = grow_pin(t->traj_pin, t->traj_pin_cap, (long)n_k * M);
             if (rc != GOM_OK) return rc;
             int* p = t->desc_pin;
@@ -265,21 +273,20 @@ extern "C" int gom_tracker_run(void* handle, int F, const int* n, const float* b
             const float* d_boxes = (const float*)(d_meta + (2L * Np + M + n_k));
             const float* d_decay = t->use_decay ? d_boxes + 4L * N : nullptr;
             const int lo = p_offs[k];
-            auto chain = gom_match_scores_f32;
-            rc = chain(pool_dev, ld_pool, d_rows, d_offs, d_meta, d_boxes, d_decay, N, T, lo, lo + n_k, M, t->enc, t->n_enc, t->dec,
+            auto chain = gom_match_scores_proj_f32;
+            // the chain's last kernel writes the n_k x M trajectory scores STRAIGHT into pinned host memory (device-visible,
+            // posted PCIe writes, complete at the stream sync below): one launch fewer per match than a copy kernel
+            rc = chain(pool_dev, ld_pool, t->proj, t->ld_proj, d_rows, d_offs, d_meta, d_boxes, d_decay, N, T, lo, lo + n_k, M, t->enc, t->n_enc, t->dec,
                        t->n_dec, t->d, t->heads, t->ffn, img_w, img_h, t->with_iou, t->max_center_dist, t->ws_dev, nws,
-                       t->traj_dev, stream);
-            if (rc != GOM_OK) return rc;
-            rc = gom_copy_words(t->traj_dev, t->traj_pin, (long)n_k * M, stream);
+                       t->traj_pin, stream);
             if (rc != GOM_OK) return rc;
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
             if (g_double_check) {                                // diagnostic: the same chain again must give the same bits
                 std::vector<float> first(t->traj_pin, t->traj_pin + (size_t)n_k * M);
-                rc = chain(pool_dev, ld_pool, d_rows, d_offs, d_meta, d_boxes, d_decay, N, T, lo, lo + n_k, M, t->enc, t->n_enc,
+                rc = chain(pool_dev, ld_pool, t->proj, t->ld_proj, d_rows, d_offs, d_meta, d_boxes, d_decay, N, T, lo, lo + n_k, M, t->enc, t->n_enc,
                            t->dec, t->n_dec, t->d, t->heads, t->ffn, img_w, img_h, t->with_iou, t->max_center_dist, t->ws_dev,
-                           nws, t->traj_dev, stream);
-                if (rc == GOM_OK) rc = gom_copy_words(t->traj_dev, t->traj_pin, (long)n_k * M, stream);
+                           nws, t->traj_pin, stream);
                 if (rc != GOM_OK) return rc;
                 if (hipStreamSynchronize(st) != hipSuccess) return GOM_ERR_HIP_BASE;
                 if (std::memcmp(first.data(), t->traj_pin, sizeof(float) * (size_t)n_k * M) != 0)
@@ -296,4 +303,14 @@ extern "C" int gom_tracker_run(void* handle, int F, const int* n, const float* b
     }
     *id_count_io = id_count;
     return GOM_OK;
+}
+
+extern "C" int gom_tracker_run(void* handle, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
+                               long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool,
+                               float img_w, float img_h, const float* decay_table, long* id_count_io, double* secs,
+                               void* stream) {
+    const int rc = tracker_run_impl(handle, F, n, boxes, rows, ids, first_new, first_real, S, s_off, pool_dev, ld_pool, img_w,
+                                    img_h, decay_table, id_count_io, secs, stream);
+    if (handle) ((Tracker*)handle)->proj = nullptr;         // projections are valid for one call only
+    return rc;
 }

@@ -81,6 +81,7 @@ SIGNATURES = {
     "gom_gather_rows_f32": (I, [P, P, P, I, I, P]),
     "gom_asso_activate_f32": (I, [P, I, P, I, I, P, I, P]),
     "gom_track_score_f32": (I, [P, I, P, P, P, F, F, I, I, I, I, F, P, P]),
+    "gom_asso_score_f32": (I, [P, I, P, I, P, P, P, F, F, I, I, I, I, F, P, P]),
     "gom_short_term_pairs_f32": (I, [P, P, I, P, P, P, F, F, I, I, I, P, P]),
     "gom_mha_core_segments_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "gom_pos_encoding_2d_valid_f32": (I, [P, P, P, I, I, I, I, P]),
@@ -106,6 +107,9 @@ SIGNATURES = {
     "gom_transpose_f32": (I, [P, P, I, I, L, L, P]),
     "gom_flash_attention_f32": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
     "gom_match_workspace_floats": (L, [I, I, I, I]),
+    "gom_gather_match_f32": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P]),
+    "gom_match_scores_proj_f32": (I, [P, I, P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
+    "gom_tracker_set_projections": (I, [P, P, I]),
     "gom_match_scores_f32": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
     "gom_tracker_create": (P, [I, F, I, I, I, F, P, I, P, I, I, I, I]),
     "gom_tracker_destroy": (None, [P]),

@@ -740,6 +740,8 @@ class GoMatching:
         return instances, id_count
 
     def _tracker_stream(self):
+        if getattr(self, "_lane_all", False) and getattr(self, "_lane_stream", None) is not None:
+            return self._lane_stream                             # experiment: the WHOLE tracker half on the reserved CUs
         if getattr(self, "_trk_stream", None) is None:
             self._trk_stream = torch.cuda.Stream(device=self.device, priority=-1)
         return self._trk_stream
@@ -772,6 +774,7 @@ class GoMatching:
         carried = [x for x in instances[-self.test_len:] if x.has("reid_features")]
         saved = [x.reid_features.clone() for x in carried]      # may alias the pool that is about to be reused
         self._pool_used = 0
+        self._proj_done = 0                                      # hoisted matcher projections follow the pool rows
         for x, f in zip(carried, saved):
             self._host(x)["row0"] = None
             x._fields["reid_features"] = f
@@ -894,6 +897,7 @@ class GoMatching:
                 so += chunks[-1].size
         S_all = np.concatenate(chunks) if chunks else np.zeros((1,), np.float32)
         trk = self._native_tracker()
+        self._hoist_projections(trk)
         idc = ctypes.c_long(int(id_count) if id_count else 0)
         secs = (ctypes.c_double * 2)(0.0, 0.0)
         hw = dets[0].image_size
@@ -950,6 +954,29 @@ class GoMatching:
         self._decay_table = np.power(np.float32(self.decay_time if self.decay_time > 0 else 1.0),
                                      np.arange(self.test_len + 1).astype(np.float32)).astype(np.float32)
         return self._ntrk
+
+    def _hoist_projections(self, trk):
+        """The matcher's two per-row projections of the RAW embeddings (encoder layer 0 q | k | v, decoder layer 0 query) for
+        every pool row that does not have them yet, handed to the next `gom_tracker_run` (gom_match_scores_proj_f32): the
+        largest product of a long-term match and one more leave its chain of dependent launches -- computed here once per
+        detection, for all new rows of the step at once, by the same small-GEMM kernel (same bits)."""
+        m = self.roi_heads._matcher(False)
+        if not ops.HOIST_MATCH_PROJECTIONS or not m.enc or not m.dec or self._pool is None:
+            return
+        d, L = m.d, ops._L()
+        cap = self._pool.shape[0]
+        if getattr(self, "_proj", None) is None or self._proj.shape[0] < cap or self._proj_pool is not self._pool:
+            self._proj = torch.empty((cap, 4 * d), dtype=_f32, device=self.device)
+            self._proj_pool, self._proj_done = self._pool, 0
+        self._proj_done = min(getattr(self, "_proj_done", 0), self._pool_used)
+        a, b = self._proj_done, self._pool_used
+        if b > a:
+            w_in, b_in = m.enc[0]["in"]
+            w_q, b_q = m.dec[0]["in"]
+            ops.gemm_small_rows(self._pool[a:b], w_in, b_in, self._proj[a:b, :3 * d])
+            ops.gemm_small_rows(self._pool[a:b], w_q[:d], b_q[:d], self._proj[a:b, 3 * d:])
+            self._proj_done = b
+        ops.check(L.gom_tracker_set_projections(trk, self._proj.data_ptr(), self._proj.stride(0)), "gom_tracker_set_projections")
 
     def close(self):
         """Release the native tracker handle (hipMalloc / hipHostMalloc buffers of csrc/tracker_rt.hip)."""

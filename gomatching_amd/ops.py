@@ -393,6 +393,7 @@ def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0)
     return out
 
 
+HOIST_MATCH_PROJECTIONS = _switch("HOIST_MATCH_PROJECTIONS")   # native tracker: per-row matcher projections computed once per detection
 PROJ_LN = _switch("PROJ_LN")         # f16x3 back-end: out_proj + residual + LayerNorm of every attention block as one launch
 POS_PERIODIC = _switch("POS_PERIODIC")   # f16x3 back-end: the encoder's position table read as row m % S (no broadcast copy)
 
@@ -1023,6 +1024,24 @@ NATIVE_MATCHER = True      # False: compose the match from per-kernel calls in P
 class MatcherLayer(ctypes.Structure):
     """Mirror of `gom_matcher_layer` (include/gomatching_hip.h)."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("in_w", "in_b", "out_w", "out_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b")]
+
+
+def gemm_small_rows(A, W, bias, out):
+    """out = A @ W^T + bias by the tracker's small-GEMM kernel WHATEVER the number of rows (in row chunks): every output has
+    the bits that kernel gives it inside a match, which is what lets per-row projections be hoisted out of the match chain."""
+    assert A.dim() == 2 and A.stride(1) == 1 and W.dim() == 2 and W.stride(1) == 1 and out.stride(1) == 1
+    M, K = A.shape
+    N = W.shape[0]
+    assert out.shape == (M, N) and K % 4 == 0
+    for t_ in (A, W, bias, out):                              # row-strided views are fine (lda / ldw / ldc below)
+        assert t_ is None or (t_.dtype == _f32 and t_.is_cuda)
+    step = max(8, ((1 << 22) // N) // 8 * 8)
+    lda, ldw, ldc = (A.stride(0) if M > 1 else K), (W.stride(0) if N > 1 else K), (out.stride(0) if M > 1 else N)
+    for a in range(0, M, step):
+        m = min(step, M - a)
+        check(_L().gom_gemm_small_f32(_p(A[a:]), None, lda, _p(W), ldw, None, _p(bias), None, 0, 0, _p(out[a:]), ldc, m, N, K,
+                                      _stream()), "gom_gemm_small_f32")
+    return out
 
 
 def matcher_layers(layers):

@@ -349,6 +349,10 @@ int gom_asso_activate_f32(const float* logits, int ld, const int* frame_offsets,
 int gom_track_score_f32(const float* act, int ld, const int* meta, const float* decay, const float* boxes, float img_w,
                         float img_h, int n_k, int Np, int M, int with_iou, float max_center_dist, float* traj,
                         void* stream);
+/* gom_asso_activate_f32 + gom_track_score_f32 of one match as ONE launch (same values; Np + n_k <= 16 384). */
+int gom_asso_score_f32(const float* logits, int ld, const int* frame_offsets, int num_frames, const int* meta,
+                       const float* decay, const float* boxes, float img_w, float img_h, int n_k, int Np, int M,
+                       int with_iou, float max_center_dist, float* traj, void* stream);
 /* Short-term matching for ALL (previous, current) frame pairs of a clip in one launch: per current detection i of pair
  * p, q.k^T logits against the previous frame's rows, softmax with the zero background logit (lstmatcher.py:373-381) and
  * S[i,j] = max(a_j, IoU(i,j)) (gom_lstmatcher.py:429-445 for tracks seen once).  pairs [device] int32 [P][6] =
@@ -376,6 +380,19 @@ typedef struct gom_matcher_layer {
     const float* lin2_b;
 } gom_matcher_layer;
 long gom_match_workspace_floats(int N, int n_k, int d, int ffn);
+/* [device] one launch for a match with hoisted projections: src [N, dim] <- pool[rows], qkv [N, 3 dim] <- proj[rows][0 : 3 dim],
+ * qdec [n_k, dim] <- proj[rows[lo .. lo + n_k)][3 dim : 4 dim]. */
+int gom_gather_match_f32(const float* pool, int ld_pool, const float* proj, int ld_proj, const int* rows, int N, int lo, int n_k,
+                         int dim, float* src, float* qkv, float* qdec, void* stream);
+/* gom_match_scores_f32 with the two per-row projections of the raw embeddings hoisted out of the chain: proj [pool rows,
+ * ld_proj >= 4 d] = (encoder layer 0 in-projection | decoder layer 0 query projection) of every pool row, computed once per
+ * detection by gom_gemm_small_f32 (same bits as in the chain).  proj == NULL: gom_match_scores_f32. */
+int gom_match_scores_proj_f32(const float* pool, int ld_pool, const float* proj, int ld_proj, const int* rows,
+                              const int* frame_offsets, const int* meta, const float* boxes, const float* decay, int N, int T,
+                              int lo, int hi, int num_tracks, const gom_matcher_layer* enc, int n_enc,
+                              const gom_matcher_layer* dec, int n_dec, int d, int heads, int ffn, float img_w, float img_h,
+                              int with_iou, float max_center_dist, float* workspace, long workspace_floats, float* traj,
+                              void* stream);
 int gom_match_scores_f32(const float* pool, int ld_pool, const int* rows, const int* frame_offsets, const int* meta,
                          const float* boxes, const float* decay, int N, int T, int lo, int hi, int num_tracks,
                          const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec, int n_dec, int d,
@@ -389,6 +406,8 @@ void* gom_tracker_create(int test_len, float overlap_thresh, int not_mult_thresh
                          float max_center_dist, const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec,
                          int n_dec, int d, int heads, int ffn);
 void gom_tracker_destroy(void* tracker);
+/* [host] hoisted projections (gom_match_scores_proj_f32) for the NEXT gom_tracker_run call only; NULL = none. */
+int gom_tracker_set_projections(void* tracker, const float* proj_dev, int ld_proj);
 
 int gom_tracker_run(void* tracker, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
                     long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool, float img_w,

@@ -527,3 +527,41 @@ def test_cu_partitioned_step_gives_identical_results():
         y = ops.gemm(torch.ones((8, 64), device=DEV), torch.ones((16, 64), device=DEV))
     lane.synchronize()
     assert float(y.min()) == 64.0 and float(y.max()) == 64.0
+
+
+@pytest.mark.parametrize("builtin", ["icdar15", "pp_dstext"])
+def test_hoisted_match_projections_change_nothing(builtin):
+    """gom_match_scores_proj_f32 / gom_tracker_set_projections: the encoder in-projection and the decoder query projection of
+    the raw embeddings computed once per detection instead of inside every match.  Same kernel, same bits: the 106-frame trace
+    processed as 100 + 6 frames (pool restart, carried window, births, re-appearances) gives identical ids with and without,
+    and the chain entry point gives identical trajectory scores."""
+    from gomatching_amd import ops
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.structures import Instances, Boxes
+    from gomatching_amd.weights import synth_state_dict
+    cfg = mini_cfg(builtin, device=DEV)
+    sd = synth_state_dict(cfg, seed=7)
+    size = (96, 128)
+
+    def run(hoist):
+        old, ops.HOIST_MATCH_PROJECTIONS = ops.HOIST_MATCH_PROJECTIONS, hoist
+        try:
+            model = GoMatching(cfg, sd, device=DEV)
+            trace = _synthetic_trace(106, model.roi_heads.feature_dim, seed=5)
+            dets = []
+            for f, b in trace:
+                inst = Instances(size)
+                inst.reid_features = torch.from_numpy(f).to(DEV)
+                inst.pred_boxes = Boxes(torch.from_numpy(b).to(DEV))
+                dets.append(inst)
+            it = iter(dets)
+            model.detect_launch = lambda batched_inputs, time_cost: list(batched_inputs)
+            model.detect_finish = lambda h, time_cost: [next(it) for _ in h]
+            insts, id_count = model.batch_inference([{} for _ in range(100)], 0, 0, [], _time_cost())
+            insts, id_count = model.batch_inference([{} for _ in range(6)], 1, id_count, insts, _time_cost())
+            return [x.track_ids.cpu().tolist() for x in insts], int(id_count)
+        finally:
+            ops.HOIST_MATCH_PROJECTIONS = old
+
+    a, b = run(True), run(False)
+    assert a == b and max(max(f, default=0) for f in a[0]) > 5
