@@ -23,3 +23,9 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/shapes -o s -- 
 echo "shapes rc $?"
 python3 tools/gemm_shapes_csv.py $out/shapes/s_kernel_trace.csv gpurun_out/gemm_shapes_order.json $out/${tag}_gemm_shapes.csv
 rm -rf $out/shapes
+# multi-GPU tracker load emulated on one GPU (same box): N = 1, 4 and 8 GPUs' frames per tracker, without / with the CU lane
+for cfg in "1 0" "4 0" "8 0" "8 32"; do
+  set -- $cfg
+  timeout 200 python3 bench.py --emulate-world $1 --tracker-cus $2 --steps 6 --warmup 2 --no-alt-backends --no-cpu-baseline > $out/emu_w$1_cu$2.json 2> $out/emu.err
+done
+bash tools/ablation.sh > $out/${tag}_ablation_same_box.log 2>&1
