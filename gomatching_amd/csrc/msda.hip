@@ -206,7 +206,136 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float* __restrict
     *reinterpret_cast<f32x4*>(out + (size_t)q_global * (HEADS * CH) + m * CH + c4) = acc;
 }
 
+// The same fused op with the per-sample arithmetic DISTRIBUTED over the eight lanes of a head (round 2).  The kernel above lets
+// all eight lanes of a head recompute every sample's location, bilinear weights and corner offsets: rocprofv3 counted 1764
+// VALU instructions per query-wave -- 854 us of pure VALU issue per encoder call on each CU, i.e. the whole kernel (930 us);
+// the gather itself (64 corner lines per query through the 64 B/clk vector-L1 path) needs ~500 us.  Here lane k of a head owns
+// samples 2k and 2k + 1 (level k >> 1): it loads only their offsets and logits, computes their location, validity, the four
+// corner weights, the attention weight and the four corner ELEMENT OFFSETS once, and the eight lanes then read each sample's
+// nine values from its owner with ds_swizzle (the LDS crossbar: no VALU issue, no memory).  Per-channel arithmetic is the
+// kernel above's, value for value: softmax numerators by the same expf, their sum in the same ascending order (every lane
+// collects the sixteen numerators by swizzle and adds them itself), w1*v1 + w2*v2 + w3*v3 + w4*v4 times the sample's weight.
+// Corner loads are buffer loads with 32-bit byte offsets from the batch image (a level map holds < 2^29 floats).
+__device__ __forceinline__ float group8_read(float v, int owner) {      // value of lane (lane & ~7) | owner, owner a constant
+    // ds_swizzle bit-mask mode: lane' = ((lane & and_mask) | or_mask) ^ xor_mask inside each half-wave of 32
+    switch (owner) {
+        case 0: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x18 | (0 << 5)));
+        case 1: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x18 | (1 << 5)));
+        case 2: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x18 | (2 << 5)));
+        case 3: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x18 | (3 << 5)));
+        case 4: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x18 | (4 << 5)));
+        case 5: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x18 | (5 << 5)));
+        case 6: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x18 | (6 << 5)));
+        default: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x18 | (7 << 5)));
+    }
+}
+
+template <bool HAS_VR>
+__global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __restrict__ value,
+                                                               const int64_t* __restrict__ shapes,
+                                                               const int64_t* __restrict__ lsi,
+                                                               const float* __restrict__ raw, int ld_raw,
+                                                               const float* __restrict__ ref, float* __restrict__ out,
+                                                               int B, int Lq, long v_bs, int v_rs,
+                                                               const float* __restrict__ vr) {
+    constexpr int POINTS = 4, LP = LEVELS * POINTS;
+    const long q_global = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+    if (q_global >= (long)B * Lq) return;
+    const int lane = threadIdx.x & 63;
+    const int m = lane >> 3, k = lane & 7;
+    const int b = (int)(q_global / Lq);
+    const int l = k >> 1;                                    // level of this lane's two samples (2k, 2k + 1)
+
+    // ---- owner part: two samples per lane ----
+    const float* op = raw + (size_t)q_global * ld_raw + m * (LP * 2) + 4 * k;      // (ox, oy) of samples 2k, 2k + 1
+    const float* lp = raw + (size_t)q_global * ld_raw + HEADS * LP * 2 + m * LP + 2 * k;
+    const f32x4 off = *reinterpret_cast<const f32x4*>(op);
+    const float lg0 = lp[0], lg1 = lp[1];
+    const float rx = ref[q_global * 2], ry = ref[q_global * 2 + 1];
+    // softmax over the head's 16 logits: max over the eight lanes' pairs (order-free), numerators by the same expf, the sum in
+    // ascending sample order on every lane (the fused kernel above sums e[0] .. e[15] in that order)
+    float mx = fmaxf(lg0, lg1);
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x1F | (1 << 10))));
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x1F | (2 << 10))));
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x1F | (4 << 10))));
+    const float e0 = expf(lg0 - mx), e1 = expf(lg1 - mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        sum += group8_read(e0, o);
+        sum += group8_read(e1, o);
+    }
+    const float inv_sum = 1.f / sum;
+
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const float Hf = (float)H, Wf = (float)W;
+    const float rW = 1.f / Wf, rH = 1.f / Hf;
+    const unsigned lvl = (unsigned)lsi[l];
+    float sw1[2], sw2[2], sw3[2], sw4[2], sww[2];
+    unsigned so1[2], so2[2], so3[2], so4[2];                 // BYTE offsets of the four corners' head slice in the batch image
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float ox = off[2 * t], oy = off[2 * t + 1];
+        float qx = ox * rW, qy = oy * rH;
+        qx = fmaf(fmaf(-qx, Wf, ox), rW, qx);
+        qy = fmaf(fmaf(-qy, Hf, oy), rH, qy);
+        const float lx = (HAS_VR ? rx * vr[2 * l] : rx) + qx, ly = (HAS_VR ? ry * vr[2 * l + 1] : ry) + qy;
+        const float w = (t ? e1 : e0) * inv_sum;
+        const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+        const bool inside = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const float lh = h_im - hf, lw = w_im - wf;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
+        const bool y0 = h_low >= 0, y1 = h_low + 1 <= H - 1;
+        const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
+        const int yc0 = y0 ? h_low : 0, yc1 = y1 ? h_low + 1 : H - 1;
+        const int xc0 = x0 ? w_low : 0, xc1 = x1 ? w_low + 1 : W - 1;
+        const unsigned r0 = lvl + (unsigned)(yc0 * W), r1 = lvl + (unsigned)(yc1 * W);
+        const unsigned head = (unsigned)(m * CH) * 4u;
+        so1[t] = (r0 + xc0) * (unsigned)v_rs * 4u + head;
+        so2[t] = (r0 + xc1) * (unsigned)v_rs * 4u + head;
+        so3[t] = (r1 + xc0) * (unsigned)v_rs * 4u + head;
+        so4[t] = (r1 + xc1) * (unsigned)v_rs * 4u + head;
+        sww[t] = inside ? w : 0.f;
+        sw1[t] = (y0 && x0) ? hh * hw : 0.f;
+        sw2[t] = (y0 && x1) ? hh * lw : 0.f;
+        sw3[t] = (y1 && x0) ? lh * hw : 0.f;
+        sw4[t] = (y1 && x1) ? lh * lw : 0.f;
+    }
+
+    // ---- gather part: every lane, all 16 samples, 4 channels ----
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(value + (size_t)b * v_bs), 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned mine = (unsigned)k * 16u;                 // this lane's 4 channels inside the head's 128-byte slice
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+        const int o = i >> 1, t = i & 1;
+        const unsigned a1 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so1[t]), o)) + mine;
+        const unsigned a2 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so2[t]), o)) + mine;
+        const unsigned a3 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so3[t]), o)) + mine;
+        const unsigned a4 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so4[t]), o)) + mine;
+        const f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a1, 0, 0));
+        const f32x4 v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a2, 0, 0));
+        const f32x4 v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a3, 0, 0));
+        const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a4, 0, 0));
+        const float w1 = group8_read(sw1[t], o), w2 = group8_read(sw2[t], o), w3 = group8_read(sw3[t], o),
+                    w4 = group8_read(sw4[t], o), ww = group8_read(sww[t], o);
+        const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        acc += val * ww;
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)q_global * (HEADS * CH) + m * CH + k * 4) = acc;
+}
+
 }  // namespace
+
+static int g_msda_lanes = 1;
+/* [host] 1 (default): the lane-distributed fused kernel; 0: the one-lane-does-all form (A/B runs, tests). */
+extern "C" int gom_msda_set_lane_distributed(int on) {
+    g_msda_lanes = on ? 1 : 0;
+    return GOM_OK;
+}
 
 extern "C" int gom_msda_fused_forward(const float* raw, int ld_raw, const float* ref, const float* value,
                                       long value_batch_stride, int value_row_stride, const int64_t* spatial_shapes,
@@ -217,9 +346,14 @@ extern "C" int gom_msda_fused_forward(const float* raw, int ld_raw, const float*
     GOM_CHECK_ARG(value_row_stride >= HEADS * CH && (value_row_stride % 4) == 0 && (value_batch_stride % 4) == 0);
     GOM_CHECK_ARG(((uintptr_t)raw % 16) == 0 && ((uintptr_t)value % 16) == 0);
     const long nq = (long)batch * num_query;
-    hipLaunchKernelGGL((msda_fused_kernel<4, false>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
-                       spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
-                       value_batch_stride, value_row_stride, (const float*)nullptr);
+    if (g_msda_lanes && value_batch_stride > 0 && value_batch_stride < (1L << 29))     // 32-bit byte offsets inside a batch image
+        hipLaunchKernelGGL((msda_fused_lanes_kernel<false>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream,
+                           value, spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
+                           value_batch_stride, value_row_stride, (const float*)nullptr);
+    else
+        hipLaunchKernelGGL((msda_fused_kernel<4, false>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
+                           spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
+                           value_batch_stride, value_row_stride, (const float*)nullptr);
     return gom_launch_status();
 }
 
@@ -231,9 +365,14 @@ extern "C" int gom_msda_fused_forward_vr(const float* raw, int ld_raw, const flo
     GOM_CHECK_ARG(batch > 0 && num_query > 0 && ld_raw >= HEADS * LEVELS * 4 * 3 && (ld_raw % 4) == 0);
     GOM_CHECK_ARG(value_row_stride >= HEADS * CH && (value_row_stride % 4) == 0 && (value_batch_stride % 4) == 0);
     const long nq = (long)batch * num_query;
-    hipLaunchKernelGGL((msda_fused_kernel<4, true>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
-                       spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
-                       value_batch_stride, value_row_stride, valid_ratios);
+    if (g_msda_lanes && value_batch_stride > 0 && value_batch_stride < (1L << 29))
+        hipLaunchKernelGGL((msda_fused_lanes_kernel<true>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream,
+                           value, spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
+                           value_batch_stride, value_row_stride, valid_ratios);
+    else
+        hipLaunchKernelGGL((msda_fused_kernel<4, true>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
+                           spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
+                           value_batch_stride, value_row_stride, valid_ratios);
     return gom_launch_status();
 }
 

@@ -24,6 +24,7 @@ SIGNATURES = {
     "gom_built_for_arch": (ctypes.c_char_p, []),
     "gom_ms_deform_attn_forward": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "gom_ms_deform_attn_forward_strided": (I, [P, L, I, P, P, P, P, P, I, I, P]),
+    "gom_msda_set_lane_distributed": (I, [I]),
     "gom_msda_fused_forward": (I, [P, I, P, P, L, I, P, P, P, I, I, P]),
     "gom_msda_prepare": (I, [P, I, P, I, P, P, P, L, P]),
     "gom_gemm_f32": (I, [P, P, P, I, P, I, P, P, P, I, I, P, I, I, I, I, P]),

@@ -513,11 +513,18 @@ def ms_deform_attn_forward_strided(value2d, batch_stride, shapes, lsi, loc, w, B
     return out
 
 
+MSDA_LANES = _switch("MSDA_LANES")   # fused MSDA: per-sample arithmetic distributed over a head's lanes (same bits, 3x fewer VALU)
+_msda_lanes_set = [None]
+
+
 def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq, valid_ratios=None):
     """raw [B*Lq, >=384] (offsets | logits, stride(1)==1), ref [B*Lq, 2], value2d [B*S, 256] column slice;
     valid_ratios [4,2] fp32 (Wv/W, Hv/H) for padded batches."""
     assert raw.stride(1) == 1 and value2d.stride(1) == 1
     _chk_f32(ref, valid_ratios)
+    if _msda_lanes_set[0] != MSDA_LANES:                     # library-side switch follows ops.MSDA_LANES
+        _L().gom_msda_set_lane_distributed(1 if MSDA_LANES else 0)
+        _msda_lanes_set[0] = MSDA_LANES
     out = torch.empty((B * Lq, 256), dtype=_f32, device=raw.device)
     if valid_ratios is not None:
         check(_L().gom_msda_fused_forward_vr(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride,

@@ -58,6 +58,7 @@ int gom_ms_deform_attn_forward_strided(const float* value, long value_batch_stri
 
 /* Fused MSDeformAttn core: gom_msda_prepare + gom_ms_deform_attn_forward_strided in one pass (locations and
  * weights never reach HBM).  raw/ref as for gom_msda_prepare with ref_levels = 1. */
+int gom_msda_set_lane_distributed(int on);   /* [host] fused MSDA: 1 = per-sample arithmetic distributed over a head's lanes (default) */
 int gom_msda_fused_forward(const float* raw, int ld_raw, const float* ref, const float* value, long value_batch_stride,
                            int value_row_stride, const int64_t* spatial_shapes, const int64_t* level_start_index,
                            float* output, int batch, int num_query, void* stream);

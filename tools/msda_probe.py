@@ -26,4 +26,17 @@ for name, amp in (("offsets ~ +-3 px", 3.0), ("offsets = 0", 0.0), ("offsets ~ +
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
-    print("%-20s %8.1f us (min %.1f)" % (name, sorted(ts)[len(ts) // 2], min(ts)), flush=True)
+    from gomatching_amd import lib
+    a = ops.msda_fused(raw, ref, value[:, 384:], S * 640, ss.to(dev), lsi.to(dev), B, S)
+    lib.load().gom_msda_set_lane_distributed(0)
+    t0 = []
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b_ = ops.msda_fused(raw, ref, value[:, 384:], S * 640, ss.to(dev), lsi.to(dev), B, S)
+        e1.record()
+        torch.cuda.synchronize()
+        t0.append(e0.elapsed_time(e1) * 1e3)
+    lib.load().gom_msda_set_lane_distributed(1)
+    print("%-20s lane-distributed %8.1f us (min %.1f) | one lane does all %8.1f us (min %.1f) | max |d| %.2e, identical: %s" % (
+        name, sorted(ts)[len(ts) // 2], min(ts), sorted(t0)[len(t0) // 2], min(t0), float((a - b_).abs().max()), bool(torch.equal(a, b_))), flush=True)
