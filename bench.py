@@ -224,8 +224,12 @@ def main():
             model.h2d_mode = args.h2d
         cus = args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world >= 8 else 0)
         if cus > 0 and device.type == "cuda":
-            model.reserve_tracker_cus(cus)
-            model._lane_all = os.environ.get("GOM_LANE_ALL") == "1"
+            try:
+                model.reserve_tracker_cus(cus)
+            except Exception as e:                               # a scheduling aid only: never let it cost the run
+                print("bench: CU reservation for the tracker unavailable (%s: %s); continuing without" % (type(e).__name__, e),
+                      file=sys.stderr, flush=True)
+                model._lane_stream = model._det_stream = None
         if not shifts:
             shifts["s"], shifts["r"] = calibrate(model, cal_inputs, frac=args.detect_frac)
         else:

@@ -740,8 +740,6 @@ class GoMatching:
         return instances, id_count
 
     def _tracker_stream(self):
-        if getattr(self, "_lane_all", False) and getattr(self, "_lane_stream", None) is not None:
-            return self._lane_stream                             # experiment: the WHOLE tracker half on the reserved CUs
         if getattr(self, "_trk_stream", None) is None:
             self._trk_stream = torch.cuda.Stream(device=self.device, priority=-1)
         return self._trk_stream
