@@ -142,6 +142,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
             split8(a, b, xf[0][s], xf[1][s]);
         }
     }
+    asm volatile("" : "+v"(range_bad));                      // decided HERE: left alone the compiler keeps the raw rows in
+                                                             // ~90 accumulator registers through the loop to compare them after it
 
     f32x16 acc2[D / 32];
 #pragma unroll
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    float hmax = 0.f;                                        // largest hidden activation of this lane's rows
     constexpr unsigned OOB = 0x7FFF0000u;                    // beyond num_records: such a DMA writes zeros (into an unused stage)
     for (int c = 0; c < p.chunks; ++c) {
         const int st = c & 1;
@@ -176,12 +179,22 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
 #define FFN_LOAD(dst, g)                                                                                      \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                          \
         dst[i_] = *reinterpret_cast<const half8*>(base + ((g) * 8 + i_) * FRAG);
-#define FFN_PIN()                                         \
+#define FFN_PIN3()                                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+#define FFN_PIN1()                                        \
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#define FFN_PIN0()                                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         // ---- H^T chunk = W1c . X^T : one accumulator, 16 k-steps x 3 plane products (smallest terms first) ----
         f32x16 acc1;
 #pragma unroll
@@ -195,10 +208,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     }
         FFN_LOAD(fa, 0)
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // group 0's reads come first, then (reads, MFMAs) pairs
-        FFN_LOAD(fb, 1) FFN_GEMM1(fa, 0) FFN_DMA(0) FFN_DMA(1) FFN_PIN()
-        FFN_LOAD(fa, 2) FFN_GEMM1(fb, 1) FFN_DMA(2) FFN_DMA(3) FFN_PIN()
-        FFN_LOAD(fb, 3) FFN_GEMM1(fa, 2) FFN_DMA(4) FFN_DMA(5) FFN_PIN()
-        FFN_LOAD(fa, 4) FFN_GEMM1(fb, 3) FFN_DMA(6) FFN_DMA(7) FFN_PIN()   // fa <- first group of W2 fragments
+        FFN_LOAD(fb, 1) FFN_GEMM1(fa, 0) FFN_DMA(0) FFN_DMA(1) FFN_DMA(2) FFN_PIN3()
+        FFN_LOAD(fa, 2) FFN_GEMM1(fb, 1) FFN_DMA(3) FFN_DMA(4) FFN_DMA(5) FFN_PIN3()
+        FFN_LOAD(fb, 3) FFN_GEMM1(fa, 2) FFN_DMA(6) FFN_DMA(7) FFN_DMA(8) FFN_PIN3()
+        FFN_LOAD(fa, 4) FFN_GEMM1(fb, 3) FFN_DMA(9) FFN_DMA(10) FFN_DMA(11) FFN_PIN3()   // fa <- first group of W2 fragments
         __builtin_amdgcn_sched_barrier(0);
         // ---- relu(acc / row scale + bias), split into two fp16 planes: registers 8u..8u+7 are the B fragment of k-step u ----
         const float* aux = reinterpret_cast<const float*>(smem + st * STAGE_BYTES + (W1_FRAGS + W2_FRAGS) * FRAG);
@@ -214,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[qq][e] = fmaxf(fmaf(acc1[4 * q + e], sc[e], bi[e]), 0.f);
-                    range_bad |= !(v[qq][e] <= 65504.f);       // beyond fp16 (or NaN): flagged, never a silent wrong result
+                    hmax = fmaxf(hmax, v[qq][e]);              // (never NaN after the max with 0) checked once, after the loop
                 }
             }
             split8(v[0], v[1], hf[0][u], hf[1][u]);
@@ -228,23 +241,22 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         acc2[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], hf[1][u_], acc2[t_], 0, 0, 0);         \
         acc2[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], hf[0][u_], acc2[t_], 0, 0, 0);         \
     }
-        FFN_LOAD(fb, 5) FFN_GEMM2(fa, 0) FFN_DMA(8) FFN_DMA(9) FFN_PIN()
-        FFN_LOAD(fa, 6) FFN_GEMM2(fb, 1) FFN_DMA(10) FFN_DMA(11) FFN_PIN()
-        FFN_LOAD(fb, 7) FFN_GEMM2(fa, 2) FFN_DMA(12) FFN_DMA(13) FFN_PIN()
-        FFN_GEMM2(fb, 3) FFN_DMA(14) FFN_DMA(15)
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        FFN_LOAD(fb, 5) FFN_GEMM2(fa, 0) FFN_DMA(12) FFN_DMA(13) FFN_DMA(14) FFN_PIN3()
+        FFN_LOAD(fa, 6) FFN_GEMM2(fb, 1) FFN_DMA(15) FFN_PIN1()
+        FFN_LOAD(fb, 7) FFN_GEMM2(fa, 2) FFN_PIN0()
+        FFN_GEMM2(fb, 3)
 #undef FFN_DMA
 #undef FFN_LOAD
-#undef FFN_PIN
+#undef FFN_PIN3
+#undef FFN_PIN1
+#undef FFN_PIN0
 #undef FFN_GEMM1
 #undef FFN_GEMM2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of the next stage has landed
         __syncthreads();                                     // ... and everybody's; nobody still reads this stage
     }
 
+    range_bad |= !(hmax <= 65504.f);                         // beyond fp16: flagged, never a silent wrong result
     // ---- epilogue: Y^T (row of X on the lane, output feature in the registers) -> row-major through LDS ----
     float* stg = reinterpret_cast<float*>(smem);             // [128][256] fp32; 16-byte chunk c of row r at chunk c ^ (r & 7)
     {
@@ -258,12 +270,23 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
                 *reinterpret_cast<f32x4*>(mine + ((chunk ^ (fr & 7)) << 2)) = v;
             }
     }
+    // The residual rows of the row pass below (row 4 g + rsel of the wave's 32, chunks sub + 16 k) are all requested HERE, in
+    // the accumulators' registers: one HBM / L2 latency, under the barrier and the first staged reads, instead of one in front
+    // of every pair of row groups.
+    const int sub = lane & 15, rsel = lane >> 4;
+    f32x4 xres[8][4];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const long m = (long)blockIdx.x * BM + wave * 32 + 4 * g + rsel;
+        const long mc = m < p.M ? m : p.M - 1;                  // tail rows recompute the last row, never stored
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xres[g][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)mc * p.ldx + (sub + 16 * k) * 4);
+    }
     __syncthreads();
     // Row pass: FOUR rows per wave-instruction, 16 lanes per row, each lane four 16-byte column chunks (sub, sub + 16, ...):
     // the two LayerNorm reductions run over 16 lanes with four DPP steps each (quad swaps + the two row mirrors) instead of
     // six cross-lane permutes over the whole wave, and eight such groups per wave are independent chains the scheduler can
     // overlap (one row per instruction with a 64-lane butterfly measured 21 % of the kernel).
-    const int sub = lane & 15, rsel = lane >> 4;
     f32x4 s2[4], b2[4], ga[4], be[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -274,34 +297,44 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         be[k] = *reinterpret_cast<const f32x4*>(p.beta + col);
     }
     int bad = range_bad;
-#pragma unroll 2
-    for (int g = 0; g < 8; ++g) {
-        const int lr = wave * 32 + 4 * g + rsel;               // row inside the workgroup's tile
-        const long m = (long)blockIdx.x * BM + lr;
-        const long mc = m < p.M ? m : p.M - 1;                  // tail rows recompute the last row, never stored
-        f32x4 v[4];
-        float sum = 0.f;
+    // Four row groups at a time: their sixteen staged chunks are read in one batch (one LDS latency, not sixteen).
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ch = sub + 16 * k;
-            const f32x4 y = *reinterpret_cast<const f32x4*>(stg + lr * D + ((ch ^ (lr & 7)) << 2));
-            const f32x4 x = *reinterpret_cast<const f32x4*>(p.X + (size_t)mc * p.ldx + ch * 4);
-            v[k] = y * s2[k] + b2[k] + x;
-            sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    for (int gh = 0; gh < 2; ++gh) {
+        f32x4 v[4][4];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const int lr = wave * 32 + 4 * (4 * gh + gi) + rsel;   // row inside the workgroup's tile
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ch = sub + 16 * k;
+                v[gi][k] = *reinterpret_cast<const f32x4*>(stg + lr * D + ((ch ^ (lr & 7)) << 2));
+            }
         }
-        const float mean = row16_sum(sum) * (1.f / D);
-        float q = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[k] = v[k] - mean;
-            q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
-        }
-        const float rstd = rsqrtf(row16_sum(q) * (1.f / D) + p.eps);
+        for (int gi = 0; gi < 4; ++gi) {
+            const int g = 4 * gh + gi;
+            const long m = (long)blockIdx.x * BM + wave * 32 + 4 * g + rsel;
+            float sum = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f32x4 o = v[k] * rstd * ga[k] + be[k];
-            bad |= !(fabsf(o[0]) <= 3.4e38f) | !(fabsf(o[1]) <= 3.4e38f) | !(fabsf(o[2]) <= 3.4e38f) | !(fabsf(o[3]) <= 3.4e38f);
-            if (m < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + (sub + 16 * k) * 4) = o;
+            for (int k = 0; k < 4; ++k) {
+                v[gi][k] = v[gi][k] * s2[k] + b2[k] + xres[g][k];
+                sum += (v[gi][k][0] + v[gi][k][1]) + (v[gi][k][2] + v[gi][k][3]);
+            }
+            const float mean = row16_sum(sum) * (1.f / D);
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[gi][k] = v[gi][k] - mean;
+                q += (v[gi][k][0] * v[gi][k][0] + v[gi][k][1] * v[gi][k][1]) + (v[gi][k][2] * v[gi][k][2] + v[gi][k][3] * v[gi][k][3]);
+            }
+            const float rstd = rsqrtf(row16_sum(q) * (1.f / D) + p.eps);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 o = v[gi][k] * rstd * ga[k] + be[k];
+                bad |= !(fabsf(o[0]) <= 3.4e38f) | !(fabsf(o[1]) <= 3.4e38f) | !(fabsf(o[2]) <= 3.4e38f) | !(fabsf(o[3]) <= 3.4e38f);
+                if (m < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + (sub + 16 * k) * 4) = o;
+            }
         }
     }
     if (bad && p.flag) atomicOr(p.flag, 1);                  // an activation left fp16's range (gemm_f16x3.hip contract)

@@ -38,7 +38,7 @@ struct RowArgs {
     const float* R;
     float* C;
     int* flag;
-    int lda, ldr, ldc, M, chunks, cpg, r_chunks, relu;
+    int lda, ldr, ldc, M, chunks, cpg, r_chunks, relu, r_period;
 };
 
 __device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) {
@@ -61,11 +61,25 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8& p0, 
     p1 = __builtin_bit_cast(half8, (u32x4{h0, h1, h2, h3}));
 }
 
+template <bool ROWS_FIRST>
+__device__ __forceinline__ f32x16 mfma_either(const half8 w, const half8 x, const f32x16 acc) {
+    if constexpr (ROWS_FIRST) return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, acc, 0, 0, 0);
+}
+
 // MUBUF LDS-DMA (not global_load_lds: see ffn_fused.hip -- the FLAT form turns every counted lgkmcnt wait into lgkmcnt(0))
 __device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned byte_offset, unsigned char* lds_frag) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)byte_offset, 0, 0, 0);
 }
 
+// LINES = false: C^T chunk = Wc . A^T, the lane is the ROW (four 16-byte stores per chunk, each 32-byte pieces of 32 lines);
+// LINES = true: C chunk = A . Wc^T, the lane is the COLUMN and register r holds row (r & 3) + 8 (r >> 2) + 4 h of the wave's 32
+// (sixteen 4-byte stores per chunk, each two WHOLE 128-byte lines).  Same products, same order: the same bits (tests).  Long
+// problems are bound by their store path -- with the stores removed the kernel takes 25 % less time (tools/exp/k256_clock.py:
+// 368 -> 274 us at M = 297 368, N = 640) -- and whole lines cost it 6-7 % less (368 -> 345 us; N = 1536: 816 -> 763 us); short
+// ones (the decoder, less than one workgroup per CU) are not, and pay 3 % for the twelve extra store instructions (18.7 -> 19.5 us
+// at M = 20 000, N = 256): the launcher picks by M.
+template <bool LINES>
 __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -168,9 +182,9 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
 #define K256_MFMA(src, g)                                                                                     \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
         const int s_ = (g) * 4 + i_;                                                                          \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[1][s_], acc, 0, 0, 0);                   \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_ + 1], xf[0][s_], acc, 0, 0, 0);               \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[0][s_], acc, 0, 0, 0);                   \
+        acc = mfma_either<LINES>(src[2 * i_], xf[1][s_], acc);                                                \
+        acc = mfma_either<LINES>(src[2 * i_ + 1], xf[0][s_], acc);                                            \
+        acc = mfma_either<LINES>(src[2 * i_], xf[0][s_], acc);                                                \
     }
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[g] = 0.f;
@@ -189,6 +203,28 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
 
     {
         const float lo = p.relu ? 0.f : -INFINITY;
+        // residual row of this lane (LINES = false); `r_period` > 0: row m reads R[m % r_period] (a table repeated per frame)
+        const long rrow = p.r_period > 0 ? row % p.r_period : row;
+        // LINES: output (and residual) rows of this workgroup through buffer descriptors that end with its last valid row --
+        // stores to rows >= M are dropped by the bounds check and still ISSUED, so that the counted wait below stays exact.
+        // Lane (column fr, half h) addresses row 4 h of its wave's 32; register r adds (r & 3) + 8 (r >> 2) rows (in the
+        // VECTOR offset: the bounds check does not see the scalar one).
+        const long tile0 = (long)blockIdx.x * BM;
+        const unsigned rows_here = (unsigned)min((long)BM, (long)p.M - tile0);
+        const unsigned c_row = (unsigned)p.ldc * 4u, r_row = (unsigned)p.ldr * 4u;
+        const __amdgpu_buffer_rsrc_t rs_c =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (size_t)tile0 * p.ldc), 0, (int)(rows_here * c_row), 0x00020000);
+        const bool periodic = p.r_period > 0;
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(!p.R ? p.C : periodic ? p.R : p.R + (size_t)tile0 * p.ldr), 0,
+            !p.R ? 0 : (int)((periodic ? (unsigned)p.r_period : rows_here) * r_row), 0x00020000);
+        const unsigned c_lane = (unsigned)(wave * 32 + 4 * fh) * c_row;
+        const unsigned r_first = periodic ? (unsigned)((tile0 + wave * 32 + 4 * fh) % p.r_period) : (unsigned)(wave * 32 + 4 * fh);
+        auto r_offset = [&](int k) {                         // byte offset of residual row (first + k), wrapped once (period >= 32)
+            unsigned rr = r_first + (unsigned)k;
+            if (periodic && rr >= (unsigned)p.r_period) rr -= (unsigned)p.r_period;
+            return rr * r_row;
+        };
         for (int c = c0; c < c1; ++c) {
             const int st = (c - c0) & 1;
             const bool more = c + 1 < c1;
@@ -197,29 +233,51 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
                              smem + (st ^ 1) * CHUNK_BYTES + W_FRAGS * FRAG);
             const unsigned nsrc = more ? (unsigned)(c + 1) * CHUNK_BYTES + wave * FRAG + lane * 16 : OOB;
             unsigned char* ndst = smem + (st ^ 1) * CHUNK_BYTES + wave * FRAG;
-            const bool use_r = p.R && c < p.r_chunks;        // residual quads of this chunk: issued before the MFMAs
-            f32x4 rv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                rv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (use_r) rv[q] = *reinterpret_cast<const f32x4*>(p.R + (size_t)row * p.ldr + CW * c + 8 * q + 4 * fh);
-            }
-            chunk_product(smem + st * CHUNK_BYTES + lane * 16, acc, nsrc, ndst);
+            const bool use_r = p.R && c < p.r_chunks;
             const float* aux = reinterpret_cast<const float*>(smem + st * CHUNK_BYTES + W_FRAGS * FRAG);
+            if constexpr (!LINES) {
+                f32x4 rv[4];                                 // residual quads of this chunk: issued before the MFMAs
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(aux + 8 * q + 4 * fh);
-                const f32x4 bi = *reinterpret_cast<const f32x4*>(aux + CW + 8 * q + 4 * fh);
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = fmaxf(fmaf(acc[4 * q + e], sc[e], bi[e]) + rv[q][e], lo);
-                    bad |= !(fabsf(v[e]) <= 3.4e38f);
+                for (int q = 0; q < 4; ++q) {
+                    rv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (use_r) rv[q] = *reinterpret_cast<const f32x4*>(p.R + (size_t)rrow * p.ldr + CW * c + 8 * q + 4 * fh);
                 }
-                *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + CW * c + 8 * q + 4 * fh) = v;
+                chunk_product(smem + st * CHUNK_BYTES + lane * 16, acc, nsrc, ndst);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(aux + 8 * q + 4 * fh);
+                    const f32x4 bi = *reinterpret_cast<const f32x4*>(aux + CW + 8 * q + 4 * fh);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaxf(fmaf(acc[4 * q + e], sc[e], bi[e]) + rv[q][e], lo);
+                        bad |= !(fabsf(v[e]) <= 3.4e38f);
+                    }
+                    *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + CW * c + 8 * q + 4 * fh) = v;
+                }
+                // the four stores may stay in flight; everything older (the next stage's DMA, the residual loads) has landed
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                const unsigned voff = (unsigned)(CW * c + fr) * 4u;
+                chunk_product(smem + st * CHUNK_BYTES + lane * 16, acc, nsrc, ndst);
+                const float sc = aux[fr], bi = aux[CW + fr];
+                // (the residual is read HERE, not in front of the MFMAs: sixteen more live registers there spill -- two
+                // workgroups per CU leave 256 -- and the other workgroup's MFMAs run under this latency)
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    rv[r] = 0.f;
+                    if (use_r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)(voff + r_offset((r & 3) + 8 * (r >> 2))), 0, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaxf(fmaf(acc[r], sc, bi) + rv[r], lo);
+                    bad |= !(fabsf(v) <= 3.4e38f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c, (int)(voff + c_lane + ((r & 3) + 8 * (r >> 2)) * c_row), 0, 0);
+                }
+                // the sixteen stores may stay in flight; everything older has landed
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             }
-            // the four stores may stay in flight; everything older (the next stage's DMA, the residual loads) has landed
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __syncthreads();                                 // next stage complete for everybody; nobody still reads this one
         }
     }
@@ -268,14 +326,20 @@ extern "C" int gom_gemm_k256_image(const void* w_planes, long w_plane_stride, in
     return gom_launch_status();
 }
 
-extern "C" int gom_gemm_k256_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr,
-                                 int r_cols, int relu, float* C, int ldc, int M, int N, int K, int col_groups, int* flag,
-                                 void* stream) {
+static int g_k256_lines = -1;                            // -1: by M (long problems), 0 / 1: forced (tests, tools)
+
+extern "C" void gom_gemm_k256_set_lines(int mode) { g_k256_lines = mode; }
+
+extern "C" int gom_gemm_k256_rp_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr,
+                                    int r_cols, int r_period, int relu, float* C, int ldc, int M, int N, int K, int col_groups,
+                                    int* flag, void* stream) {
     GOM_CHECK_ARG(A && image && C && M >= 0 && K == KD && N > 0 && (N % CW) == 0);
     GOM_CHECK_ARG(lda >= KD && (lda % 4) == 0 && ldc >= N && (ldc % 4) == 0 && (!R || (ldr >= r_cols && (ldr % 4) == 0)));
     GOM_CHECK_ARG(((uintptr_t)A % 16) == 0 && (!A2 || ((uintptr_t)A2 % 16) == 0) && ((uintptr_t)C % 16) == 0 &&
                   (!R || ((uintptr_t)R % 16) == 0) && ((uintptr_t)image % 16) == 0);
     GOM_CHECK_ARG(!R || (r_cols > 0 && r_cols <= N && (r_cols % CW) == 0));
+    // a periodic residual: at least one wave's rows per period (one wrap per wave), the table below 4 GB (buffer descriptor)
+    GOM_CHECK_ARG(r_period == 0 || (R && r_period >= 32 && (long)r_period * ldr * 4 < (1L << 32)));
     if (M == 0) return GOM_OK;
     const int chunks = N / CW, tiles = cdiv(M, BM);
     int groups = col_groups;
@@ -288,14 +352,25 @@ extern "C" int gom_gemm_k256_f32(const float* A, const float* A2, int lda, const
     RowArgs a{};
     a.A = A; a.A2 = A2; a.img = (const unsigned char*)image; a.R = R; a.C = C; a.flag = flag;
     a.lda = lda; a.ldr = ldr; a.ldc = ldc; a.M = M; a.chunks = chunks; a.cpg = cdiv(chunks, groups);
-    a.r_chunks = R ? r_cols / CW : 0; a.relu = relu ? 1 : 0;
+    a.r_chunks = R ? r_cols / CW : 0; a.relu = relu ? 1 : 0; a.r_period = r_period;
     const dim3 grid((unsigned)tiles, (unsigned)cdiv(chunks, a.cpg));
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_k256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_k256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)gemm_k256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_k256_kernel, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    // whole-line stores for long problems (>= one round of two workgroups per CU), see the kernel's header
+    const bool lines = g_k256_lines < 0 ? tiles >= 512 : g_k256_lines != 0;
+    if (lines) hipLaunchKernelGGL(gemm_k256_kernel<true>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gemm_k256_kernel<false>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return gom_launch_status();
+}
+
+extern "C" int gom_gemm_k256_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr,
+                                 int r_cols, int relu, float* C, int ldc, int M, int N, int K, int col_groups, int* flag,
+                                 void* stream) {
+    return gom_gemm_k256_rp_f32(A, A2, lda, image, R, ldr, r_cols, 0, relu, C, ldc, M, N, K, col_groups, flag, stream);
 }

@@ -93,6 +93,8 @@ class DeepSolo:
         for i in range(self.n_enc):
             p = t + "encoder.layers.%d." % i
             attn, n1 = msda(p + "self_attn"), norm(p + "norm1")
+            # long problem, N = 640: the row-resident K = 256 kernel's whole-line-store form under the f16x3 back-end
+            attn["raw_value"] = ops.k256_linear(*attn["raw_value"])
             self.enc.append({"attn": attn, "norm1": n1, "lin1": lin(p + "linear1"),
                              "lin2": lin(p + "linear2"), "norm2": norm(p + "norm2"), "ffn": ffn(p, "norm2"),
                              # out_proj + residual + norm1 as one launch (csrc/proj_ln.hip) under the f16x3 back-end, else None
@@ -249,9 +251,8 @@ class DeepSolo:
     def encoder(self, src, geo, B):
         S = geo["S"]
         for li, L in enumerate(self.enc):
-            w, b = L["attn"]["raw_value"]
-            rv = ops.gemm(src, w, bias=b, R=geo["pos_w"][li], r_cols=384,
-                          r_period=S if geo["pos_periodic"] else 0)                       # [B*S, 384 | 256]
+            rv = ops.linear(src, L["attn"]["raw_value"], R=geo["pos_w"][li], r_cols=384,
+                            r_period=S if geo["pos_periodic"] else 0)                     # [B*S, 384 | 256]
             if geo["vr"] is not None:                      # padded batch: value.masked_fill(padding_mask, 0)
                 ops.zero_padded_tokens_(rv, 384, 256, geo["shapes"], geo["lsi"], geo["vshapes"], B, S)
             samp = ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, geo["vr"])

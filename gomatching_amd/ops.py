@@ -324,16 +324,18 @@ def masked_stream(mask_words, device):
 
 K256_GEMM = _switch("K256_GEMM")   # f16x3 back-end: K = 256 products on the row-resident kernel where it measures faster (below)
 K256_MAX_ROWS = 1 << 16  # "short" problems (the decoder's Q side: M = frames x queries x points)
+K256_LONG = _switch("K256_LONG")   # long problems: N >= 512 on the kernel's whole-line-store form (off: N >= 1024, 16-byte stores)
 
 
 def k256_wins(M, N, has_a2):
     """Kernel choice from tools/gemm_k256_bench.py (interleaved A/B on MI355X).  Both kernels return the same
     bits, so this is a pure speed rule.  Short problems: N = 256 (21 vs 24 us at M = 20 000) and everything with a second
-    addend (the tile kernel needs an `add` launch first: 23-54 vs 32-56 us); long problems: wide outputs (N = 1536:
-    811 vs 972 us at M = 297 368; the tile kernel wins at N = 256 / 640 there)."""
+    addend (the tile kernel needs an `add` launch first: 23-54 vs 32-56 us); long problems (whole-line-store form of the kernel):
+    N >= 512 (at M = 297 368: N = 640 with the periodic position table 354 vs 449 us, N = 1536 747 vs 944 us; the tile kernel
+    keeps N = 256: 170 vs 175 us)."""
     if M <= K256_MAX_ROWS:
         return N == 256 or has_a2
-    return N >= 1024
+    return N >= (512 if K256_LONG else 1024)
 
 
 class K256Linear:
@@ -360,13 +362,14 @@ def k256_linear(w, bias=None):
     return (w, bias)
 
 
-def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0):
-    """act((x [+ A2]) @ W^T + b [+ R]) for `lin` = K256Linear or a (weight, bias) pair."""
+def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0, r_period=0):
+    """act((x [+ A2]) @ W^T + b [+ R]) for `lin` = K256Linear or a (weight, bias) pair; r_period > 0: row m adds
+    R[m % r_period] (ops.gemm)."""
     if not isinstance(lin, K256Linear):
-        return gemm(x, lin[0], bias=lin[1], A2=A2, R=R, relu=relu, r_cols=r_cols, out=out)
+        return gemm(x, lin[0], bias=lin[1], A2=A2, R=R, relu=relu, r_cols=r_cols, out=out, r_period=r_period)
     M = x.shape[0]
     if M == 0 or not (groups or k256_wins(M, lin.N, A2 is not None)):       # an explicit `groups` forces the kernel (tests, tools)
-        return gemm(x, lin.W, bias=lin.bias, A2=A2, R=R, relu=relu, r_cols=r_cols, out=out)
+        return gemm(x, lin.W, bias=lin.bias, A2=A2, R=R, relu=relu, r_cols=r_cols, out=out, r_period=r_period)
     assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == lin.K and x.dtype == _f32
     lda = x.stride(0) if M > 1 else lin.K
     if A2 is not None:
@@ -379,16 +382,18 @@ def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0)
     if R is not None:
         assert R.dim() == 2 and R.stride(1) == 1 and R.dtype == _f32
         ldr, rc = (R.stride(0) if R.shape[0] > 1 else R.shape[1]), (r_cols if r_cols is not None else N)
+    if not K256_LONG:
+        _L().gom_gemm_k256_set_lines(0)                      # (A/B switch only: the round-2 mid-state of the kernel)
     prof = _gemm_profile if _gemm_profile is not None else None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_L().gom_gemm_k256_f32(_p(x), _p(A2), lda, _p(lin.image), _p(R), ldr, rc, 1 if relu else 0, _p(out),
-                                 out.stride(0) if out.shape[0] > 1 else N, M, N, lin.K, groups or 1, _p(range_flag(x.device)),
-                                 _stream()), "gom_gemm_k256_f32")
+    check(_L().gom_gemm_k256_rp_f32(_p(x), _p(A2), lda, _p(lin.image), _p(R), ldr, rc, int(r_period), 1 if relu else 0, _p(out),
+                                    out.stride(0) if out.shape[0] > 1 else N, M, N, lin.K, groups or 1,
+                                    _p(range_flag(x.device)), _stream()), "gom_gemm_k256_rp_f32")
     if prof is not None:
         e1.record()
-        nbytes = 4.0 * M * lin.K * (2 if A2 is not None else 1) + lin.image.numel() + 4.0 * M * N + 4.0 * M * rc
+        nbytes = 4.0 * M * lin.K * (2 if A2 is not None else 1) + lin.image.numel() + 4.0 * M * N + 4.0 * (r_period or M) * rc
         prof.append((e0, e1, 2.0 * M * N * lin.K, nbytes, "k256:%dx%dx%d" % (M, N, lin.K)))
     return out
 

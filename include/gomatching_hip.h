@@ -156,6 +156,14 @@ int gom_gemm_k256_image(const void* w_planes, long w_plane_stride, int ldw, cons
                         int N, int K, void* image, long image_bytes, void* stream);
 int gom_gemm_k256_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr, int r_cols,
                       int relu, float* C, int ldc, int M, int N, int K, int col_groups, int* flag, void* stream);
+/* ... with a PERIODIC residual: r_period > 0 -> row m reads R[m % r_period] (the encoder's position-embedding table, one copy
+ * per frame: deformable_transformer.py:235-248 with_pos_embed folded into the projection); r_period >= 32, table < 4 GB.
+ * gom_gemm_k256_f32 = r_period 0.  Long problems (>= 512 row tiles) run the kernel's whole-line-store form, short ones its
+ * 16-byte-store form -- the same bits; gom_gemm_k256_set_lines(0 / 1) forces one (tests, tools), -1 = by M. */
+int gom_gemm_k256_rp_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr, int r_cols,
+                         int r_period, int relu, float* C, int ldc, int M, int N, int K, int col_groups, int* flag,
+                         void* stream);
+void gom_gemm_k256_set_lines(int mode);
 
 /* Fused FFN block of a DeepSolo transformer layer (deformable_transformer.py:250-251,266-273 encoder linear1/ReLU/linear2 +
  * residual + norm2; :352-354,368-369 decoder + norm3):

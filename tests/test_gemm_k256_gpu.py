@@ -42,6 +42,38 @@ def test_k256_equals_tile_kernel(M, N, groups):
     ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
 
 
+@pytest.mark.parametrize("lines", [0, 1])
+@pytest.mark.parametrize("M,N,period", [(20000, 640, 2500), (4097, 96, 33), (129, 64, 32), (70000, 256, 0), (300, 512, 301)])
+def test_k256_store_forms_and_periodic_residual(lines, M, N, period):
+    """The kernel's two store forms (16-byte pieces with the row on the lane / whole 128-byte lines with the column on the
+    lane, gom_gemm_k256_set_lines) return the tile kernel's bits -- with a residual on the leading columns, a PERIODIC one
+    (row m adds R[m % period]: the encoder's position table, deepsolo.py encoder), ragged tails, column groups and `out` views."""
+    ops = _ops()
+    from gomatching_amd import lib
+    g = torch.Generator().manual_seed(M + N + period)
+    A = torch.randn((M, 256), generator=g).to(DEV) * 1.3
+    W = (torch.randn((N, 256), generator=g) * torch.logspace(-2, 1, N).view(-1, 1)).to(DEV)
+    b = torch.randn((N,), generator=g).to(DEV)
+    sw = ops.split_weight(W, kind="f16x3")
+    lin = ops.K256Linear(sw, b)
+    rc = max(32, (N * 3 // 5) // 32 * 32)
+    R = torch.randn((period or M, rc), generator=g).to(DEV)
+    wide = torch.full((M, N + 64), 7.0, device=DEV)
+    try:
+        lib.load().gom_gemm_k256_set_lines(lines)
+        for groups in (1, 2):
+            for kw in ({}, {"R": R, "r_cols": rc, "r_period": period}, {"R": R, "r_cols": rc, "r_period": period, "relu": True}):
+                ref = ops.gemm(A, sw, bias=b, **kw)
+                got = ops.linear(A, lin, groups=groups, **kw)
+                assert torch.equal(got, ref), (groups, sorted(kw), float((got - ref).abs().max()))
+        ops.linear(A, lin, groups=1, out=wide[:, 32:32 + N], R=R, r_cols=rc, r_period=period)
+        assert torch.equal(wide[:, 32:32 + N], ops.gemm(A, sw, bias=b, R=R, r_cols=rc, r_period=period))
+        assert float((wide[:, :32] - 7.0).abs().max()) == 0.0 and float((wide[:, 32 + N:] - 7.0).abs().max()) == 0.0
+    finally:
+        lib.load().gom_gemm_k256_set_lines(-1)
+    ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
+
+
 def test_k256_views_slices_and_range_flag():
     """Row-strided operands (column slices of wider buffers), a weight ROW slice (the fused in_proj's q|k and v parts), no bias,
     an `out` view -- and the fp16 range contract: an activation beyond 65504 raises at the next check."""
@@ -74,11 +106,11 @@ def test_kernel_choice_rule_is_a_speed_rule_only():
     """ops.linear picks the kernel from (M, N, second addend): whatever it picks, the bits are the tile kernel's."""
     ops = _ops()
     g = torch.Generator().manual_seed(3)
-    for M, N, a2 in ((5000, 256, False), (5000, 512, True), (5000, 512, False), (70000, 1024, False), (70000, 256, False)):
+    for M, N, a2 in ((5000, 256, False), (5000, 512, True), (5000, 512, False), (70000, 1024, False), (70000, 640, False), (70000, 256, False)):
         A = torch.randn((M, 256), generator=g).to(DEV)
         A2 = torch.randn((M, 256), generator=g).to(DEV) if a2 else None
         sw = ops.split_weight(torch.randn((N, 256), generator=g).to(DEV), kind="f16x3")
         b = torch.randn((N,), generator=g).to(DEV)
         assert torch.equal(ops.linear(A, ops.K256Linear(sw, b), A2=A2), ops.gemm(A, sw, bias=b, A2=A2))
     assert ops.k256_wins(20000, 256, False) and ops.k256_wins(20000, 768, True) and not ops.k256_wins(20000, 768, False)
-    assert ops.k256_wins(297368, 1536, False) and not ops.k256_wins(297368, 640, False)
+    assert ops.k256_wins(297368, 1536, False) and ops.k256_wins(297368, 640, False) and not ops.k256_wins(297368, 256, False)

@@ -54,3 +54,32 @@ for M in (20000, 297368):
         t2 = ab([lambda: ops.gemm(A, sw, bias=b, A2=A2, out=out), lambda: ops.linear(A, lin, A2=A2, out=out, groups=1)])
         line += " | +A2: add+tile %6.1f, k256 g1 %6.1f" % (t2[0], t2[1])
         print(line, flush=True)
+
+# Long problems: the kernel's two store forms (gom_gemm_k256_set_lines) against the tile kernel, with the encoder's periodic
+# position table on the first 384 columns (period = tokens per frame) where r_cols > 0.
+from gomatching_amd import lib
+M, S = 297368, 37171
+A = torch.randn((M, 256), generator=g).to(dev)
+for N, rc in ((640, 384), (640, 0), (256, 0), (1536, 0)):
+    W = torch.randn((N, 256), generator=g).to(dev)
+    b = torch.randn((N,), generator=g).to(dev)
+    R = torch.randn((S, rc), generator=g).to(dev) if rc else None
+    sw = ops.split_weight(W, kind="f16x3")
+    lin = ops.K256Linear(sw, b)
+    out = torch.empty((M, N), device=dev)
+    kw = {"R": R, "r_cols": rc, "r_period": S} if rc else {}
+    ref = ops.gemm(A, sw, bias=b, **kw)
+    same = []
+
+    def k256(mode):
+        def f():
+            lib.load().gom_gemm_k256_set_lines(mode)
+            ops.linear(A, lin, out=out, groups=1, **kw)
+            lib.load().gom_gemm_k256_set_lines(-1)
+        return f
+    for mode in (0, 1):
+        k256(mode)()
+        same.append(bool(torch.equal(out, ref)))
+    t = ab([lambda: ops.gemm(A, sw, bias=b, out=out, **kw), k256(0), k256(1)])
+    print("M %6d N %4d periodic R-cols %3d  tile %7.1f us | k256 16-byte stores %7.1f us | k256 whole-line stores %7.1f us | bits equal to the tile kernel: %s" % (
+        M, N, rc, t[0], t[1], t[2], same), flush=True)

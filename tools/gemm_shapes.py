@@ -58,10 +58,7 @@ for label, M, N, K, rc, a2 in SHAPES:
     # the product's own dispatch: ops.linear picks the row-resident K = 256 kernel where it measured faster (ops.k256_wins)
     lin = ops.k256_linear(W, b) if K == 256 else (W, b)
     kern = "gemm_k256_kernel" if isinstance(lin, ops.K256Linear) and ops.k256_wins(M, N, a2) else "gemm_f16x3_kernel"
-    if period:
-        run(label, lambda: ops.gemm(A, W, bias=b, R=R, r_cols=rc, r_period=period, out=out), 2.0 * M * N * K, kern)
-    else:
-        run(label, lambda: ops.linear(A, lin, R=R, r_cols=rc if rc else None, A2=A2, out=out), 2.0 * M * N * K, kern)
+    run(label, lambda: ops.linear(A, lin, R=R, r_cols=rc if rc else None, r_period=period, A2=A2, out=out), 2.0 * M * N * K, kern)
     del A, W, R, A2, out
 for label, M in (("enc out_proj + residual + LayerNorm fused (proj_ln)", S8), ("dec out_proj + residual + LayerNorm fused", Q)):
     w = (torch.randn((256, 256), generator=g) * 0.06).to(dev)
