@@ -362,7 +362,9 @@ def main():
     k256_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("k256:")]    # the decoder's row-resident K = 256 kernel
     pl_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("projln:")]    # out_proj + residual + LayerNorm launches
     all_prof = prof
-    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:")))]   # the dominant kernel: plain GEMMs
+    # the dominant kernel = the 128x128 tile kernel: every launch of it in the step, through the GEMM API and as the backbone's
+    # pointwise convolutions ("pw:", the same instantiation: csrc/gemm_f16x3.hip dispatch<0, 0>)
+    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:")))]
     dur_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     flops = sum(p[2] for p in prof)
     alg_bytes = sum(p[3] for p in prof)
@@ -371,7 +373,7 @@ def main():
         grids = set()
         for p_ in prof:
             if len(p_) > 4:
-                M_, N_, _ = [int(v) for v in p_[4].split("x")]
+                M_, N_, _ = [int(v) for v in p_[4].split(":")[-1].split("x")]
                 grids.add(((M_ + 127) // 128) * ((N_ + 127) // 128) * 256)
         with open(os.environ["GOM_BENCH_WRITE_GRIDS"], "w") as f:
             json.dump(sorted(grids), f)
@@ -429,9 +431,9 @@ def main():
                                   "frac": alg_bytes / (dur_ms * 1e-3) / 1e12 / 8.0 if dur_ms > 0 else 0.0,
                                   "flop_per_byte": flops / alg_bytes if alg_bytes > 0 else 0.0,
                                   "balance_flop_per_byte": PEAKS[args.gemm][1] * 1e12 / 8.0e12},
-                     "hbm_note": "the K = 256 shapes of this kernel (fp32 in, fp32 out) carry 44-105 FLOP per byte, below the "
-                                 "chip's balance of ~130: their HBM roofline (8 TB/s) caps them at 0.31-0.50 of the MFMA "
-                                 "peak whatever the kernel does (DESIGN.md §3)",
+                     "hbm_note": "fp32 in, fp32 out: the K = 256 shapes of this kernel carry 44-105 FLOP per byte and the backbone's pointwise "
+                                 "convolutions 32-200, around or below the chip's balance of ~104: the HBM roofline (8 TB/s) caps most "
+                                 "of them at 0.3-0.5 of the MFMA peak whatever the kernel does (DESIGN.md §3)",
                      "share_of_step_time": (dur_ms / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
                      "by_shape_MxNxK": {k: {"launches_per_step": v[0] // PROFILE_STEPS, "avg_us": v[1] * 1e3 / v[0],
                                             "tflops": v[2] / (v[1] * 1e-3) / 1e12,
@@ -452,12 +454,28 @@ def main():
             "note": "linear1 + ReLU + linear2 + residual + LayerNorm of every encoder / decoder layer in one launch: 2 KB of HBM "
                     "traffic per token instead of 13 (csrc/ffn_fused.hip)"}
         both_ms, both_fl = dur_ms + fd, flops + ff
+        k256_long = [p_ for p_ in k256_prof if int(p_[4].split(":")[1].split("x")[0]) > 65536]   # encoder-sized launches
+        k256_prof = [p_ for p_ in k256_prof if p_ not in k256_long]
+        if k256_long:
+            ld = sum(p_[0].elapsed_time(p_[1]) for p_ in k256_long)
+            lf, lb = sum(p_[2] for p_ in k256_long), sum(p_[3] for p_ in k256_long)
+            line["roofline_k256_long"] = {
+                "bound": "hbm", "kernel": "gemm_k256_kernel<true>", "achieved": lb / (ld * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
+                "frac": lb / (ld * 1e-3) / 1e12 / 8.0, "traffic": pmc_traffic("gemm_k256_kernel<true>"),
+                "mfma_view": {"achieved": lf / (ld * 1e-3) / 1e12, "peak": PEAKS["f16x3"][1], "unit": "TFLOP/s",
+                              "frac": lf / (ld * 1e-3) / 1e12 / PEAKS["f16x3"][1]},
+                "launches_per_step": len(k256_long) // PROFILE_STEPS, "avg_launch_us": ld * 1e3 / len(k256_long),
+                "share_of_step_time": (ld / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
+                "note": "the encoder's offsets | logits | value projection (N = 640, periodic position table) and the hoisted "
+                        "value_proj x6 (N = 1536) at M = frames x tokens on the row-resident kernel's whole-line-store form: 86 "
+                        "FLOP per HBM byte, an HBM-stream kernel (csrc/gemm_k256.hip)"}
+            both_ms, both_fl = both_ms + ld, both_fl + lf
         if k256_prof:
             kd = sum(p_[0].elapsed_time(p_[1]) for p_ in k256_prof)
             kf = sum(p_[2] for p_ in k256_prof)
             line["roofline_decoder_k256"] = {
-                "bound": "mfma", "kernel": "gemm_k256_kernel", "achieved": kf / (kd * 1e-3) / 1e12, "peak": PEAKS["f16x3"][1],
-                "unit": "TFLOP/s", "frac": kf / (kd * 1e-3) / 1e12 / PEAKS["f16x3"][1], "traffic": pmc_traffic("gemm_k256_kernel"),
+                "bound": "mfma", "kernel": "gemm_k256_kernel<false>", "achieved": kf / (kd * 1e-3) / 1e12, "peak": PEAKS["f16x3"][1],
+                "unit": "TFLOP/s", "frac": kf / (kd * 1e-3) / 1e12 / PEAKS["f16x3"][1], "traffic": pmc_traffic("gemm_k256_kernel<false>"),
                 "launches_per_step": len(k256_prof) // PROFILE_STEPS, "avg_launch_us": kd * 1e3 / len(k256_prof),
                 "share_of_step_time": (kd / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
                 "note": "the decoder's Q-side nn.Linear layers (M = frames x queries x points = 20 000 rows, K = 256): rows "
@@ -476,7 +494,8 @@ def main():
                         "HBM traffic per token (X, R in; Y out) instead of 5; 26 FLOP per byte, i.e. an HBM-stream kernel"}
             both_ms, both_fl = both_ms + pd, both_fl + sum(p_[2] for p_ in pl_prof)
         line["roofline"]["gemm_class_combined"] = {
-            "what": "plain GEMM launches + fused FFN launches together (round 1 ran the FFN's two GEMMs on the plain kernel)",
+            "what": "every GEMM-class launch of the step together: the tile kernel (GEMM API + pointwise convolutions), the fused FFN, "
+                    "the row-resident K = 256 kernel (both forms) and out_proj + LayerNorm",
             "achieved": both_fl / (both_ms * 1e-3) / 1e12, "frac": both_fl / (both_ms * 1e-3) / 1e12 / PEAKS[args.gemm][1],
             "share_of_step_time": (both_ms / PROFILE_STEPS) / (elapsed / args.steps * 1e3)}
     solo = rank == 0 and world == 1 and args.backbone == "r50" and args.emulate_world == 1

@@ -276,10 +276,21 @@ def conv2d_nhwc(x, w_ohwi, scale=None, shift=None, R=None, relu=False, stride=1,
             nbytes = 4 * splits * M * Cout
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
         if w_ohwi.kind == "f16x3":
+            # a pointwise convolution IS a launch of the GEMM tile kernel (dispatch<0, 0> in csrc/gemm_f16x3.hip): bench.py's
+            # roofline sample of that kernel covers these launches too (label "pw:")
+            prof = _gemm_profile if (_gemm_profile is not None and KH == 1 and stride == 1 and pad == 0 and splits == 1
+                                     and Cout > 64) else None
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _after = lambda: (e1.record(), prof.append((e0, e1, 2.0 * M * Cout * Cin, 4.0 * M * Cin + 4.0 * M * Cout * (
+                    2 if R is not None else 1) + 4.0 * Cout * Cin, "pw:%dx%dx%d" % (M, Cout, Cin))))
             check(_L().gom_conv2d_nhwc_f32_f16x3(_p(x), _p(pl), pl.stride(0), pl.stride(1), _p(w_ohwi.inv_scale),
                                                  _p(scale), _p(shift), _p(R), 1 if relu else 0, _p(y), B, H, Wd, Cin,
                                                  Cout, KH, KW, stride, pad, _p(ws), nbytes, splits,
                                                  _p(range_flag(x.device)), _stream()), "gom_conv2d_nhwc_f32_f16x3")
+            if prof is not None:
+                _after()
             return y
         check(_L().gom_conv2d_nhwc_f32_bf16x6_splitk(_p(x), _p(pl), pl.stride(0), pl.stride(1), _p(scale), _p(shift),
                                                      _p(R), 1 if relu else 0, _p(y), B, H, Wd, Cin, Cout, KH, KW, stride,

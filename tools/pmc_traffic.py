@@ -44,9 +44,10 @@ def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE", api_grids), per_kernel(sys.argv[2], "WRITE_SIZE", api_grids)
     out = {"_meta": {"kernel_source_hash": kernel_source_hash(), "round": tag,
                      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/gemm_shapes.py-free bench.py steps; "
-                             "FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM).  The dominant GEMM instantiation is split by grid "
-                             "size: launches whose workgroup count equals a GEMM-API shape of bench.py's transformer vs the "
-                             "backbone's pointwise convolutions (key + ' [pointwise conv]')"}}
+                             "FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM).  The dominant GEMM instantiation's key covers the "
+                             "launches bench.py's roofline sample covers (grid sizes written by GOM_BENCH_WRITE_GRIDS: the GEMM-API "
+                             "shapes of the transformer AND the backbone's pointwise convolutions wider than 64 channels); any "
+                             "other launch of the instantiation goes under key + ' [pointwise conv]'"}}
     for k in sorted(set(fetch) | set(write)):
         f = sum(fetch.get(k, [0])) / max(len(fetch.get(k, [0])), 1) * 1024.0
         w = sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1) * 1024.0
