@@ -278,7 +278,7 @@ def conv2d_nhwc(x, w_ohwi, scale=None, shift=None, R=None, relu=False, stride=1,
         if w_ohwi.kind == "f16x3":
             # a pointwise convolution IS a launch of the GEMM tile kernel (dispatch<0, 0> in csrc/gemm_f16x3.hip): bench.py's
             # roofline sample of that kernel covers these launches too (label "pw:")
-            prof = _gemm_profile if (_gemm_profile is not None and KH == 1 and stride == 1 and pad == 0 and splits == 1
+            prof = _gemm_profile if (_gemm_profile is not None and KH == 1 and stride == 1 and pad == 0 and splits <= 1
                                      and Cout > 64) else None
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
