@@ -12,17 +12,17 @@ import sys
 
 
 def per_kernel(path, counter, api_grids):
-    """{kernel name (+ ' [pointwise conv]' for launches of a GEMM instantiation whose grid is not a GEMM-API shape): values}"""
+    """{kernel name: values}; the dominant GEMM instantiation also under name + ' [gemm api]' / ' [pointwise conv]' by grid size"""
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
             name = name.split("(")[0].replace(" ", "")
+            agg[name].append(float(r["Counter_Value"]))
             if name.startswith("gemm_f16x3_kernel<128,128,0,0") or name.startswith("gemm_bf16x6_kernel<128,128,0,0") or \
                     name.startswith("gemm_f32_kernel<128,128,64,64,0,0"):
-                if api_grids and int(r["Grid_Size"]) not in api_grids:
-                    name += " [pointwise conv]"
-            agg[name].append(float(r["Counter_Value"]))
+                if api_grids:                                # the two populations of the instantiation, apart as well
+                    agg[name + (" [gemm api]" if int(r["Grid_Size"]) in api_grids else " [pointwise conv]")].append(float(r["Counter_Value"]))
     return agg
 
 
@@ -44,10 +44,10 @@ def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE", api_grids), per_kernel(sys.argv[2], "WRITE_SIZE", api_grids)
     out = {"_meta": {"kernel_source_hash": kernel_source_hash(), "round": tag,
                      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/gemm_shapes.py-free bench.py steps; "
-                             "FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM).  The dominant GEMM instantiation's key covers the "
-                             "launches bench.py's roofline sample covers (grid sizes written by GOM_BENCH_WRITE_GRIDS: the GEMM-API "
-                             "shapes of the transformer AND the backbone's pointwise convolutions wider than 64 channels); any "
-                             "other launch of the instantiation goes under key + ' [pointwise conv]'"}}
+                             "FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM).  The dominant GEMM instantiation appears three times: "
+                             "its plain key = every launch of it (what bench.py's `roofline` covers), key + ' [gemm api]' = launches "
+                             "whose grid is a GEMM-API shape of the transformer (grid sizes written by GOM_BENCH_WRITE_GRIDS), key + "
+                             "' [pointwise conv]' = the rest (the backbone's pointwise convolutions)"}}
     for k in sorted(set(fetch) | set(write)):
         f = sum(fetch.get(k, [0])) / max(len(fetch.get(k, [0])), 1) * 1024.0
         w = sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1) * 1024.0
