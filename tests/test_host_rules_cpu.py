@@ -1,0 +1,65 @@
+"""Host-side rules that need no GPU: the kernel-choice rule of ops.linear (pure speed rule) and the reduction of
+the two rocprofv3 PMC passes to profiles/pmc_traffic.json (tools/pmc_traffic.py): every launch of the dominant GEMM
+instantiation under its plain key, its GEMM-API and pointwise-convolution populations apart, FETCH_SIZE doubled."""
+import csv
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_k256_choice_rule():
+    from gomatching_amd import ops
+    long_before = ops.K256_LONG
+    try:
+        ops.K256_LONG = True
+        # short problems (the decoder's Q side): N = 256, or anything with a second addend
+        assert ops.k256_wins(20000, 256, False) and ops.k256_wins(20000, 512, True) and not ops.k256_wins(20000, 512, False)
+        assert ops.k256_wins(ops.K256_MAX_ROWS, 256, False)
+        # long problems: wide outputs on the whole-line-store form, N = 256 stays on the tile kernel
+        assert ops.k256_wins(297368, 640, False) and ops.k256_wins(297368, 1536, False) and not ops.k256_wins(297368, 256, False)
+        assert not ops.k256_wins(297368, 256, True)
+        ops.K256_LONG = False                                # the A/B switch restores the mid-round rule
+        assert not ops.k256_wins(297368, 640, False) and ops.k256_wins(297368, 1536, False)
+    finally:
+        ops.K256_LONG = long_before
+
+
+def _pmc_module():
+    spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(ROOT, "tools", "pmc_traffic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_pmc_reduction_splits_the_dominant_kernels_populations(tmp_path):
+    mod = _pmc_module()
+    dom = "void (anonymous namespace)::gemm_f16x3_kernel<128, 128, 0, 0, 3>((anonymous namespace)::Args)"
+    rows = [(dom, 1024, 100.0), (dom, 1024, 300.0), (dom, 4096, 1000.0),            # two GEMM-API launches, one pointwise conv
+            ("(anonymous namespace)::ffn_fused_kernel((anonymous namespace)::FfnArgs)", 512, 50.0)]
+    for name, counter in (("f.csv", "FETCH_SIZE"), ("w.csv", "WRITE_SIZE")):
+        with open(tmp_path / name, "w", newline="") as f:
+            wr = csv.writer(f)
+            wr.writerow(["Kernel_Name", "Grid_Size", "Counter_Name", "Counter_Value"])
+            for kn, grid, val in rows:
+                wr.writerow([kn, grid, counter, val])
+                wr.writerow([kn, grid, "SOMETHING_ELSE", 7.0])
+    fetch = mod.per_kernel(str(tmp_path / "f.csv"), "FETCH_SIZE", {1024})
+    key = "gemm_f16x3_kernel<128,128,0,0,3>"
+    assert fetch[key] == [100.0, 300.0, 1000.0]
+    assert fetch[key + " [gemm api]"] == [100.0, 300.0] and fetch[key + " [pointwise conv]"] == [1000.0]
+    assert fetch["ffn_fused_kernel"] == [50.0]
+    assert mod.per_kernel(str(tmp_path / "f.csv"), "FETCH_SIZE", set())[key] == [100.0, 300.0, 1000.0]   # no grid file: no split
+    # the hash that ties the committed counters to a build is the one bench.py checks
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert mod.kernel_source_hash() == bench.kernel_source_hash()
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        rec = json.load(f)
+    assert "kernel_source_hash" in rec["_meta"] and key in rec and (key + " [gemm api]") in rec
+    if rec["_meta"]["kernel_source_hash"] != bench.kernel_source_hash():
+        assert bench.pmc_traffic(key) is None                # counters of another build are never printed
+    else:
+        assert bench.pmc_traffic(key) == rec[key]["hbm_bytes_per_launch"]
