@@ -15,26 +15,29 @@ SO = os.path.join(HERE, "libk256_clock.so")
 def build():
     src = open(os.path.join(ROOT, "gomatching_amd", "csrc", "gemm_k256.hip")).read()
 
-    def once(s, a, b):
-        assert s.count(a) == 1, a
+    def once(s, a, b, n=1):
+        assert s.count(a) == n, a
         return s.replace(a, b)
-    src = once(src, '__global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {',
+    src = once(src, 'template <bool LINES>\n__global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {',
                '__device__ unsigned long long g_stamp[8192 * 12];\n'
                '#define NOW() __builtin_amdgcn_s_memtime()\n'
-               '__global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {\n'
+               'template <bool LINES>\n__global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {\n'
                '    const unsigned long long t_start = NOW(), r_start = __builtin_amdgcn_s_memrealtime();\n'
                '    unsigned long long t_prod = 0, t_store = 0, t_wait = 0, t_bar = 0;\n')
     src = once(src, '    {\n        const float lo = p.relu ? 0.f : -INFINITY;',
                '    const unsigned long long t_loop = NOW(), r_loop = __builtin_amdgcn_s_memrealtime();\n    {\n        const float lo = p.relu ? 0.f : -INFINITY;')
-    src = once(src, '            chunk_product(smem + st * CHUNK_BYTES + lane * 16, acc, nsrc, ndst);',
-               '            const unsigned long long ta_ = FINE ? NOW() : 0;\n'
-               '            chunk_product(smem + st * CHUNK_BYTES + lane * 16, acc, nsrc, ndst);\n'
-               '            const unsigned long long tb_ = FINE ? NOW() : 0;')
-    src = once(src, '            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");\n            __syncthreads();',
-               '            const unsigned long long tc_ = FINE ? NOW() : 0;\n'
-               '            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");\n'
-               '            const unsigned long long td_ = FINE ? NOW() : 0;\n            __syncthreads();\n'
-               '            if (FINE) { t_prod += tb_ - ta_; t_store += tc_ - tb_; t_wait += td_ - tc_; t_bar += NOW() - td_; }')
+    # both store forms of the kernel (template <bool LINES>): stamps around the product, the scale + store block and the wait
+    src = once(src, '                chunk_product(smem + st * CHUNK_BYTES + lane * 16, acc, nsrc, ndst);',
+               '                const unsigned long long ta_ = FINE ? NOW() : 0;\n'
+               '                chunk_product(smem + st * CHUNK_BYTES + lane * 16, acc, nsrc, ndst);\n'
+               '                const unsigned long long tb_ = FINE ? NOW() : 0;', 2)
+    for n_ in ("4", "16"):
+        src = once(src, '                asm volatile("s_waitcnt vmcnt(%s)" ::: "memory");' % n_,
+                   '                const unsigned long long tc_ = FINE ? NOW() : 0;\n'
+                   '                asm volatile("s_waitcnt vmcnt(%s)" ::: "memory");\n'
+                   '                if (FINE) { t_prod += tb_ - ta_; t_store += tc_ - tb_; t_wait += NOW() - tc_; }' % n_)
+    src = once(src, '            __syncthreads();                                 // next stage complete for everybody; nobody still reads this one',
+               '            const unsigned long long td_ = FINE ? NOW() : 0;\n            __syncthreads();\n            if (FINE) t_bar += NOW() - td_;')
     src = once(src, '    if (bad && p.flag) atomicOr(p.flag, 1);                  // an operand left fp16',
                '    if (blockIdx.y == 0 && blockIdx.x < 8192 && lane == 0 && wave == 0) {\n'
                '        unsigned long long* o = g_stamp + blockIdx.x * 12;\n'
@@ -43,8 +46,10 @@ def build():
                '    if (bad && p.flag) atomicOr(p.flag, 1);                  // an operand left fp16')
     src += ('\nextern "C" int k256_clock_read(unsigned long long* host) {\n'
             '    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 8192 * 12);\n}\n')
-    src = once(src, '                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c,',
-               '                if (!NOSTORE || p.M < 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c,')
+    src = once(src, '                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c,',
+               '                    if (!NOSTORE || p.M < 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c,')
+    src = once(src, '                    *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + CW * c + 8 * q + 4 * fh) = v;',
+               '                    if (!NOSTORE || p.M < 0) *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + CW * c + 8 * q + 4 * fh) = v;')
     gen = os.path.join(HERE, "_k256_clock_gen.hip")
     open(gen, "w").write(src)
     for fine in (0, 1, 2):
