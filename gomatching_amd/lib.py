@@ -49,6 +49,7 @@ SIGNATURES = {
     "gom_gemm_k256_f32": (I, [P, P, I, P, P, I, I, I, P, I, I, I, I, I, P, P]),
     "gom_gemm_k256_rp_f32": (I, [P, P, I, P, P, I, I, I, I, P, I, I, I, I, I, P, P]),
     "gom_gemm_k256_set_lines": (None, [I]),
+    "gom_stem_conv_pool_f32": (I, [P, P, L, I, P, P, P, P, I, I, I, P, P]),
     "gom_ffn_fused_image_bytes": (L, [I, I]),
     "gom_ffn_fused_image": (I, [P, L, I, P, P, P, L, I, I, I, P, L, P]),
     "gom_ffn_fused_ln_f32": (I, [P, I, P, P, P, P, P, F, P, I, I, I, I, P, P]),

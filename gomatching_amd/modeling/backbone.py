@@ -59,8 +59,12 @@ class ResNet50:
 
     def forward(self, x_nhwc4):
         """x: [B,H,W,4] normalised RGB + zero channel.  Returns {'res3','res4','res5'} NHWC."""
-        x = self._conv(x_nhwc4, "stem.conv1", stride=2, pad=3, relu=True)
-        x = ops.maxpool3x3s2(x)
+        w, sc, sh = self.convs["stem.conv1"]
+        if ops.stem_pool_serves(w):                          # one launch: the 910 MB between conv and pool never exist
+            x = ops.stem_conv_pool(x_nhwc4.contiguous(), w, scale=sc, shift=sh)
+        else:
+            x = self._conv(x_nhwc4, "stem.conv1", stride=2, pad=3, relu=True)
+            x = ops.maxpool3x3s2(x)
         outs = {}
         for stage, p, s, has_sc, last in self.blocks:
             sc = self._conv(x, p + "shortcut", stride=s) if has_sc else x

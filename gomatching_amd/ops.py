@@ -641,6 +641,31 @@ def ingest(frames, out_h, out_w, mean, std, flip):
     return out
 
 
+STEM_POOL = _switch("STEM_POOL")     # f16x3 back-end: the ResNet stem (conv 7x7 / 2 + BN + ReLU + max-pool 3x3 / 2) as one launch
+
+
+def stem_conv_pool(x, w, scale=None, shift=None):
+    """relu(conv7x7 / stride 2 / pad 3 (x) * scale + shift) followed by max_pool2d(3, 2, 1), one launch (csrc/stem_pool.hip):
+    x [B, H, W, 4] fp32, w = prep_conv_weight of the [64, 7, 7, 4] stem weight under the f16x3 back-end.  Equal bit for bit to
+    conv2d_nhwc(..., relu=True, stride=2, pad=3) + maxpool3x3s2."""
+    assert isinstance(w, SplitWeight) and w.kind == "f16x3" and tuple(w.conv_shape) == (64, 7, 7, 4)
+    _chk_f32(x, scale, shift)
+    B, H, Wd, Cin = x.shape
+    assert Cin == 4 and x.is_contiguous()
+    OH, OW = (H + 6 - 7) // 2 + 1, (Wd + 6 - 7) // 2 + 1
+    PH, PW = (OH + 2 - 3) // 2 + 1, (OW + 2 - 3) // 2 + 1
+    y = torch.empty((B, PH, PW, 64), dtype=_f32, device=x.device)
+    pl = w.planes
+    check(_L().gom_stem_conv_pool_f32(_p(x), _p(pl), pl.stride(0), pl.stride(1), _p(w.inv_scale), _p(scale), _p(shift), _p(y),
+                                      B, H, Wd, _p(range_flag(x.device)), _stream()), "gom_stem_conv_pool_f32")
+    return y
+
+
+def stem_pool_serves(w):
+    return bool(STEM_POOL and GEMM_MODE == "f16x3" and isinstance(w, SplitWeight) and w.kind == "f16x3"
+                and tuple(getattr(w, "conv_shape", ())) == (64, 7, 7, 4))
+
+
 def maxpool3x3s2(x):
     _chk_f32(x)
     B, H, W, C = x.shape

@@ -129,6 +129,13 @@ int gom_conv2d_nhwc_f32_f16x3(const float* X, const void* Wplanes, long w_plane_
                               const float* scale, const float* shift, const float* R, int relu, float* Y, int B, int H,
                               int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
                               long workspace_bytes, int splits, int* flag, void* stream);
+/* The ResNet stem as one launch (csrc/stem_pool.hip): conv 7x7 / stride 2 / pad 3 from the 4-channel NHWC input to 64 channels
+ * (weights = the gom_split_f16x2 planes of the [64, 7*7*4] matrix, K padded to ldw) + per-channel scale / shift (folded
+ * BatchNorm, may be NULL) + ReLU + max_pool2d(3, stride 2, pad 1): Y [B, PH, PW, 64], PH = ((H - 1) / 2) / 2 + 1 likewise PW
+ * (detectron2 BasicStem: modeling/backbone/resnet.py as built by adet's build_resnet_backbone).  Equal bit
+ * for bit to gom_conv2d_nhwc_f32_f16x3 followed by gom_maxpool3x3s2_nhwc_f32, same range contract and *flag. */
+int gom_stem_conv_pool_f32(const float* X, const void* Wplanes, long w_plane_stride, int ldw, const float* wscale,
+                           const float* scale, const float* shift, float* Y, int B, int H, int Wd, int* flag, void* stream);
 
 /* Output projection + residual + LayerNorm of an attention block in ONE launch (csrc/proj_ln.hip):
  *     Y = LayerNorm(X W^T + b + R) * gamma + beta,   X, R, Y [M, 256] fp32 (row strides ldx / ldr / ldy; Y may alias R), W [256, 256]
