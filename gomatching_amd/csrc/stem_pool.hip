@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 float v = acc[i][r] * sc + sh;
+                bad |= !(fabsf(v) <= 3.4e38f);               // BEFORE the ReLU: max(NaN, 0) = 0 would hide an Inf - Inf
                 v = fmaxf(v, 0.f);
-                bad |= !(fabsf(v) <= 3.4e38f);
                 patch[row * PITCH + n] = v;
             }
     }
