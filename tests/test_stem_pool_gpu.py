@@ -45,9 +45,8 @@ def test_stem_range_flag_and_backbone_switch():
     # the backbone with the fused stem equals the backbone without it
     from gomatching_amd.modeling.backbone import ResNet50
     from gomatching_amd.weights import synth_state_dict
-    from gomatching_amd.config import get_cfg
-    cfg = get_cfg()
-    sd = synth_state_dict(cfg, seed=0)
+    from helpers import mini_cfg
+    sd = synth_state_dict(mini_cfg(), seed=0)
     x = torch.randn((1, 96, 160, 4), generator=g).to(DEV)
     x[..., 3] = 0.0
     outs = []
