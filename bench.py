@@ -84,7 +84,7 @@ def calibrate(model, inputs, frac=0.3):
     T = model.cfg.MODEL.TRANSFORMER
     m = out["pred_logits"].view(T.NUM_QUERIES, T.NUM_POINTS).mean(1)
     shift = logit_thr - float(torch.quantile(m, max(0.0, 1 - frac))) + (1.0 if frac >= 1.0 else 0.0)
-    model.detection_transformer.ctrl_class[1].add_(shift)
+    model.add_class_bias(shift)
     re_shift = None
     if model.with_rescore:
         r = model.roi_heads.rescoring_head(out["query_features"]).view(T.NUM_QUERIES, T.NUM_POINTS).mean(1)
@@ -135,6 +135,47 @@ def cpu_baseline(cfg, sd, shift, re_shift, frames_chw, orig_hw, gpu_res, gpu_id_
             "full_size_parity_clip": parity}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: start N fresh child processes of this script, one per GPU (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment; the reference starts its own workers the same way,
+    train_net.py:198-209 -> detectron2 `launch`), relay their output -- rank 0 prints the one JSON line -- and return non-zero
+    when any rank fails.  The parent never touches the GPU (device_count() does not initialise HIP on this image), and
+    nothing is exec'ed from a process that has."""
+    import socket
+    import subprocess
+    backend = os.environ.get("GOM_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print("bench.py: --gpus %d but only %d GPU(s) visible (RCCL needs one device per rank; GOM_BENCH_BACKEND=gloo lets "
+              "the ranks share a device for a dry run)" % (n, have), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:                                               # a dead rank would leave the others in a collective for ever
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("bench.py: rank %d exited with %d; stopping the other ranks" % (procs.index(p), code), file=sys.stderr)
+                for q in alive:
+                    q.terminate()
+        time.sleep(0.2)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,14 +205,19 @@ def main():
     ap.add_argument("--gemm", default="f16x3", choices=["f16x3", "bf16x6", "fp32"],
                     help="contraction back-end: two-plane fp16 split on the fp16 matrix cores (default), three-plane bf16 "
                          "split, or exact-fp32 MFMA")
+    ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU,
+                    help="diagnostic: frames of the clip each rank owns per step (BASELINE.json: 8; the self-launch test compares "
+                         "N=2 x 8 with N=1 x 16, the same 16-frame clip)")
     args = ap.parse_args()
+    globals()["FRAMES_PER_GPU"] = args.frames_per_gpu
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))              # plain `python bench.py --gpus N`: spawn the ranks ourselves
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
     # GOM_BENCH_BACKEND=gloo is a dry-run aid only: several ranks share the one GPU of a test box and exchange through host
     # memory, which exercises the whole N>1 code path except RCCL itself (the driver's multi-GPU runs use the default)
@@ -233,7 +279,7 @@ def main():
         if not shifts:
             shifts["s"], shifts["r"] = calibrate(model, cal_inputs, frac=args.detect_frac)
         else:
-            model.detection_transformer.ctrl_class[1].add_(shifts["s"])
+            model.add_class_bias(shifts["s"])
             if shifts["r"] is not None:
                 model.roi_heads._rescoring[1].add_(shifts["r"])
         tc_box = [new_time_cost()]
@@ -426,7 +472,14 @@ def main():
                    % world if world > 1 else "single GPU",
                    "detect_frac": args.detect_frac,
                    "detections_per_frame": [len(r["instances"]) for r in res[:FRAMES_PER_GPU]],
-                   "tracks": int(id_count)},
+                   "tracks": int(id_count),
+                   # ranks whose records arrived through the step's one all-gather (rows of the gathered buffer / frames per
+                   # rank), and the track ids of the whole clip after short-track removal (every rank holds the same)
+                   "rccl_ranks_seen": (getattr(model, "_last_gathered_frames", None) or FRAMES_PER_GPU) // FRAMES_PER_GPU
+                   if world > 1 else 1,
+                   "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                   "track_ids_per_frame": [r["instances"].track_ids.cpu().tolist() if len(r["instances"]) else []
+                                           for r in res]},
         # The dominant kernel = the 128x128 tile kernel, EVERY launch of it in the step.  Its launches' mean intensity (algorithmic
         # FLOP per algorithmic byte, fp32 in / fp32 out) is below the chip's balance point, so the roof that bounds it is HBM:
         # `bound` / `achieved` / `peak` / `frac` are that view, `mfma_view` the other (the round-1 figure, 0.27, was this one on

@@ -355,7 +355,20 @@ __global__ __launch_bounds__(256) void copy_words_kernel(const unsigned* __restr
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i];
 }
+__global__ __launch_bounds__(256) void flag_nonfinite_kernel(const float* __restrict__ x, long n, int* __restrict__ flag) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) bad |= !(fabsf(x[i]) <= 3.4e38f);
+    if (bad) atomicOr(flag, 1);
+}
 }  // namespace
+
+extern "C" int gom_flag_nonfinite_f32(const float* x, long n, int* flag, void* stream) {
+    GOM_CHECK_ARG(flag && n >= 0 && (x || n == 0));
+    if (n == 0) return GOM_OK;
+    const long blocks = cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048;
+    hipLaunchKernelGGL(flag_nonfinite_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, flag);
+    return gom_launch_status();
+}
 
 extern "C" int gom_copy_words(const void* src, void* dst, long n_words, void* stream) {
     GOM_CHECK_ARG(src && dst && n_words >= 0);

@@ -341,6 +341,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const Args p) {
                 const int m = m0 + wr * WM + i * 32 + row;
                 f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ES + c4);
                 v = v * sc + sh + rv[t];
+                // range check on the PRE-activation value: fmaxf(NaN, 0) = 0 would hide the Inf - Inf of an operand beyond fp16
+                const bool bad_v = !(fabsf(v[0]) <= 3.4e38f) | !(fabsf(v[1]) <= 3.4e38f) | !(fabsf(v[2]) <= 3.4e38f) |
+                                   !(fabsf(v[3]) <= 3.4e38f);
                 if (p.relu == 2) {                           // exact GELU (Swin MLP, swin_transformer.py:36-38)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
@@ -349,8 +352,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const Args p) {
                     v[2] = fmaxf(v[2], relu_lo); v[3] = fmaxf(v[3], relu_lo);
                 }
                 if (n_ok && m < p.M) {
-                    bad |= !(fabsf(v[0]) <= 3.4e38f) | !(fabsf(v[1]) <= 3.4e38f) | !(fabsf(v[2]) <= 3.4e38f) |
-                           !(fabsf(v[3]) <= 3.4e38f);
+                    bad |= bad_v;
                     *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
                 }
             }
@@ -374,8 +376,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const Args p) {
                 if (n_ok && m < p.M) {
                     float v = acc[i][j][r] * sc + sh;
                     if (use_r) v += p.R[(size_t)(p.r_period > 0 ? m % p.r_period : m) * p.ldr + n];
+                    bad |= !(fabsf(v) <= 3.4e38f);             // before the activation (see above)
                     v = p.relu == 2 ? 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)) : fmaxf(v, relu_lo);
-                    bad |= !(fabsf(v) <= 3.4e38f);
                     p.C[(size_t)m * p.ldc + n] = v;
                 }
             }
@@ -393,9 +395,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Args p, int sp
     for (int s = 0; s < splits; ++s) v += p.partial[(size_t)s * p.M * p.N + i];
     v = v * ((p.scale ? p.scale[n] : 1.f) * (p.wscale ? p.wscale[n] : 1.f)) + (p.shift ? p.shift[n] : 0.f);
     if (p.R && n < p.r_cols) v += p.R[(size_t)(p.r_period > 0 ? m % p.r_period : m) * p.ldr + n];
+    if (!(fabsf(v) <= 3.4e38f) && p.flag) atomicOr(p.flag, 1);   // before the activation: fmaxf(NaN, 0) = 0
     if (p.relu == 1) v = fmaxf(v, 0.f);
     if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-    if (!(fabsf(v) <= 3.4e38f) && p.flag) atomicOr(p.flag, 1);
     p.C[(size_t)m * p.ldc + n] = v;
 }
 

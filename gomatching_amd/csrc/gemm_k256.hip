@@ -250,8 +250,9 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = fmaxf(fmaf(acc[4 * q + e], sc[e], bi[e]) + rv[q][e], lo);
-                        bad |= !(fabsf(v[e]) <= 3.4e38f);
+                        const float t = fmaf(acc[4 * q + e], sc[e], bi[e]) + rv[q][e];
+                        bad |= !(fabsf(t) <= 3.4e38f);         // before the ReLU: fmaxf(NaN, 0) = 0 would hide it
+                        v[e] = fmaxf(t, lo);
                     }
                     *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + CW * c + 8 * q + 4 * fh) = v;
                 }
@@ -271,8 +272,9 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = fmaxf(fmaf(acc[r], sc, bi) + rv[r], lo);
-                    bad |= !(fabsf(v) <= 3.4e38f);
+                    const float t = fmaf(acc[r], sc, bi) + rv[r];
+                    bad |= !(fabsf(t) <= 3.4e38f);             // before the ReLU: fmaxf(NaN, 0) = 0 would hide it
+                    const float v = fmaxf(t, lo);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c, (int)(voff + c_lane + ((r & 3) + 8 * (r >> 2)) * c_row), 0, 0);
                 }
                 // the sixteen stores may stay in flight; everything older has landed

@@ -122,5 +122,6 @@ def exchange_and_track(model, dets, batch_id, id_count, instances, time_cost, gr
     hw = dets[0].image_size
     rec = pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, model.device)
     allrec = all_gather_records(rec, group)
+    model._last_gathered_frames = int(allrec.shape[0])         # bench.py reports the ranks seen in the gathered buffer
     all_dets = unpack_records(allrec, hw, model.roi_heads.feature_dim, T.NUM_POINTS)
     return model.track_frames(all_dets, batch_id, id_count, instances, time_cost)

@@ -75,6 +75,7 @@ SIGNATURES = {
     "gom_encoder_reference_points": (I, [P, P, I, P, L, P]),
     "gom_bezier_reference_points": (I, [P, P, P, P, I, P, P, I, L, I, I, I, P]),
     "gom_scale_xy_f32": (I, [P, L, F, F, P]),
+    "gom_flag_nonfinite_f32": (I, [P, L, P, P]),
     "gom_add_f32": (I, [P, P, P, L, P]),
     "gom_copy_words": (I, [P, P, L, P]),
     "gom_broadcast_rows_f32": (I, [P, P, L, I, P]),

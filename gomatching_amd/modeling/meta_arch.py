@@ -71,21 +71,43 @@ class GoMatching:
 
         sd = normalize_state_dict(state_dict)
         self._head_state = {k: v for k, v in sd.items() if k.startswith("roi_heads.")}
-        if cfg.MODEL.BACKBONE.NAME == "build_swin_backbone":
-            if cfg.MODEL.SWIN.TYPE != "tiny":
-                raise NotImplementedError("only Swin-T is built (detection_transformer_wobackbone.py:61-64)")
-            self.backbone = SwinTiny(sd, self.device)
-        elif cfg.MODEL.BACKBONE.NAME == "build_vitaev2_backbone":
-            if cfg.MODEL.ViTAEv2.TYPE != "vitaev2_s":
-                raise NotImplementedError("only vitaev2_s exists (detection_transformer_wobackbone.py:64-68)")
-            self.backbone = ViTAEv2S(sd, self.device)
-        else:
-            self.backbone = ResNet50(sd, self.device)
+        # Precision fallback (the reference runs whatever a checkpoint holds, gom_lstmatcher.py:268-351): the f16x3 kernels raise
+        # a device flag when an activation leaves fp16's range; `detect_finish` then re-runs that step on a bf16x6 twin of the
+        # detector (fp32's exponent range; weights split lazily, once, from the retained state dict), warns and continues.
+        self.gemm_mode = ops.GEMM_MODE
+        self.precision_fallback = True
+        self.fallback_steps = 0                                  # steps re-run on the bf16x6 twin so far
+        self._sd = {k: v for k, v in sd.items() if not k.startswith("roi_heads.")}
+        self._fallback_det = None
+        self.backbone, self.detection_transformer = self._build_detector(self._sd)
         self.feature_names = self.backbone.out_features
-        self.detection_transformer = DeepSolo(cfg, sd, self.device)
         self.roi_heads = build_roi_heads(cfg, sd, self.device)
         self._pool = None
         self._pool_used = 0
+
+    def _build_detector(self, sd):
+        """(backbone, DeepSolo) under the current contraction back-end (ops.GEMM_MODE)."""
+        cfg = self.cfg
+        if cfg.MODEL.BACKBONE.NAME == "build_swin_backbone":
+            if cfg.MODEL.SWIN.TYPE != "tiny":
+                raise NotImplementedError("only Swin-T is built (detection_transformer_wobackbone.py:61-64)")
+            backbone = SwinTiny(sd, self.device)
+        elif cfg.MODEL.BACKBONE.NAME == "build_vitaev2_backbone":
+            if cfg.MODEL.ViTAEv2.TYPE != "vitaev2_s":
+                raise NotImplementedError("only vitaev2_s exists (detection_transformer_wobackbone.py:64-68)")
+            backbone = ViTAEv2S(sd, self.device)
+        else:
+            backbone = ResNet50(sd, self.device)
+        return backbone, DeepSolo(cfg, sd, self.device)
+
+    def add_class_bias(self, shift):
+        """Shift the detector's point-class bias (bench / test calibration of random-init weights) on the live detector, in the
+        retained state dict and on the fallback twin, so that all of them keep holding the same weights."""
+        self.detection_transformer.ctrl_class[1].add_(shift)
+        for k in [k for k in self._sd if k.startswith("detection_transformer.ctrl_point_class.") and k.endswith(".bias")]:
+            self._sd[k] = self._sd[k] + shift
+        if self._fallback_det is not None:
+            self._fallback_det[1].ctrl_class[1].add_(shift)
 
     @classmethod
     def from_config(cls, cfg, state_dict, **kw):
@@ -209,7 +231,7 @@ class GoMatching:
         """Detection + re-id embedding for a step of frames (gom_lstmatcher.py:268-351), batched."""
         return self.detect_finish(self.detect_launch(batched_inputs, time_cost), time_cost)
 
-    def _detect_core(self, raw, kind, time_cost):
+    def _detect_core(self, raw, kind, time_cost, detector=None, flag=None):
         """Every detector kernel of a step, queued on the current stream: no host sync, no host<->device copy, shapes
         fixed by (B, input kind) -- which is what lets `_detect_graphed` capture it."""
         sync = torch.cuda.synchronize if time_cost.get("_sync") else (lambda: None)
@@ -221,10 +243,16 @@ class GoMatching:
         # no batch padding: the reference hands `ImageList.from_tensors(images)` (gom_lstmatcher.py:169, no
         # size_divisibility) to the backbone, and Swin pads inside its own blocks (swin_transformer.py:251-253, :320,
         # :477-479) -- so do csrc/swin.hip's patchify / window / merge kernels
-        feats = self.backbone.forward(x)
+        backbone, transformer = detector if detector is not None else (self.backbone, self.detection_transformer)
+        feats = backbone.forward(x)
         sync(); time_cost["backbone"] += time.time() - t0
         t0 = time.time()
-        out = self.detection_transformer.forward([feats[k] for k in self.feature_names])
+        out = transformer.forward([feats[k] for k in self.feature_names])
+        if ops.GEMM_MODE != "f16x3":
+            # the bf16x6 / exact-fp32 GEMM kernels carry no range flag: check the head outputs (a non-finite activation anywhere
+            # upstream reaches them through the last layer's products) -- `detect_finish` raises instead of returning garbage
+            for name in ("pred_logits", "pred_text_logits", "pred_ctrl_points", "pred_bd_points"):
+                ops.flag_nonfinite(out[name], flag if flag is not None else ops.range_flag(self.device))
         sync(); time_cost["detector"] += time.time() - t0
         re = None
         if self.with_rescore:
@@ -316,10 +344,41 @@ class GoMatching:
             hw = kind[1]
         host = torch.empty((det["small"].numel() + 1,), dtype=torch.int32, pin_memory=True)
         host[:-1].copy_(det["small"], non_blocking=True)
-        host[-1:].copy_(ops.range_flag(self.device), non_blocking=True)   # f16x3 kernels: "a result was not finite"
+        flag = ops.range_flag(self.device)
+        host[-1:].copy_(flag, non_blocking=True)                 # f16x3 kernels: "a result was not finite"
+        flag.zero_()                                             # in stream order: the next step starts with a clean flag
         ev = torch.cuda.Event()
         ev.record()
-        return {"query_features": qf, "det": det, "host": host, "event": ev, "B": B, "hw": hw}
+        return {"query_features": qf, "det": det, "host": host, "event": ev, "B": B, "hw": hw, "inputs": batched_inputs}
+
+    def _fallback_detect(self, h, time_cost):
+        """Re-run the detector of step `h` on the bf16x6 twin (eagerly, on the current stream) and put its results in the
+        handle.  The twin is what a model built under ops.GEMM_MODE = "bf16x6" holds, so the step's results are those of a
+        pure-bf16x6 run (tests/test_model_gpu.py)."""
+        import warnings
+        warnings.warn("gomatching_amd: an activation left fp16's range (|x| > 65504) under the f16x3 back-end; this step is "
+                      "re-run on the bf16x6 kernels (fp32's exponent range, ~1.6x slower).  Build the model under "
+                      "ops.GEMM_MODE = 'bf16x6' if this checkpoint does it on every step.")
+        with ops.gemm_mode("bf16x6"):
+            if self._fallback_det is None:
+                self._fallback_det = self._build_detector(self._sd)
+            raw, kind = self._raw_input(h["inputs"])
+            tc = {k: 0.0 for k in time_cost if k != "_sync"}
+            # a flag word of the twin's own: the next step's f16x3 detector may be running (and flagging) on the other stream
+            if getattr(self, "_fb_flag", None) is None:
+                self._fb_flag = torch.zeros((1,), dtype=torch.int32, device=self.device)
+            flag = self._fb_flag
+            flag.zero_()
+            qf, det = self._detect_core(raw, kind, tc, detector=self._fallback_det, flag=flag)
+        host = torch.empty((det["small"].numel() + 1,), dtype=torch.int32, pin_memory=True)
+        host[:-1].copy_(det["small"], non_blocking=True)
+        host[-1:].copy_(flag, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        self.fallback_steps += 1
+        h.update(query_features=qf, det=det, host=host, hw=kind[1])
+        if int(host[-1]) != 0:
+            raise ops._lib_mod.GomError("the detector produced a non-finite value under the bf16x6 back-end as well: the input "
+                                        "or the weights are not finite, or an activation overflowed fp32")
 
     def detect_finish(self, h, time_cost):
         """Second half: wait for the step's event (the one host sync of the step), embed the kept detections
@@ -334,10 +393,20 @@ class GoMatching:
         h["event"].synchronize()
         for tns in (h["query_features"], det["small"], det["ctrl"], det["bd"], det["recs"]):
             tns.record_stream(cur)
-        small = h["host"].numpy()
-        if small[-1] != 0:                                       # never a silent wrong result (gemm_f16x3.hip)
-            ops.check_range_flag(self.device)
-        small = small[:-1]
+        if h["host"][-1] != 0:                                   # never a silent wrong result (gemm_f16x3.hip)
+            if self.gemm_mode == "f16x3" and self.precision_fallback and h.get("inputs") is not None:
+                self._fallback_detect(h, time_cost)
+                det = h["det"]
+                for tns in (h["query_features"], det["small"], det["ctrl"], det["bd"], det["recs"]):
+                    tns.record_stream(cur)
+            elif self.gemm_mode == "f16x3":
+                raise ops._lib_mod.GomError("f16x3 GEMM produced a non-finite value: an activation left fp16's range "
+                                            "(|x| > 65504) or the input was not finite; set precision_fallback or build the "
+                                            "model under ops.GEMM_MODE = 'bf16x6'")
+            else:
+                raise ops._lib_mod.GomError("the detector produced a non-finite value (%s back-end): the input or the weights "
+                                            "are not finite, or an activation overflowed fp32" % self.gemm_mode)
+        small = h["host"].numpy()[:-1]
         o1, o2, o3 = det["small_layout"]
         counts = small[:o1]
         keep = small[o1:o2].reshape(B, nq)

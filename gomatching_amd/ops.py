@@ -127,6 +127,27 @@ def check_range_flag(device):
                                 "or the input was not finite; run with ops.GEMM_MODE = 'bf16x6'")
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def gemm_mode(mode):
+    """Run a block (model construction and / or a forward pass) under another contraction back-end; the model's precision
+    fallback builds and runs its bf16x6 twin of the detector this way (GoMatching._fallback_detect)."""
+    global GEMM_MODE
+    old, GEMM_MODE = GEMM_MODE, mode
+    try:
+        yield
+    finally:
+        GEMM_MODE = old
+
+
+def flag_nonfinite(x, flag):
+    """flag |= 1 on the device when x holds an Inf / NaN (result check of the back-ends whose GEMMs carry no range flag)."""
+    _chk_f32(x)
+    check(_L().gom_flag_nonfinite_f32(_p(x), x.numel(), _p(flag), _stream()), "gom_flag_nonfinite_f32")
+
+
 def prep_weight(w, min_n=33):
     """Weight preparation policy for the detector's nn.Linear weights."""
     if GEMM_MODE in ("bf16x6", "f16x3") and w.shape[0] >= min_n:

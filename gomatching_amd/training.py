@@ -399,19 +399,28 @@ def loss_res(params, cfg, query_features, pred_ctrl_points, targets, prefix="roi
 def allreduce_gradients(parameters, group=None):
     """Data-parallel training of the head (train_net.py runs under DistributedDataParallel): ONE all-reduce (RCCL over xGMI with
     backend "nccl"; gloo in the CPU test) of all gradients flattened into one bucket, averaged over the ranks.  The head has
-    12-33 M parameters (47-131 MB): one bucket is latency-optimal on the point-to-point xGMI ring."""
+    12-33 M parameters (47-131 MB): one bucket is latency-optimal on the point-to-point xGMI ring.
+    The bucket is RANK-INVARIANT: every parameter with `requires_grad`, in the order given, zeros where this rank has no
+    gradient (a clip without ground-truth ids returns the zero loss, a clip whose short-term matcher had no rows leaves that
+    matcher's parameters without one -- on that rank only); the averaged gradient is written back to every one of them, as
+    DistributedDataParallel does.  No rank ever skips the collective."""
     torch = _torch()
     import torch.distributed as dist
-    params = [p for p in parameters if p.grad is not None]
-    if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    params = [p for p in parameters if p.requires_grad]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    if not params:
+        return 0                                                 # rank-invariant: `requires_grad` is a property of the model
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat /= dist.get_world_size(group)
     o = 0
     for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        n = p.numel()
+        if p.grad is None:
+            p.grad = flat[o:o + n].view_as(p).clone()
+        else:
+            p.grad.copy_(flat[o:o + n].view_as(p.grad))
         o += n
     return flat.numel()
 

@@ -261,6 +261,9 @@ int gom_bezier_reference_points(const float* coord_raw, const int* topk_idx, con
 /* A18: in-place (x, y) pair scaling, detector_postprocess gom_lstmatcher.py:100-109. */
 int gom_scale_xy_f32(float* x, long n_pairs, float sx, float sy, void* stream);
 int gom_add_f32(const float* a, const float* b, float* out, long n, void* stream);
+/* *flag |= 1 when any of x[0..n) is Inf / NaN: the result check of the bf16x6 / exact-fp32 back-ends, whose GEMM kernels carry
+ * no range flag (the reference lets a non-finite activation flow on silently, gom_lstmatcher.py:268-351; here it raises). */
+int gom_flag_nonfinite_f32(const float* x, long n, int* flag, void* stream);
 /* dst[i] = src[i] over 32-bit words, as a kernel; src may be pinned host memory (device-mapped). */
 int gom_copy_words(const void* src, void* dst, long n_words, void* stream);
 int gom_broadcast_rows_f32(const float* src, float* out, long n, int B, void* stream);

@@ -83,13 +83,21 @@ def _grad_worker(rank, world, port, q):
         from gomatching_amd.training import allreduce_gradients
         g = torch.Generator().manual_seed(7)
         params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in ((5, 3), (7,), (2, 2, 2))]
-        frozen = torch.nn.Parameter(torch.randn(4, generator=g))                     # no gradient: left alone
+        frozen = torch.nn.Parameter(torch.randn(4, generator=g), requires_grad=False)   # frozen: left alone
+        # gradients that exist on ONE rank only (a clip without ground-truth ids, a short-term matcher without rows): the
+        # bucket must be the same on every rank, the missing gradient counting as zero
+        only0 = torch.nn.Parameter(torch.randn(6, generator=g))
+        nowhere = torch.nn.Parameter(torch.randn(3, generator=g))
         for i, p in enumerate(params):
             p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
-        n = allreduce_gradients(params + [frozen])
-        ok = n == sum(p.numel() for p in params) and frozen.grad is None
+        if rank == 0:
+            only0.grad = torch.full_like(only0, 8.0)
+        n = allreduce_gradients([params[0], frozen, only0] + params[1:] + [nowhere])
+        ok = n == sum(p.numel() for p in params) + 6 + 3 and frozen.grad is None
         for i, p in enumerate(params):
             ok &= bool(torch.allclose(p.grad, torch.full_like(p, (1 + 2) / 2 * (i + 1))))
+        ok &= only0.grad is not None and bool(torch.allclose(only0.grad, torch.full_like(only0, 4.0)))
+        ok &= nowhere.grad is not None and float(nowhere.grad.abs().max()) == 0.0
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

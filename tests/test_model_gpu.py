@@ -565,3 +565,51 @@ def test_hoisted_match_projections_change_nothing(builtin):
 
     a, b = run(True), run(False)
     assert a == b and max(max(f, default=0) for f in a[0]) > 5
+
+
+def test_precision_fallback_equals_pure_bf16x6():
+    """A checkpoint whose activations leave fp16's range (here: res2.0.conv1's FrozenBN scaled by 2^18 and conv2's weight by
+    2^-18 -- the same function, but the 3x3 convolution's A operand is beyond 65504, which used to be silently ZEROED behind
+    its ReLU) must not raise and must not differ from a pure-bf16x6 run: every step whose range flag is up is re-run on the
+    bf16x6 twin of the detector (eager step, captured step and replayed step alike); without the fallback it raises."""
+    import warnings
+    from gomatching_amd import ops
+    from gomatching_amd.lib import GomError
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.synth import make_clip
+    g = golden("e2e_lst.npz")
+    cfg = mini_cfg("icdar15", device=DEV)
+    sd = dict(e2e_state_dict(cfg, g))
+    c = float(2 ** 18)
+    p = "backbone.0.backbone.res2.0."
+    sd[p + "conv1.norm.weight"], sd[p + "conv1.norm.bias"] = sd[p + "conv1.norm.weight"] * c, sd[p + "conv1.norm.bias"] * c
+    sd[p + "conv2.weight"] = sd[p + "conv2.weight"] / c
+    hw = tuple(int(v) for v in g["hw"])
+    clip = make_clip(8, hw[0], hw[1], clip_id=1)
+    inputs = [{"image": torch.as_tensor(f.astype("float32").transpose(2, 0, 1))} for f in clip]
+    assert ops.GEMM_MODE == "f16x3"
+    with ops.gemm_mode("bf16x6"):
+        pure = GoMatching(cfg, sd, device=DEV, frames_per_step=4)
+        ref, ref_idc = pure.batch_inference(inputs, 0, 0, [], _time_cost())
+        assert pure.fallback_steps == 0
+    assert sum(len(x) for x in ref) > 0
+    assert [x.track_ids.cpu().tolist() for x in ref] == [g["pre_ids_%d" % f].tolist() for f in range(8)]   # power-of-two scaling
+    model = GoMatching(cfg, sd, device=DEV, frames_per_step=4)
+    for rnd in range(3):                                          # eager, capture, replay
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            insts, idc = model.batch_inference(inputs, 0, 0, [], _time_cost())
+        assert any("fp16's range" in str(x.message) for x in w)
+        assert model.fallback_steps == 2 * (rnd + 1)
+        assert int(idc) == int(ref_idc)
+        for a, b in zip(insts, ref):
+            assert torch.equal(a.track_ids, b.track_ids) and torch.equal(a.scores, b.scores)
+            assert torch.equal(a.recs, b.recs) and torch.equal(a.bd, b.bd) and torch.equal(a.ctrl_points, b.ctrl_points)
+            assert torch.equal(a.reid_features, b.reid_features)
+    model.precision_fallback = False
+    with pytest.raises(GomError, match="fp16's range"):
+        model.batch_inference(inputs, 0, 0, [], _time_cost())
+    # in-range weights never take the fallback
+    good = GoMatching(cfg, e2e_state_dict(cfg, g), device=DEV, frames_per_step=4)
+    good.batch_inference(inputs, 0, 0, [], _time_cost())
+    assert good.fallback_steps == 0 and good._fallback_det is None

@@ -128,6 +128,52 @@ def test_gemm_split_epilogue_gather_and_extremes(kind):
         ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
 
 
+def test_f16x3_range_flag_is_raised_in_front_of_every_relu():
+    """An activation beyond fp16's range splits into (Inf, -Inf) planes whose products sum to NaN, and fmaxf(NaN, 0) = 0: every
+    f16x3 epilogue with a ReLU checks the PRE-activation value, so such a result is flagged, never silently zeroed -- the tile
+    kernel's 16-byte and scalar epilogues, the split-K reduction, implicit-GEMM convolutions, the row-resident K = 256 kernel
+    (both store forms)."""
+    ops = _ops()
+    from gomatching_amd import lib
+    dev = torch.device(DEV, torch.cuda.current_device())
+    K = 256
+
+    def expect_flag(what):
+        with pytest.raises(Exception, match="fp16's range"):
+            ops.check_range_flag(dev)
+        ops.check_range_flag(dev)                              # ... and the check re-arms the flag
+
+    ops.check_range_flag(dev)
+    big = torch.full((200, K), 7e4, device=DEV)
+    for N in (64, 256, 66):                                    # N = 66: the scalar epilogue (N % 4 != 0)
+        sw = ops.split_weight(torch.ones(N, K, device=DEV), kind="f16x3")
+        out = ops.gemm(big, sw, relu=True)
+        assert not bool(torch.isfinite(out).all()) or float(out.abs().max()) == 0.0   # what the hole looked like: all zeros
+        expect_flag("gemm N=%d" % N)
+        ops.gemm(torch.ones((200, K), device=DEV), sw, relu=True)
+        ops.check_range_flag(dev)                              # in-range operands under the same epilogue: no flag
+    # convolutions: 1x1 (the pointwise form of the tile kernel), 3x3, and the split-K 3x3 / 2 of input_proj[3]
+    for Cin, Cout, k, stride, pad, H, W in ((64, 256, 1, 1, 0, 12, 20), (64, 64, 3, 1, 1, 12, 20), (2048, 256, 3, 2, 1, 8, 12)):
+        x = torch.ones((2, H, W, Cin), device=DEV)
+        w = torch.ones((Cout, k, k, Cin), device=DEV) / (Cin * k * k)
+        sw = ops.split_weight(w.reshape(Cout, -1), conv_shape=tuple(w.shape), kind="f16x3")
+        ops.conv2d_nhwc(x, sw, relu=True, stride=stride, pad=pad)
+        ops.check_range_flag(dev)
+        x[1, H // 2, W // 2, 3] = 7e4
+        ops.conv2d_nhwc(x, sw, relu=True, stride=stride, pad=pad)
+        expect_flag("conv %dx%d" % (k, k))
+    # the row-resident kernel, 16-byte-store and whole-line-store forms
+    W = torch.ones((64, K), device=DEV)
+    lin = ops.K256Linear(ops.split_weight(W, kind="f16x3"), None)
+    try:
+        for lines in (0, 1):
+            lib.load().gom_gemm_k256_set_lines(lines)
+            ops.linear(big, lin, groups=1, relu=True)
+            expect_flag("k256 lines=%d" % lines)
+    finally:
+        lib.load().gom_gemm_k256_set_lines(-1)
+
+
 def test_gemm_epilogue_and_gather():
     ops = _ops()
     g = torch.Generator().manual_seed(3)
