@@ -402,6 +402,8 @@ def test_detector_graph_replay_equals_eager_and_is_bounded():
             got = model.inference(clips[hw], _time_cost())
             for a, b in zip(got, ref[hw]):
                 assert torch.equal(a.scores, b.scores) and torch.equal(a.bd, b.bd) and torch.equal(a.recs, b.recs)
+                assert a.has("reid_features") == b.has("reid_features")
+            if a.has("reid_features"):
                 assert torch.equal(a.reid_features, b.reid_features)
     assert model.use_graphs                                          # capture did not fall back
     assert sum(isinstance(v, dict) for v in model._graphs.values()) <= model.max_graphs
@@ -605,7 +607,9 @@ def test_precision_fallback_equals_pure_bf16x6():
         for a, b in zip(insts, ref):
             assert torch.equal(a.track_ids, b.track_ids) and torch.equal(a.scores, b.scores)
             assert torch.equal(a.recs, b.recs) and torch.equal(a.bd, b.bd) and torch.equal(a.ctrl_points, b.ctrl_points)
-            assert torch.equal(a.reid_features, b.reid_features)
+            assert a.has("reid_features") == b.has("reid_features")
+            if a.has("reid_features"):
+                assert torch.equal(a.reid_features, b.reid_features)
     model.precision_fallback = False
     with pytest.raises(GomError, match="fp16's range"):
         model.batch_inference(inputs, 0, 0, [], _time_cost())

@@ -135,3 +135,25 @@ def test_end_to_end_mini_clip(builtin, tag):
         assert r["recs"].tolist() == g["recs_%d" % f].tolist()
         for k in ("scores", "bd", "ctrl_points", "pred_boxes"):
             np.testing.assert_allclose(r[k].numpy(), g["%s_%d" % (k, f)], atol=1e-3, rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["c1", "c2"])
+def test_oracle_vs_reference_full_size(name):
+    """the oracle against the reference's OWN DeepSolo module at full size -- C1 640x640 (S = 8 500) and C2
+    1000x1778 (S = 37 171), 100 queries -- where the proposal stage's top-k runs over tens of thousands of near-tied class
+    logits (deformable_transformer.py:183-199).  Fixture: oracle/gen_golden_full.py."""
+    from full_fixture import case, compare
+    g, cfg, sd, image = case(name)
+    T = cfg.MODEL.TRANSFORMER
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+    std = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+    with torch.no_grad():
+        feats = O.resnet50(((image - mean) / std)[None], sd)
+        feats = [feats[k] for k in ("res3", "res4", "res5")]
+        masks = [torch.zeros(1, f.shape[2], f.shape[3], dtype=torch.bool) for f in feats]
+        taps = {}
+        out = O.deepsolo_forward(sd, cfg, feats, masks, [O.pos_encoding_2d(m, T.HIDDEN_DIM // 2, T.TEMPERATURE) for m in masks],
+                                 taps=taps)
+    assert int(g["S"][0]) == taps["memory"].shape[1]
+    err, moved = compare(g, out, taps["topk"].reshape(-1), T.NUM_QUERIES, T.NUM_POINTS, tol=2e-5, what="oracle " + name)
+    assert moved == 0
