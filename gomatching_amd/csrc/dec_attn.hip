@@ -1,0 +1,649 @@
+// The two self-attention blocks of a DeepSolo composite decoder layer, each as ONE launch (f16x3 split, fp32-class accuracy):
+//
+//   intra:  tgt = norm_intra(tgt + out_proj(MHA(q = k = tgt + query_pos, v = tgt)))   over the 25 points of one query
+//   inter:  tgt = norm_inter(tgt + out_proj(MHA(q = k = v = tgt)))                    over the nq queries of one (frame, point)
+//
+// (/root/reference/third_party/adet/layers/deformable_transformer.py:386-404; nn.MultiheadAttention, 8 heads of 32, eval mode).
+// Both are LOCAL problems -- 25 x 256 resp. nq x 256 tokens -- that used to run as five launches through HBM each (q|k
+// projection, v projection, attention core, out_proj + LayerNorm; 140 + 200 us per layer at 8 x 100 x 25 rows, the Q-side
+// products at 0.15 of the f16x3 MFMA peak).  Here a token never leaves its lane between the first load and the final store:
+//
+//   * a wave owns up to 32 tokens of ONE attention group (intra: the 25 points of a query; inter: a quarter of the queries of
+//     a (frame, point)) as MFMA operand fragments in 128 VGPRs, as in gemm_k256.hip / ffn_fused.hip; a workgroup = 4 waves =
+//     four intra groups or one inter group; one wave per SIMD with the whole register file;
+//   * the in-projection weights stream through a two-stage LDS ring by MUBUF LDS-DMA from a fragment-linear image, one 33 KB
+//     stage per (head, q | k | v): q and k are computed TRANSPOSED (lane = token, registers = the head's 32 features), v STRAIGHT
+//     (lane = feature, registers = tokens) -- which are exactly the operand layouts the attention products want:
+//         S^T[key, query] = K . Q^T     A = K accumulators (lane = key), B = Q accumulators (lane = query); the k index runs
+//                                       over the head's features in ACCUMULATOR order, the same permutation on both sides
+//         O^T[d,  query]  = V^T . P^T   A = V accumulators (lane = d, registers = keys), B = P straight from S^T's registers
+//     after an fp16 two-plane split of the registers -- no shuffle, no LDS round trip (the fused FFN kernel's trick); softmax
+//     statistics are per-lane scalars + one exchange between the half-waves;
+//   * inter: the four waves exchange the K and V^T fragments of a head through 32 KB of LDS (written once, read by all);
+//   * O^T (lane = token) is the B operand of out_proj, whose weights follow in eight k-major stages whose k order is the
+//     accumulator order of O^T (baked into the image); Y^T's statistics are in-lane sums, so residual + LayerNorm finish in
+//     registers and every lane stores its token's 16-byte pieces.
+// Plane products in the tile kernel's order (x-lo w-hi, x-hi w-lo, x-hi w-hi per 16-wide k-step); activations must stay within
+// fp16's range (|x| <= 65504: q, k, v and the inputs are checked, *flag is raised otherwise -- gemm_f16x3.hip's contract).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int D = 256, NH = 8;                           // model width, heads (head dim 32 = one 32-column chunk)
+constexpr int FRAG = 1024;                               // bytes of one MFMA operand fragment
+constexpr int W_FRAGS = 32;                              // weight fragments of a stage
+constexpr int CHUNK_FRAGS = W_FRAGS + 4;                 // + (1 / row scale | bias) of the chunk's 32 columns + 3 unused: 9 per wave
+constexpr int CHUNK_BYTES = CHUNK_FRAGS * FRAG;          // 36 KB
+constexpr int STAGES = 3 * NH + NH;                      // 24 projection chunks + 8 out_proj stages
+constexpr int SLOTS = 3;                                 // ring depth: stage i + 2 is requested while stage i computes
+constexpr int RING_BYTES = SLOTS * CHUNK_BYTES;
+constexpr int WS_WAVE_BYTES = NH * 4 * FRAG;             // intra: a wave's V^T fragments of every head, parked in global memory
+constexpr int XCH_BYTES = 4 * 8 * FRAG;                  // inter: K (4) + V^T (4) fragments of each of the four waves, one head
+constexpr int IMAGE_BYTES = STAGES * CHUNK_BYTES;
+
+struct DecArgs {
+    const float* X;                                          // tgt [rows, 256]
+    const float* P;                                          // query_pos (intra) or null
+    const unsigned char* img;
+    const float* inv_o;                                      // out_proj: 1 / row scale of the split weight, bias
+    const float* bias_o;
+    const float* gamma;
+    const float* beta;
+    float* Y;
+    unsigned char* ws;                                       // intra: WS_WAVE_BYTES per wave of the launch
+    int* flag;
+    float eps, scale;
+    int ldx, ldp, ldy;
+    int groups;                                              // attention groups of the launch
+    int G;                                                   // tokens per group
+    int per_wave;                                            // inter: tokens of a group per wave = ceil(G / 4)
+    int inner;                                               // inter: rows between consecutive tokens of a group (= points)
+};
+
+__device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) {
+    const f32x2 v = {x, y};
+    const half2_t h0 = __builtin_convertvector(v, half2_t);
+    const f32x2 b = __builtin_convertvector(h0, f32x2);
+    const f32x2 r = {x - b[0], y - b[1]};
+    const half2_t h1 = __builtin_convertvector(r, half2_t);
+    q0 = __builtin_bit_cast(unsigned int, h0);
+    q1 = __builtin_bit_cast(unsigned int, h1);
+}
+
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8& p0, half8& p1) {
+    unsigned int l0, l1, l2, l3, h0, h1, h2, h3;
+    split2(a[0], a[1], l0, h0);
+    split2(a[2], a[3], l1, h1);
+    split2(b[0], b[1], l2, h2);
+    split2(b[2], b[3], l3, h3);
+    p0 = __builtin_bit_cast(half8, (u32x4{l0, l1, l2, l3}));
+    p1 = __builtin_bit_cast(half8, (u32x4{h0, h1, h2, h3}));
+}
+
+__device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned byte_offset, unsigned char* lds_frag) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)byte_offset, 0, 0, 0);
+}
+
+// registers 8 s .. 8 s + 7 of a 32x32 accumulator -> the two planes of k-step s of an operand fragment
+__device__ __forceinline__ void acc_to_frags(const f32x16& a, half8 (&f)[2][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        split8(f32x4{a[8 * s], a[8 * s + 1], a[8 * s + 2], a[8 * s + 3]},
+               f32x4{a[8 * s + 4], a[8 * s + 5], a[8 * s + 6], a[8 * s + 7]}, f[s][0], f[s][1]);
+}
+
+// C (+)= A . B on the f16x3 planes: a / b = [k-step][plane hi, lo]
+__device__ __forceinline__ f32x16 mfma_x3(const half8 a_hi, const half8 a_lo, const half8 b_hi, const half8 b_lo, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, c, 0, 0, 0);
+    return c;
+}
+
+// one weight stage: 32 fragments in four groups of eight, group g + 1 read while the MFMAs of group g issue (two-deep register
+// pipeline pinned with sched_group_barrier); the next stage's fragments of this wave are requested one per four MFMAs
+#define DA_LOAD(dst, g)                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                          \
+        dst[i_] = *reinterpret_cast<const half8*>(base + ((g) * 8 + i_) * FRAG);
+#define DA_DMA(i) dma_fragment(rs_img, nsrc + (i) * 4 * FRAG, ndst + (i) * 4 * FRAG);
+#define DA_PIN3()                                         \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+#define DA_PIN2()                                         \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#define DA_STAGE(MFMA)                                                                                        \
+    {                                                                                                         \
+        half8 fa[8], fb[8];                                                                                   \
+        DA_LOAD(fa, 0)                                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                                    \
+        DA_LOAD(fb, 1) MFMA(fa, 0) DA_DMA(0) DA_DMA(1) DA_DMA(2) DA_PIN3()                                    \
+        DA_LOAD(fa, 2) MFMA(fb, 1) DA_DMA(3) DA_DMA(4) DA_DMA(5) DA_PIN3()                                    \
+        DA_LOAD(fb, 3) MFMA(fa, 2) DA_DMA(6) DA_DMA(7) DA_DMA(8) DA_PIN3()                                    \
+        MFMA(fb, 3)                                                                                           \
+    }
+
+// projection chunk, transposed: acc[feature][token] += W chunk . X^T  (A = weight fragment, B = the rows in registers)
+#define DA_MFMA_T(src, g)                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+        const int s_ = (g) * 4 + i_;                                                                          \
+        acc = mfma_x3(src[2 * i_], src[2 * i_ + 1], xf[0][s_], xf[1][s_], acc);                               \
+    }
+// projection chunk, straight: acc[token][feature] += X . W chunk^T  (A = the rows in registers, B = weight fragment)
+#define DA_MFMA_S(src, g)                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+        const int s_ = (g) * 4 + i_;                                                                          \
+        acc = mfma_x3(xf[0][s_], xf[1][s_], src[2 * i_], src[2 * i_ + 1], acc);                               \
+    }
+// out_proj stage of head `hh_`: fragments [tile][k-step][plane]; group g = output tiles 2 g, 2 g + 1
+#define DA_MFMA_O(src, g)                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+        const int t_ = 2 * (g) + (i_ >> 1), s_ = i_ & 1;                                                      \
+        yacc[t_] = mfma_x3(src[2 * i_], src[2 * i_ + 1], of[hh_][s_][0], of[hh_][s_][1], yacc[t_]);           \
+    }
+
+template <bool INTER>
+__global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xch = smem + RING_BYTES;                  // inter only
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    constexpr int NB = INTER ? 4 : 1;                        // key blocks (waves) of an attention group
+
+    // ---- which token this lane owns ----
+    long row;
+    bool valid;
+    int ntok[NB];                                            // valid key slots per block
+    if constexpr (!INTER) {
+        const long gi = (long)blockIdx.x * 4 + wave;
+        const long g = gi < p.groups ? gi : p.groups - 1;
+        ntok[0] = p.G;
+        valid = gi < p.groups && fr < p.G;
+        row = g * p.G + (fr < p.G ? fr : 0);
+    } else {
+        const long gi = blockIdx.x;
+        const long b = gi / p.inner, pp = gi % p.inner;
+#pragma unroll
+        for (int w = 0; w < NB; ++w) {
+            const int left = p.G - w * p.per_wave;
+            ntok[w] = left < 0 ? 0 : (left < p.per_wave ? left : p.per_wave);
+        }
+        const int mine = p.G - wave * p.per_wave;
+        valid = fr < p.per_wave && fr < mine;
+        const long tq = valid ? (long)wave * p.per_wave + fr : 0;
+        row = (b * p.G + tq) * p.inner + pp;
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, IMAGE_BYTES, 0x00020000);
+    constexpr unsigned OOB = 0x7FFF0000u;                    // beyond num_records: the DMA writes zeros (into an unused stage)
+    for (int f = wave; f < 2 * CHUNK_FRAGS; f += 4) dma_fragment(rs_img, f * FRAG + lane * 16, smem + f * FRAG);   // stages 0, 1
+
+    // range bookkeeping: a running maximum of |value| over everything that is split into fp16 planes, and a NaN / Inf detector
+    // over the outputs (o * 0 accumulates to NaN for a non-finite o).  NOT `bad |= !(|v| <= limit)` per value: the compiler defers
+    // those compares to the end of the kernel and keeps (spills) every compared value until then -- 1000 registers of scratch.
+    float amax = 0.f, chk = 0.f;
+    half8 xf[2][D / 16];
+    // this wave's rows as operand fragments: lane (r, h) holds x[row r][16 s + 8 h .. + 7], two planes (gemm_k256.hip)
+    auto load_rows = [&](bool with_pos) {
+        const float* xr = p.X + (size_t)row * p.ldx + fh * 8;
+        if (with_pos) {
+            const float* x2 = p.P + (size_t)row * p.ldp + fh * 8;
+            // a quarter's loads must not be requested before the previous quarter is split: the pointers pass through an
+            // empty asm that reads the last split result (sched_barrier alone lets the adds and splits sink below all loads)
+#pragma unroll
+            for (int hk = 0; hk < 4; ++hk) {                 // four quarters of K: 64 raw registers in flight, not 256
+                f32x4 ra[D / 32], rb[D / 32];
+#pragma unroll
+                for (int i = 0; i < D / 64; ++i) {
+                    const int s = hk * (D / 64) + i;
+                    ra[2 * i] = *reinterpret_cast<const f32x4*>(xr + 16 * s);
+                    ra[2 * i + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
+                    rb[2 * i] = *reinterpret_cast<const f32x4*>(x2 + 16 * s);
+                    rb[2 * i + 1] = *reinterpret_cast<const f32x4*>(x2 + 16 * s + 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < D / 64; ++i) {
+                    const int s = hk * (D / 64) + i;
+                    const f32x4 a = ra[2 * i] + rb[2 * i], b = ra[2 * i + 1] + rb[2 * i + 1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(a[e]), fabsf(b[e])));
+                    split8(a, b, xf[0][s], xf[1][s]);
+                }
+                asm volatile("" : "+v"(xr), "+v"(x2), "+v"(amax) : "v"(xf[1][hk * (D / 64) + D / 64 - 1]) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            f32x4 ra[D / 8];
+#pragma unroll
+            for (int s = 0; s < D / 16; ++s) {
+                ra[2 * s] = *reinterpret_cast<const f32x4*>(xr + 16 * s);
+                ra[2 * s + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < D / 16; ++s) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(ra[2 * s][e]), fabsf(ra[2 * s + 1][e])));
+                split8(ra[2 * s], ra[2 * s + 1], xf[0][s], xf[1][s]);
+            }
+            asm volatile("" : "+v"(amax));
+        }
+    };
+    load_rows(false);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // per stage: `base` = this lane's slice of the stage in the ring, `nsrc` / `ndst` = this wave's fragments of the next one
+#define DA_STAGE_VARS(i)                                                                                      \
+    const unsigned char* base = smem + ((i) % SLOTS) * CHUNK_BYTES + lane * 16;                               \
+    const float* aux = reinterpret_cast<const float*>(smem + ((i) % SLOTS) * CHUNK_BYTES + W_FRAGS * FRAG);   \
+    const unsigned nsrc = (i) + 2 < STAGES ? (unsigned)((i) + 2) * CHUNK_BYTES + wave * FRAG + lane * 16 : OOB; \
+    unsigned char* ndst = smem + (((i) + 2) % SLOTS) * CHUNK_BYTES + wave * FRAG;
+    // end of a stage: everything older than this stage's nine requests (= stage i + 1, requested a stage ago) has landed --
+    // loads return in issue order; stages that issue other vector-memory operations behind their requests wait for all
+#define DA_STAGE_END()                                                                                        \
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                                          \
+    __syncthreads();                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#define DA_STAGE_END_ALL()                                                                                    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+    __syncthreads();                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // transposed chunk epilogue: value = acc * (1 / row scale) + bias, features (g & 3) + 8 (g >> 2) + 4 fh of the chunk
+    auto finish_t = [&](f32x16& acc, const float* aux) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(aux + 8 * q + 4 * fh);
+            const f32x4 bi = *reinterpret_cast<const f32x4*>(aux + 32 + 8 * q + 4 * fh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[4 * q + e] = fmaf(acc[4 * q + e], sc[e], bi[e]);
+                amax = fmaxf(amax, fabsf(acc[4 * q + e]));
+            }
+        }
+        asm volatile("" : "+v"(amax));
+    };
+    // straight chunk epilogue: the lane is the feature
+    auto finish_s = [&](f32x16& acc, const float* aux) {
+        const float sc = aux[fr], bi = aux[32 + fr];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            acc[g] = fmaf(acc[g], sc, bi);
+            amax = fmaxf(amax, fabsf(acc[g]));
+        }
+        asm volatile("" : "+v"(amax));
+    };
+
+    half8 of[NH][2][2];                                      // O^T of every head as out_proj's B operand: [head][k-step][plane]
+
+    // softmax(scale * S^T) over the keys of the group (registers of `s` <-> key slot (g & 3) + 8 (g >> 2) + 4 fh of block b),
+    // unnormalised probabilities left in `s`, returns 1 / sum
+    auto softmax_keys = [&](f32x16 (&s)[NB]) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int j = (g & 3) + 8 * (g >> 2) + 4 * fh;
+                s[b][g] = j < ntok[b] ? s[b][g] * p.scale : -INFINITY;
+                mx = fmaxf(mx, s[b][g]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                s[b][g] = expf(s[b][g] - mx);
+                sum += s[b][g];
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        return 1.f / sum;
+    };
+
+    if constexpr (!INTER) {
+        // ---- sweep 1: V of every head (stages 0 .. 7).  Its A-operand fragments (16 registers per head) are PARKED in global
+        // memory, lane-linear, 32 KB per wave (L2-resident), and fetched back a head at a time in sweep 2: with them in registers
+        // beside the rows' fragments and O^T the kernel spilled a thousand registers to scratch (3.2 KB per lane) ----
+        unsigned char* wsw = p.ws + ((size_t)blockIdx.x * 4 + wave) * WS_WAVE_BYTES + lane * 16;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            DA_STAGE_VARS(h)
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+            DA_STAGE(DA_MFMA_S)
+            finish_s(acc, aux);
+            half8 vf[2][2];
+            acc_to_frags(acc, vf);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) *reinterpret_cast<half8*>(wsw + (h * 4 + f) * FRAG) = vf[f >> 1][f & 1];
+            DA_STAGE_END_ALL()
+        }
+        // ---- sweep 2: q | k of (tgt + query_pos) per head (stages 8 + 2 h, 9 + 2 h), attention in registers ----
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(true);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            half8 qf[2][2], kf[2][2], vf[2][2];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) vf[f >> 1][f & 1] = *reinterpret_cast<const half8*>(wsw + (h * 4 + f) * FRAG);
+            {
+                DA_STAGE_VARS(NH + 2 * h)
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+                DA_STAGE(DA_MFMA_T)
+                finish_t(acc, aux);
+                acc_to_frags(acc, qf);
+                DA_STAGE_END()
+            }
+            {
+                DA_STAGE_VARS(NH + 2 * h + 1)
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+                DA_STAGE(DA_MFMA_T)
+                finish_t(acc, aux);
+                acc_to_frags(acc, kf);
+                DA_STAGE_END()
+            }
+            f32x16 s[1];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s[0][g] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) s[0] = mfma_x3(kf[ks][0], kf[ks][1], qf[ks][0], qf[ks][1], s[0]);
+            const float inv = softmax_keys(s);
+            half8 pf[2][2];
+            acc_to_frags(s[0], pf);
+            f32x16 o;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) o[g] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) o = mfma_x3(vf[ks][0], vf[ks][1], pf[ks][0], pf[ks][1], o);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) o[g] *= inv;
+            acc_to_frags(o, of[h]);
+        }
+    } else {
+        // ---- per head: q, k, v of tgt (stages 3 h, 3 h + 1, 3 h + 2); K and V^T fragments shared through LDS ----
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            half8 qf[2][2];
+            {
+                DA_STAGE_VARS(3 * h)
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+                DA_STAGE(DA_MFMA_T)
+                finish_t(acc, aux);
+                acc_to_frags(acc, qf);
+                DA_STAGE_END()
+            }
+            {
+                DA_STAGE_VARS(3 * h + 1)
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+                DA_STAGE(DA_MFMA_T)
+                finish_t(acc, aux);
+                half8 kf[2][2];
+                acc_to_frags(acc, kf);
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    *reinterpret_cast<half8*>(xch + (wave * 8 + f) * FRAG + lane * 16) = kf[f >> 1][f & 1];
+                DA_STAGE_END()
+            }
+            {
+                DA_STAGE_VARS(3 * h + 2)
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+                DA_STAGE(DA_MFMA_S)
+                finish_s(acc, aux);
+                half8 vf[2][2];
+                acc_to_frags(acc, vf);
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    *reinterpret_cast<half8*>(xch + (wave * 8 + 4 + f) * FRAG + lane * 16) = vf[f >> 1][f & 1];
+                DA_STAGE_END()
+            }
+            f32x16 s[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) s[b][g] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const half8 k_hi = *reinterpret_cast<const half8*>(xch + (b * 8 + 2 * ks) * FRAG + lane * 16);
+                    const half8 k_lo = *reinterpret_cast<const half8*>(xch + (b * 8 + 2 * ks + 1) * FRAG + lane * 16);
+                    s[b] = mfma_x3(k_hi, k_lo, qf[ks][0], qf[ks][1], s[b]);
+                }
+            }
+            const float inv = softmax_keys(s);
+            f32x16 o;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) o[g] = 0.f;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                half8 pf[2][2];
+                acc_to_frags(s[b], pf);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const half8 v_hi = *reinterpret_cast<const half8*>(xch + (b * 8 + 4 + 2 * ks) * FRAG + lane * 16);
+                    const half8 v_lo = *reinterpret_cast<const half8*>(xch + (b * 8 + 4 + 2 * ks + 1) * FRAG + lane * 16);
+                    o = mfma_x3(v_hi, v_lo, pf[ks][0], pf[ks][1], o);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) o[g] *= inv;
+            acc_to_frags(o, of[h]);
+        }
+    }
+
+    // ---- out_proj: Y^T[256 x tokens] += Wo[:, head h's features] . O_h^T, eight stages ----
+    f32x16 yacc[D / 32];
+#pragma unroll
+    for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) yacc[t][g] = 0.f;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        constexpr int dummy_ = 0;
+        (void)dummy_;
+        const int hh_ = h;
+        DA_STAGE_VARS(3 * NH + h)
+        (void)aux;
+        DA_STAGE(DA_MFMA_O)
+        DA_STAGE_END()
+    }
+
+    // ---- residual + LayerNorm in registers: lane (token, fh) holds features 32 t + 8 q + 4 fh .. + 3 of its token ----
+    // (one 32-feature tile at a time, fenced: left alone the compiler requests every residual / scale / bias vector of the row
+    // up front -- 384 registers -- and spills the accumulators)
+    {
+        const float* rr = p.X + (size_t)row * p.ldx + 4 * fh;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < D / 32; ++t) {
+            f32x4 r[4], sc[4], bi[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = 32 * t + 8 * q;
+                r[q] = *reinterpret_cast<const f32x4*>(rr + col);
+                sc[q] = *reinterpret_cast<const f32x4*>(p.inv_o + col + 4 * fh);
+                bi[q] = *reinterpret_cast<const f32x4*>(p.bias_o + col + 4 * fh);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaf(yacc[t][4 * q + e], sc[q][e], bi[q][e]) + r[q][e];
+                    yacc[t][4 * q + e] = v;
+                    sum += v;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                yacc[t][g] -= mean;
+                sq += yacc[t][g] * yacc[t][g];
+            }
+        sq += __shfl_xor(sq, 32, 64);
+        const float rstd = rsqrtf(sq * (1.f / D) + p.eps);
+        float* yr = p.Y + (size_t)row * p.ldy + 4 * fh;
+#pragma unroll
+        for (int t = 0; t < D / 32; ++t) {
+            f32x4 ga[4], be[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = 32 * t + 8 * q;
+                ga[q] = *reinterpret_cast<const f32x4*>(p.gamma + col + 4 * fh);
+                be[q] = *reinterpret_cast<const f32x4*>(p.beta + col + 4 * fh);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = yacc[t][4 * q + e] * rstd * ga[q][e] + be[q][e];
+                    chk = fmaf(o[e], 0.f, chk);
+                }
+                if (valid) *reinterpret_cast<f32x4*>(yr + 32 * t + 8 * q) = o;
+            }
+            asm volatile("" : "+v"(chk));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // an operand left fp16's range, or a result is not finite (gemm_f16x3.hip contract; fmaxf drops a NaN, `chk` catches it)
+    if ((!(amax <= 65504.f) || !(chk == 0.f)) && p.flag) atomicOr(p.flag, 1);
+}
+
+#undef DA_LOAD
+#undef DA_DMA
+#undef DA_PIN3
+#undef DA_PIN2
+#undef DA_STAGE
+#undef DA_MFMA_T
+#undef DA_MFMA_S
+#undef DA_MFMA_O
+#undef DA_STAGE_VARS
+#undef DA_STAGE_END
+
+// Fragment-linear image of a block's weights (row-scaled planes of gom_split_f16x2): in_proj W [768, 256] = q | k | v rows,
+// out_proj W [256, 256].  Stage order -- intra: v_0 .. v_7, then (q_h, k_h) for h = 0 .. 7; inter: (q_h, k_h, v_h) for
+// h = 0 .. 7; then the eight out_proj stages.  A projection stage = gemm_k256.hip's chunk of the 32 weight rows of (head, q | k |
+// v): fragment f = 2 s + p: element j of lane (r, h) = plane p of Ws[row0 + r][16 s + 8 h + j]; fragment 32: floats 0..31 =
+// 1 / row scale, 32..63 = bias.  out_proj stage hd: fragment (t * 2 + s) * 2 + p: element j of lane (r, h) = plane p of
+// Wo[32 t + r][32 hd + (j & 3) + 8 (2 s + (j >> 2)) + 4 h] -- O^T's accumulator order of head hd's features.
+__global__ __launch_bounds__(256) void dec_attn_image_kernel(const unsigned short* __restrict__ in_planes, long in_stride, int ld_in,
+                                                             const float* __restrict__ in_inv, const float* __restrict__ in_bias,
+                                                             const unsigned short* __restrict__ out_planes, long out_stride,
+                                                             int ld_out, int inter, unsigned short* __restrict__ img) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)STAGES * CHUNK_FRAGS * 512;
+    if (idx >= total) return;
+    const int e = (int)(idx % 512), f = (int)((idx / 512) % CHUNK_FRAGS), st = (int)(idx / (512L * CHUNK_FRAGS));
+    const int l = e >> 3, j = e & 7, r = l & 31, h = l >> 5;
+    if (st < 3 * NH) {
+        int row0;
+        if (inter) row0 = (st % 3) * D + (st / 3) * 32;      // q | k | v of head st / 3
+        else row0 = st < NH ? 2 * D + st * 32 : ((st - NH) & 1) * D + ((st - NH) >> 1) * 32;
+        if (f < W_FRAGS) {
+            const int s = f >> 1, pl = f & 1;
+            img[idx] = in_planes[pl * in_stride + (size_t)(row0 + r) * ld_in + 16 * s + 8 * h + j];
+        } else if (f == W_FRAGS) {
+            const int fi = e >> 1;
+            float v = 0.f;
+            if (fi < 32) v = in_inv[row0 + fi];
+            else if (fi < 64) v = in_bias ? in_bias[row0 + fi - 32] : 0.f;
+            const unsigned bits = __builtin_bit_cast(unsigned, v);
+            img[idx] = (unsigned short)((e & 1) ? (bits >> 16) : (bits & 0xffffu));
+        } else {
+            img[idx] = 0;
+        }
+    } else {
+        const int hd = st - 3 * NH;
+        if (f < W_FRAGS) {
+            const int pl = f & 1, s = (f >> 1) & 1, t = f >> 2;
+            img[idx] = out_planes[pl * out_stride + (size_t)(32 * t + r) * ld_out + 32 * hd + (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * h];
+        } else {
+            img[idx] = 0;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" long gom_dec_attn_image_bytes(int d_model, int heads) {
+    if (d_model != D || heads != NH) return -1;
+    return IMAGE_BYTES;
+}
+
+extern "C" int gom_dec_attn_image(const void* in_planes, long in_plane_stride, int ld_in, const float* in_inv_scale,
+                                  const float* in_bias, const void* out_planes, long out_plane_stride, int ld_out, int inter,
+                                  void* image, long image_bytes, void* stream) {
+    GOM_CHECK_ARG(in_planes && in_inv_scale && out_planes && image && ld_in >= D && ld_out >= D);
+    GOM_CHECK_ARG(image_bytes >= IMAGE_BYTES);
+    const long total = (long)STAGES * CHUNK_FRAGS * 512;
+    hipLaunchKernelGGL(dec_attn_image_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)in_planes, in_plane_stride, ld_in, in_inv_scale, in_bias,
+                       (const unsigned short*)out_planes, out_plane_stride, ld_out, inter ? 1 : 0, (unsigned short*)image);
+    return gom_launch_status();
+}
+
+extern "C" long gom_dec_attn_workspace_bytes(int groups, int inter) {
+    if (groups < 0) return -1;
+    return inter ? 0 : (long)cdiv(groups, 4) * 4 * WS_WAVE_BYTES;
+}
+
+extern "C" int gom_dec_attn_f32(const float* X, int ldx, const float* P, int ldp, const void* image, const float* out_inv_scale,
+                                const float* out_bias, const float* gamma, const float* beta, float eps, float* Y, int ldy,
+                                int groups, int group_tokens, int inner, int inter, void* workspace, long workspace_bytes,
+                                int* flag, void* stream) {
+    GOM_CHECK_ARG(X && image && out_inv_scale && out_bias && gamma && beta && Y && groups >= 0 && group_tokens > 0);
+    GOM_CHECK_ARG(ldx >= D && ldy >= D && (ldx % 4) == 0 && (ldy % 4) == 0 && (!P || (ldp >= D && (ldp % 4) == 0)));
+    GOM_CHECK_ARG(((uintptr_t)X % 16) == 0 && (!P || ((uintptr_t)P % 16) == 0) && ((uintptr_t)Y % 16) == 0 &&
+                  ((uintptr_t)image % 16) == 0 && ((uintptr_t)out_inv_scale % 16) == 0 && ((uintptr_t)out_bias % 16) == 0 &&
+                  ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0);
+    GOM_CHECK_ARG(inter ? (!P && inner > 0 && group_tokens <= 128) : (P && group_tokens <= 32));
+    GOM_CHECK_ARG(inter || (workspace && ((uintptr_t)workspace % 16) == 0 &&
+                            workspace_bytes >= gom_dec_attn_workspace_bytes(groups, 0)));
+    if (groups == 0) return GOM_OK;
+    DecArgs a{};
+    a.ws = (unsigned char*)workspace;
+    a.X = X; a.P = P; a.img = (const unsigned char*)image; a.inv_o = out_inv_scale; a.bias_o = out_bias; a.gamma = gamma;
+    a.beta = beta; a.Y = Y; a.flag = flag; a.eps = eps; a.scale = 1.0f / sqrtf(32.f); a.ldx = ldx; a.ldp = ldp; a.ldy = ldy;
+    a.groups = groups; a.G = group_tokens; a.per_wave = cdiv(group_tokens, 4); a.inner = inner;
+    const int lds = inter ? RING_BYTES + XCH_BYTES : RING_BYTES;
+    hipError_t e = hipFuncSetAttribute((const void*)dec_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)dec_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES + XCH_BYTES);
+    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+    if (inter) hipLaunchKernelGGL(dec_attn_kernel<true>, dim3((unsigned)groups), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(dec_attn_kernel<false>, dim3((unsigned)cdiv(groups, 4)), dim3(256), lds, (hipStream_t)stream, a);
+    return gom_launch_status();
+}

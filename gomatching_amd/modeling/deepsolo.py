@@ -113,10 +113,14 @@ class DeepSolo:
             cross["raw"], cross["out"] = qlin(cross["raw"]), qlin(cross["out"])
             intra_out, inter_out = lin(p + "attn_intra.out_proj"), lin(p + "attn_inter.out_proj")
             n_intra, n_inter, n_cross = norm(p + "norm_intra"), norm(p + "norm_inter"), norm(p + "norm_cross")
+            wx, bx = ops.prep_weight(g(p + "attn_inter.in_proj_weight")), g(p + "attn_inter.in_proj_bias")
             self.dec.append({
+                # the whole block (in_proj, attention, out_proj, residual, norm) as ONE launch under the f16x3 back-end, else None
+                "intra_block": ops.dec_attn_block(wi, bi, intra_out, n_intra, inter=False),
+                "inter_block": ops.dec_attn_block(wx, bx, inter_out, n_inter, inter=True) if self.nq <= 128 else None,
                 "intra_qk": qlin((wi[:2 * E], bi[:2 * E])), "intra_v": qlin((wi[2 * E:], bi[2 * E:])),
                 "intra_out": qlin(intra_out), "norm_intra": n_intra, "intra_out_ln": ops.proj_ln_block(intra_out, n_intra),
-                "inter_in": qlin((ops.prep_weight(g(p + "attn_inter.in_proj_weight")), g(p + "attn_inter.in_proj_bias"))),
+                "inter_in": qlin((wx, bx)),
                 "inter_out": qlin(inter_out), "norm_inter": n_inter, "inter_out_ln": ops.proj_ln_block(inter_out, n_inter),
                 "cross": cross, "norm_cross": n_cross, "cross_out_ln": ops.proj_ln_block(cross["out"], n_cross),
                 "lin1": lin(p + "linear1"), "lin2": lin(p + "linear2"), "norm3": norm(p + "norm3"),
@@ -303,20 +307,29 @@ class DeepSolo:
             qpos = ops.linear(qpos, self.ref_point_head[0], relu=True)
             qpos = ops.linear(qpos, self.ref_point_head[1])
             # intra-instance attention over the 25 points of each query (deformable_transformer.py:386-394)
-            qk = ops.linear(tgt, L["intra_qk"], A2=qpos)                                       # [Q, 512]
-            v = ops.linear(tgt, L["intra_v"])
-            attn = torch.empty((Q, E), dtype=_f32, device=self.device)
-            qkf = qk.view(-1)
-            ops.mha_core(qkf, qkf[E:], v, attn, B * nq, 1, 8, 32, P, P,
-                         [P * 2 * E, 0, 2 * E, P * 2 * E, 0, 2 * E, P * E, 0, E, P * E, 0, E])
-            tgt = self._out_norm(attn, L, "intra", tgt)
+            attn = None
+            if L["intra_block"] is not None and P <= 32:
+                tgt = ops.dec_attn(tgt, L["intra_block"], B * nq, P, pos=qpos)
+            else:
+                qk = ops.linear(tgt, L["intra_qk"], A2=qpos)                                   # [Q, 512]
+                v = ops.linear(tgt, L["intra_v"])
+                attn = torch.empty((Q, E), dtype=_f32, device=self.device)
+                qkf = qk.view(-1)
+                ops.mha_core(qkf, qkf[E:], v, attn, B * nq, 1, 8, 32, P, P,
+                             [P * 2 * E, 0, 2 * E, P * 2 * E, 0, 2 * E, P * E, 0, E, P * E, 0, E])
+                tgt = self._out_norm(attn, L, "intra", tgt)
             # inter-instance attention over the nq queries, batched over (frame, point) (:396-404)
-            qkv = ops.linear(tgt, L["inter_in"])                                               # [Q, 768]
-            f = qkv.view(-1)
-            ld = 3 * E
-            ops.mha_core(f, f[E:], f[2 * E:], attn, B, P, 8, 32, nq, nq,
-                         [nq * P * ld, ld, P * ld] * 3 + [nq * P * E, E, P * E])
-            tgt = self._out_norm(attn, L, "inter", tgt)
+            if L["inter_block"] is not None:
+                tgt = ops.dec_attn(tgt, L["inter_block"], B * P, nq, inner=P)
+            else:
+                qkv = ops.linear(tgt, L["inter_in"])                                           # [Q, 768]
+                if attn is None:
+                    attn = torch.empty((Q, E), dtype=_f32, device=self.device)
+                f = qkv.view(-1)
+                ld = 3 * E
+                ops.mha_core(f, f[E:], f[2 * E:], attn, B, P, 8, 32, nq, nq,
+                             [nq * P * ld, ld, P * ld] * 3 + [nq * P * E, E, P * E])
+                tgt = self._out_norm(attn, L, "inter", tgt)
             # deformable cross attention into the encoder memory (:406-422)
             value = values[:, lid * E:(lid + 1) * E]
             samp = self._msda_strided(L["cross"], tgt, qpos, refs.view(Q, 1, 2), value, values.stride(0), geo, B,

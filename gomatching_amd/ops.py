@@ -481,6 +481,77 @@ def proj_ln(x, blk, R, out=None):
     return out
 
 
+DEC_ATTN = _switch("DEC_ATTN")       # f16x3 back-end: the decoder's intra / inter self-attention blocks as one launch each
+DEC_ATTN_INTRA = _switch("DEC_ATTN_INTRA")
+DEC_ATTN_INTER = _switch("DEC_ATTN_INTER")
+
+
+class DecAttnBlock:
+    """One self-attention block of a composite decoder layer -- in_proj (q | k | v), 8 x 32 attention, out_proj, residual,
+    LayerNorm -- prepared for gom_dec_attn_f32 (csrc/dec_attn.hip): the fragment-linear image of in_proj_weight [768, 256] and
+    out_proj.weight [256, 256] in the kernel's stage order + what its epilogue needs.  `inter`: attention over the queries of a
+    (frame, point) (deformable_transformer.py:396-404) instead of over the points of a query (:386-394)."""
+
+    def __init__(self, in_w, in_b, out_w, out_b, gamma, beta, inter, eps=1e-5):
+        assert tuple(in_w.shape) == (768, 256) and tuple(out_w.shape) == (256, 256)
+        nbytes = _L().gom_dec_attn_image_bytes(256, 8)
+        if nbytes < 0:
+            raise _lib_mod.GomError("decoder attention kernel serves d_model 256 / 8 heads only")
+        si = in_w if isinstance(in_w, SplitWeight) else split_weight(in_w.contiguous(), kind="f16x3")
+        so = out_w if isinstance(out_w, SplitWeight) else split_weight(out_w.contiguous(), kind="f16x3")
+        assert si.kind == "f16x3" and so.kind == "f16x3"
+        _chk_f32(in_b, out_b, gamma, beta)
+        self.image = torch.empty((nbytes,), dtype=torch.uint8, device=si.planes.device)
+        pi, po = si.planes, so.planes
+        check(_L().gom_dec_attn_image(_p(pi), pi.stride(0), pi.stride(1), _p(si.inv_scale), _p(in_b), _p(po), po.stride(0),
+                                      po.stride(1), 1 if inter else 0, _p(self.image), nbytes, _stream()), "gom_dec_attn_image")
+        self.inv_o, self.bias_o, self.gamma, self.beta, self.eps, self.inter = so.inv_scale, out_b, gamma, beta, eps, bool(inter)
+
+
+def dec_attn_block(in_w, in_b, out_pair, norm, inter):
+    """DecAttnBlock when the back-end allows, else None (callers keep the five-launch path)."""
+    w, b = out_pair if not isinstance(out_pair, K256Linear) else (out_pair.W, out_pair.bias)
+    on = DEC_ATTN and (DEC_ATTN_INTER if inter else DEC_ATTN_INTRA)
+    if on and GEMM_MODE == "f16x3" and isinstance(in_w, SplitWeight) and in_w.kind == "f16x3" and tuple(in_w.shape) == (768, 256) \
+            and isinstance(w, SplitWeight) and w.kind == "f16x3" and tuple(w.shape) == (256, 256):
+        return DecAttnBlock(in_w, in_b, w, b, norm[0], norm[1], inter)
+    return None
+
+
+def dec_attn(x, blk, groups, group_tokens, inner=1, pos=None, out=None):
+    """LayerNorm(x + out_proj(MHA(...))) of one decoder self-attention block in one launch.  x [rows, 256]; intra (blk.inter
+    False): `groups` runs of `group_tokens` <= 32 consecutive rows, q = k = x + pos, v = x; inter: token t of group g is row
+    ((g // inner) * group_tokens + t) * inner + g % inner, q = k = v = x."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == 256 and x.dtype == _f32
+    assert (pos is None) == blk.inter
+    if pos is not None:
+        assert pos.shape == x.shape and pos.stride(1) == 1 and pos.dtype == _f32
+    rows = groups * group_tokens
+    assert x.shape[0] >= rows
+    if out is None:
+        out = torch.empty((x.shape[0], 256), dtype=_f32, device=x.device)
+    ws, ws_bytes = None, 0
+    if not blk.inter:                                        # V fragments parked per wave (csrc/dec_attn.hip), 32 KB per group
+        ws_bytes = _L().gom_dec_attn_workspace_bytes(groups, 0)
+        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=x.device)
+    prof = _gemm_profile if (_gemm_profile is not None and rows > 0) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().gom_dec_attn_f32(_p(x), x.stride(0) if x.shape[0] > 1 else 256, _p(pos),
+                                (pos.stride(0) if pos.shape[0] > 1 else 256) if pos is not None else 0, _p(blk.image),
+                                _p(blk.inv_o), _p(blk.bias_o), _p(blk.gamma), _p(blk.beta), blk.eps, _p(out),
+                                out.stride(0) if out.shape[0] > 1 else 256, groups, group_tokens, inner,
+                                1 if blk.inter else 0, _p(ws), ws_bytes, _p(range_flag(x.device)), _stream()), "gom_dec_attn_f32")
+    if prof is not None:
+        e1.record()
+        # the block's nn.Linear products (in_proj 768 + out_proj 256 columns) + QK^T and PV of every head
+        flops = 2.0 * rows * 256 * 1024 + 4.0 * rows * group_tokens * 256
+        nbytes = 4.0 * rows * 256 * (3 if pos is not None else 2) + blk.image.numel()
+        prof.append((e0, e1, flops, nbytes, "decattn:%s:%dx%d" % ("inter" if blk.inter else "intra", groups, group_tokens)))
+    return out
+
+
 FUSED_FFN = _switch("FUSED_FFN")     # f16x3 back-end: FFN blocks as one fused launch (False: GEMM, GEMM, LayerNorm)
 
 

@@ -1,0 +1,103 @@
+"""GPU: the decoder's self-attention blocks as one launch each (csrc/dec_attn.hip) against a float64 statement of
+nn.MultiheadAttention + residual + LayerNorm (deformable_transformer.py:386-404), and against the five-launch path."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _weights(seed):
+    g = torch.Generator().manual_seed(seed)
+    in_w = torch.randn(768, 256, generator=g) / 16 * torch.logspace(-1, 1, 768).view(-1, 1) ** 0.3
+    in_b = torch.randn(768, generator=g) * 0.1
+    out_w = torch.randn(256, 256, generator=g) / 16
+    out_b = torch.randn(256, generator=g) * 0.1
+    gamma = torch.rand(256, generator=g) + 0.5
+    beta = torch.randn(256, generator=g) * 0.1
+    return in_w, in_b, out_w, out_b, gamma, beta
+
+
+def _ref(x, pos, w, groups):
+    """groups: LongTensor [n_groups, G] of row indices; float64."""
+    in_w, in_b, out_w, out_b, gamma, beta = [t.double() for t in w]
+    x = x.double()
+    qk_in = x if pos is None else x + pos.double()
+    q = qk_in @ in_w[:256].t() + in_b[:256]
+    k = qk_in @ in_w[256:512].t() + in_b[256:512]
+    v = x @ in_w[512:].t() + in_b[512:]
+    out = torch.zeros_like(x)
+    n, G = groups.shape
+    qg = q[groups].view(n, G, 8, 32).transpose(1, 2)
+    kg = k[groups].view(n, G, 8, 32).transpose(1, 2)
+    vg = v[groups].view(n, G, 8, 32).transpose(1, 2)
+    a = torch.softmax(qg @ kg.transpose(-1, -2) / math.sqrt(32.0), -1)
+    o = (a @ vg).transpose(1, 2).reshape(n * G, 256)
+    y = o @ out_w.t() + out_b + x[groups.reshape(-1)]
+    y = torch.nn.functional.layer_norm(y, (256,), gamma, beta, 1e-5)
+    out[groups.reshape(-1)] = y
+    return out
+
+
+def _block(ops, w, inter):
+    d = [t.to(DEV) for t in w]
+    return ops.DecAttnBlock(d[0], d[1], d[2], d[3], d[4], d[5], inter)
+
+
+@pytest.mark.parametrize("groups,G", [(1, 25), (4, 25), (37, 25), (800, 25), (5, 32), (9, 3), (6, 1)])
+def test_intra_block(groups, G):
+    from gomatching_amd import ops
+    g = torch.Generator().manual_seed(groups * 31 + G)
+    w = _weights(1)
+    rows = groups * G
+    x, pos = torch.randn(rows, 256, generator=g), torch.randn(rows, 256, generator=g) * 0.7
+    blk = _block(ops, w, False)
+    out = torch.full((rows + 3, 256), 7.0, device=DEV)
+    xd = torch.cat([x, torch.zeros(3, 256)]).to(DEV)
+    pd = torch.cat([pos, torch.zeros(3, 256)]).to(DEV)
+    ops.dec_attn(xd, blk, groups, G, pos=pd, out=out)
+    ref = _ref(x, pos, w, torch.arange(rows).view(groups, G))
+    err = float((out[:rows].cpu().double() - ref).abs().max())
+    assert err < 2e-5, err
+    assert float((out[rows:] - 7.0).abs().max()) == 0.0             # rows beyond the groups are not touched
+    ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
+
+
+@pytest.mark.parametrize("B,nq,P", [(1, 100, 25), (2, 12, 25), (8, 100, 25), (1, 128, 3), (3, 7, 2), (2, 1, 5), (1, 97, 1)])
+def test_inter_block(B, nq, P):
+    from gomatching_amd import ops
+    g = torch.Generator().manual_seed(B * 131 + nq * 7 + P)
+    w = _weights(2)
+    rows = B * nq * P
+    x = torch.randn(rows, 256, generator=g)
+    blk = _block(ops, w, True)
+    out = torch.full((rows, 256), 7.0, device=DEV)
+    ops.dec_attn(x.to(DEV), blk, B * P, nq, inner=P, out=out)
+    idx = torch.arange(rows).view(B, nq, P).permute(0, 2, 1).reshape(B * P, nq)
+    ref = _ref(x, None, w, idx)
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err < 2e-5, err
+    ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
+
+
+def test_blocks_raise_the_range_flag():
+    from gomatching_amd import ops
+    dev = torch.device(DEV, torch.cuda.current_device())
+    w = _weights(3)
+    ops.check_range_flag(dev)
+    x = torch.randn(100, 256, device=DEV)
+    x[37, 5] = 7e4
+    ops.dec_attn(x, _block(ops, w, False), 4, 25, pos=torch.zeros_like(x))
+    with pytest.raises(Exception, match="fp16's range"):
+        ops.check_range_flag(dev)
+    ops.dec_attn(x, _block(ops, w, True), 4, 25, inner=1)
+    with pytest.raises(Exception, match="fp16's range"):
+        ops.check_range_flag(dev)
+    big = list(w)
+    big[0] = w[0].clone()
+    big[0][300] *= 1e6                                               # one k feature beyond fp16 after the projection
+    ops.dec_attn(torch.randn(100, 256, device=DEV), _block(ops, big, True), 4, 25, inner=1)
+    with pytest.raises(Exception, match="fp16's range"):
+        ops.check_range_flag(dev)
