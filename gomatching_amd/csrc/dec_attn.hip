@@ -50,10 +50,6 @@ struct DecArgs {
     const float* X;                                          // tgt [rows, 256]
     const float* P;                                          // query_pos (intra) or null
     const unsigned char* img;
-    const float* inv_o;                                      // out_proj: 1 / row scale of the split weight, bias
-    const float* bias_o;
-    const float* gamma;
-    const float* beta;
     float* Y;
     unsigned char* ws;                                       // intra: WS_WAVE_BYTES per wave of the launch
     int* flag;
@@ -137,6 +133,17 @@ __device__ __forceinline__ f32x16 mfma_x3(const half8 a_hi, const half8 a_lo, co
         MFMA(fb, 3)                                                                                           \
     }
 
+#define DA_STAGE_LAST(MFMA)                                                                                   \
+    {                                                                                                         \
+        half8 fa[8], fb[8];                                                                                   \
+        DA_LOAD(fa, 0)                                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                                    \
+        DA_LOAD(fb, 1) MFMA(fa, 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); __builtin_amdgcn_sched_group_barrier(0x008, 12, 0); \
+        DA_LOAD(fa, 2) MFMA(fb, 1) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); __builtin_amdgcn_sched_group_barrier(0x008, 12, 0); \
+        DA_LOAD(fb, 3) MFMA(fa, 2) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); __builtin_amdgcn_sched_group_barrier(0x008, 12, 0); \
+        MFMA(fb, 3)                                                                                           \
+    }
+
 // projection chunk, transposed: acc[feature][token] += W chunk . X^T  (A = weight fragment, B = the rows in registers)
 #define DA_MFMA_T(src, g)                                                                                     \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
@@ -191,7 +198,6 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
 
     const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, IMAGE_BYTES, 0x00020000);
     constexpr unsigned OOB = 0x7FFF0000u;                    // beyond num_records: the DMA writes zeros (into an unused stage)
-    for (int f = wave; f < 2 * CHUNK_FRAGS; f += 4) dma_fragment(rs_img, f * FRAG + lane * 16, smem + f * FRAG);   // stages 0, 1
 
     // range bookkeeping: a running maximum of |value| over everything that is split into fp16 planes, and a NaN / Inf detector
     // over the outputs (o * 0 accumulates to NaN for a non-finite o).  NOT `bad |= !(|v| <= limit)` per value: the compiler defers
@@ -229,12 +235,16 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
+            // (kernel start) the rows are requested FIRST, the ring's first two stages behind them: the split below runs while
+            // the 72 KB of weights are still on their way
             f32x4 ra[D / 8];
 #pragma unroll
             for (int s = 0; s < D / 16; ++s) {
                 ra[2 * s] = *reinterpret_cast<const f32x4*>(xr + 16 * s);
                 ra[2 * s + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            for (int f = wave; f < 2 * CHUNK_FRAGS; f += 4) dma_fragment(rs_img, f * FRAG + lane * 16, smem + f * FRAG);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < D / 16; ++s) {
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                s[b][g] = expf(s[b][g] - mx);
+                s[b][g] = __expf(s[b][g] - mx);               // v_exp_f32: ~1 ulp, far inside the block's fp32-class error
                 sum += s[b][g];
             }
         sum += __shfl_xor(sum, 32, 64);
@@ -465,43 +475,53 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
     for (int t = 0; t < D / 32; ++t)
 #pragma unroll
         for (int g = 0; g < 16; ++g) yacc[t][g] = 0.f;
+    // the residual rows (= X, last read at the kernel's start) are requested in front of the first out_proj stage, into the
+    // registers the row fragments no longer need; epilogue vectors (1 / row scale, bias, gamma, beta) ride in the unused
+    // fragments of the last two stages
+    f32x4 res[D / 8];
+    {
+        const float* rr = p.X + (size_t)row * p.ldx + 4 * fh;
+#pragma unroll
+        for (int i = 0; i < D / 8; ++i) res[i] = *reinterpret_cast<const f32x4*>(rr + 8 * i);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-        constexpr int dummy_ = 0;
-        (void)dummy_;
         const int hh_ = h;
         DA_STAGE_VARS(3 * NH + h)
         (void)aux;
-        DA_STAGE(DA_MFMA_O)
-        DA_STAGE_END()
+        if (h < NH - 2) {
+            DA_STAGE(DA_MFMA_O)
+            DA_STAGE_END()
+        } else {
+            (void)nsrc;
+            (void)ndst;
+            DA_STAGE_LAST(DA_MFMA_O)
+            if (h == NH - 2) { DA_STAGE_END_ALL() }
+        }
     }
 
     // ---- residual + LayerNorm in registers: lane (token, fh) holds features 32 t + 8 q + 4 fh .. + 3 of its token ----
-    // (one 32-feature tile at a time, fenced: left alone the compiler requests every residual / scale / bias vector of the row
-    // up front -- 384 registers -- and spills the accumulators)
     {
-        const float* rr = p.X + (size_t)row * p.ldx + 4 * fh;
+        const float* v_inv = reinterpret_cast<const float*>(smem + ((STAGES - 1) % SLOTS) * CHUNK_BYTES + (W_FRAGS + 1) * FRAG);
+        const float* v_bias = v_inv + 256;
+        const float* v_gamma = v_inv + 512;
+        const float* v_beta = reinterpret_cast<const float*>(smem + ((STAGES - 2) % SLOTS) * CHUNK_BYTES + (W_FRAGS + 1) * FRAG);
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < D / 32; ++t) {
-            f32x4 r[4], sc[4], bi[4];
+        for (int t = 0; t < D / 32; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = 32 * t + 8 * q;
-                r[q] = *reinterpret_cast<const f32x4*>(rr + col);
-                sc[q] = *reinterpret_cast<const f32x4*>(p.inv_o + col + 4 * fh);
-                bi[q] = *reinterpret_cast<const f32x4*>(p.bias_o + col + 4 * fh);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
+                const int col = 32 * t + 8 * q + 4 * fh;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(v_inv + col);
+                const f32x4 bi = *reinterpret_cast<const f32x4*>(v_bias + col);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = fmaf(yacc[t][4 * q + e], sc[q][e], bi[q][e]) + r[q][e];
+                    const float v = fmaf(yacc[t][4 * q + e], sc[e], bi[e]) + res[4 * t + q][e];
                     yacc[t][4 * q + e] = v;
                     sum += v;
                 }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            }
         sum += __shfl_xor(sum, 32, 64);
         const float mean = sum * (1.f / D);
         float sq = 0.f;
@@ -516,27 +536,21 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
         const float rstd = rsqrtf(sq * (1.f / D) + p.eps);
         float* yr = p.Y + (size_t)row * p.ldy + 4 * fh;
 #pragma unroll
-        for (int t = 0; t < D / 32; ++t) {
-            f32x4 ga[4], be[4];
+        for (int t = 0; t < D / 32; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = 32 * t + 8 * q;
-                ga[q] = *reinterpret_cast<const f32x4*>(p.gamma + col + 4 * fh);
-                be[q] = *reinterpret_cast<const f32x4*>(p.beta + col + 4 * fh);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
+                const int col = 32 * t + 8 * q + 4 * fh;
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(v_gamma + col);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(v_beta + col);
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = yacc[t][4 * q + e] * rstd * ga[q][e] + be[q][e];
+                    o[e] = yacc[t][4 * q + e] * rstd * ga[e] + be[e];
                     chk = fmaf(o[e], 0.f, chk);
                 }
                 if (valid) *reinterpret_cast<f32x4*>(yr + 32 * t + 8 * q) = o;
             }
-            asm volatile("" : "+v"(chk));
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        asm volatile("" : "+v"(chk));
     }
     // an operand left fp16's range, or a result is not finite (gemm_f16x3.hip contract; fmaxf drops a NaN, `chk` catches it)
     if ((!(amax <= 65504.f) || !(chk == 0.f)) && p.flag) atomicOr(p.flag, 1);
@@ -562,7 +576,10 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
 __global__ __launch_bounds__(256) void dec_attn_image_kernel(const unsigned short* __restrict__ in_planes, long in_stride, int ld_in,
                                                              const float* __restrict__ in_inv, const float* __restrict__ in_bias,
                                                              const unsigned short* __restrict__ out_planes, long out_stride,
-                                                             int ld_out, int inter, unsigned short* __restrict__ img) {
+                                                             int ld_out, const float* __restrict__ out_inv,
+                                                             const float* __restrict__ out_bias, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int inter,
+                                                             unsigned short* __restrict__ img) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)STAGES * CHUNK_FRAGS * 512;
     if (idx >= total) return;
@@ -591,7 +608,17 @@ __global__ __launch_bounds__(256) void dec_attn_image_kernel(const unsigned shor
             const int pl = f & 1, s = (f >> 1) & 1, t = f >> 2;
             img[idx] = out_planes[pl * out_stride + (size_t)(32 * t + r) * ld_out + 32 * hd + (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * h];
         } else {
-            img[idx] = 0;
+            // unused fragments of the last two stages: stage 31: 1 / row scale | bias | gamma (fragments 33, 34, 35), stage 30:
+            // beta (fragment 33) -- 256 floats each, read by the epilogue straight from the ring
+            const float* vec = nullptr;
+            if (st == STAGES - 1) vec = f == W_FRAGS + 1 ? out_inv : f == W_FRAGS + 2 ? out_bias : f == W_FRAGS + 3 ? gamma : nullptr;
+            if (st == STAGES - 2 && f == W_FRAGS + 1) vec = beta;
+            unsigned short v16 = 0;
+            if (vec) {
+                const unsigned bits = __builtin_bit_cast(unsigned, vec[e >> 1]);
+                v16 = (unsigned short)((e & 1) ? (bits >> 16) : (bits & 0xffffu));
+            }
+            img[idx] = v16;
         }
     }
 }
@@ -604,14 +631,17 @@ extern "C" long gom_dec_attn_image_bytes(int d_model, int heads) {
 }
 
 extern "C" int gom_dec_attn_image(const void* in_planes, long in_plane_stride, int ld_in, const float* in_inv_scale,
-                                  const float* in_bias, const void* out_planes, long out_plane_stride, int ld_out, int inter,
-                                  void* image, long image_bytes, void* stream) {
+                                  const float* in_bias, const void* out_planes, long out_plane_stride, int ld_out,
+                                  const float* out_inv_scale, const float* out_bias, const float* gamma, const float* beta,
+                                  int inter, void* image, long image_bytes, void* stream) {
     GOM_CHECK_ARG(in_planes && in_inv_scale && out_planes && image && ld_in >= D && ld_out >= D);
+    GOM_CHECK_ARG(out_inv_scale && out_bias && gamma && beta);
     GOM_CHECK_ARG(image_bytes >= IMAGE_BYTES);
     const long total = (long)STAGES * CHUNK_FRAGS * 512;
     hipLaunchKernelGGL(dec_attn_image_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)in_planes, in_plane_stride, ld_in, in_inv_scale, in_bias,
-                       (const unsigned short*)out_planes, out_plane_stride, ld_out, inter ? 1 : 0, (unsigned short*)image);
+                       (const unsigned short*)out_planes, out_plane_stride, ld_out, out_inv_scale, out_bias, gamma, beta,
+                       inter ? 1 : 0, (unsigned short*)image);
     return gom_launch_status();
 }
 
@@ -620,23 +650,20 @@ extern "C" long gom_dec_attn_workspace_bytes(int groups, int inter) {
     return inter ? 0 : (long)cdiv(groups, 4) * 4 * WS_WAVE_BYTES;
 }
 
-extern "C" int gom_dec_attn_f32(const float* X, int ldx, const float* P, int ldp, const void* image, const float* out_inv_scale,
-                                const float* out_bias, const float* gamma, const float* beta, float eps, float* Y, int ldy,
+extern "C" int gom_dec_attn_f32(const float* X, int ldx, const float* P, int ldp, const void* image, float eps, float* Y, int ldy,
                                 int groups, int group_tokens, int inner, int inter, void* workspace, long workspace_bytes,
                                 int* flag, void* stream) {
-    GOM_CHECK_ARG(X && image && out_inv_scale && out_bias && gamma && beta && Y && groups >= 0 && group_tokens > 0);
+    GOM_CHECK_ARG(X && image && Y && groups >= 0 && group_tokens > 0);
     GOM_CHECK_ARG(ldx >= D && ldy >= D && (ldx % 4) == 0 && (ldy % 4) == 0 && (!P || (ldp >= D && (ldp % 4) == 0)));
     GOM_CHECK_ARG(((uintptr_t)X % 16) == 0 && (!P || ((uintptr_t)P % 16) == 0) && ((uintptr_t)Y % 16) == 0 &&
-                  ((uintptr_t)image % 16) == 0 && ((uintptr_t)out_inv_scale % 16) == 0 && ((uintptr_t)out_bias % 16) == 0 &&
-                  ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0);
+                  ((uintptr_t)image % 16) == 0);
     GOM_CHECK_ARG(inter ? (!P && inner > 0 && group_tokens <= 128) : (P && group_tokens <= 32));
     GOM_CHECK_ARG(inter || (workspace && ((uintptr_t)workspace % 16) == 0 &&
                             workspace_bytes >= gom_dec_attn_workspace_bytes(groups, 0)));
     if (groups == 0) return GOM_OK;
     DecArgs a{};
     a.ws = (unsigned char*)workspace;
-    a.X = X; a.P = P; a.img = (const unsigned char*)image; a.inv_o = out_inv_scale; a.bias_o = out_bias; a.gamma = gamma;
-    a.beta = beta; a.Y = Y; a.flag = flag; a.eps = eps; a.scale = 1.0f / sqrtf(32.f); a.ldx = ldx; a.ldp = ldp; a.ldy = ldy;
+    a.X = X; a.P = P; a.img = (const unsigned char*)image; a.Y = Y; a.flag = flag; a.eps = eps; a.scale = 1.0f / sqrtf(32.f); a.ldx = ldx; a.ldp = ldp; a.ldy = ldy;
     a.groups = groups; a.G = group_tokens; a.per_wave = cdiv(group_tokens, 4); a.inner = inner;
     const int lds = inter ? RING_BYTES + XCH_BYTES : RING_BYTES;
     hipError_t e = hipFuncSetAttribute((const void*)dec_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES);

@@ -504,8 +504,9 @@ class DecAttnBlock:
         self.image = torch.empty((nbytes,), dtype=torch.uint8, device=si.planes.device)
         pi, po = si.planes, so.planes
         check(_L().gom_dec_attn_image(_p(pi), pi.stride(0), pi.stride(1), _p(si.inv_scale), _p(in_b), _p(po), po.stride(0),
-                                      po.stride(1), 1 if inter else 0, _p(self.image), nbytes, _stream()), "gom_dec_attn_image")
-        self.inv_o, self.bias_o, self.gamma, self.beta, self.eps, self.inter = so.inv_scale, out_b, gamma, beta, eps, bool(inter)
+                                      po.stride(1), _p(so.inv_scale), _p(out_b), _p(gamma), _p(beta), 1 if inter else 0,
+                                      _p(self.image), nbytes, _stream()), "gom_dec_attn_image")
+        self.eps, self.inter = eps, bool(inter)
 
 
 def dec_attn_block(in_w, in_b, out_pair, norm, inter):
@@ -540,7 +541,7 @@ def dec_attn(x, blk, groups, group_tokens, inner=1, pos=None, out=None):
         e0.record()
     check(_L().gom_dec_attn_f32(_p(x), x.stride(0) if x.shape[0] > 1 else 256, _p(pos),
                                 (pos.stride(0) if pos.shape[0] > 1 else 256) if pos is not None else 0, _p(blk.image),
-                                _p(blk.inv_o), _p(blk.bias_o), _p(blk.gamma), _p(blk.beta), blk.eps, _p(out),
+                                blk.eps, _p(out),
                                 out.stride(0) if out.shape[0] > 1 else 256, groups, group_tokens, inner,
                                 1 if blk.inter else 0, _p(ws), ws_bytes, _p(range_flag(x.device)), _stream()), "gom_dec_attn_f32")
     if prof is not None:

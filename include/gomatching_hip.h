@@ -159,17 +159,17 @@ int gom_proj_ln_f32(const float* X, int ldx, const void* image, const float* w_i
  *     Y = LayerNorm(X + out_proj(MHA_8x32(...))) * gamma + beta,   X, P, Y [rows, 256] fp32; Y must not alias X.
  * f16x3 scheme, range contract and *flag of gom_gemm_f32_f16x3 (q, k, v, the inputs and the probabilities are split into two
  * fp16 planes; fp32 accumulation and softmax).  gom_dec_attn_image: one-time weight preparation from the gom_split_f16x2
- * planes of in_proj_weight [768, 256] (+ inverse row scales, in_proj_bias) and out_proj.weight [256, 256];
- * out_inv_scale / out_bias = out_proj's inverse row scales and bias. */
+ * planes of in_proj_weight [768, 256] (+ inverse row scales, in_proj_bias) and out_proj.weight [256, 256] (+ inverse row
+ * scales, bias) and the LayerNorm's gamma / beta [256]. */
 long gom_dec_attn_image_bytes(int d_model, int heads);
 /* inter = 0 parks the V fragments of its groups in `workspace` (gom_dec_attn_workspace_bytes(groups, 0) bytes, 16-byte aligned,
  * contents irrelevant before and after the launch); inter = 1 needs none. */
 long gom_dec_attn_workspace_bytes(int groups, int inter);
 int gom_dec_attn_image(const void* in_planes, long in_plane_stride, int ld_in, const float* in_inv_scale, const float* in_bias,
-                       const void* out_planes, long out_plane_stride, int ld_out, int inter, void* image, long image_bytes,
+                       const void* out_planes, long out_plane_stride, int ld_out, const float* out_inv_scale,
+                       const float* out_bias, const float* gamma, const float* beta, int inter, void* image, long image_bytes,
                        void* stream);
-int gom_dec_attn_f32(const float* X, int ldx, const float* P, int ldp, const void* image, const float* out_inv_scale,
-                     const float* out_bias, const float* gamma, const float* beta, float eps, float* Y, int ldy, int groups,
+int gom_dec_attn_f32(const float* X, int ldx, const float* P, int ldp, const void* image, float eps, float* Y, int ldy, int groups,
                      int group_tokens, int inner, int inter, void* workspace, long workspace_bytes, int* flag, void* stream);
 
 /* Row-resident K = 256 form of gom_gemm_f32_f16x3 for SHORT problems (the decoder's Q-side nn.Linear layers at
