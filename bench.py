@@ -404,13 +404,18 @@ def main():
 
     total_frames = FRAMES_PER_GPU * world * args.steps
     fps = total_frames / elapsed
+    # north_star's decoder figure: every launch inside the six composite decoder layers that performs Q-side nn.Linear products
+    # (M = frames x queries x points rows: ref_point_head, the self-attention blocks, cross-attention offsets | logits and
+    # out_proj, FFN, the ctrl-point MLP) against those products' algorithmic FLOPs (7.375 GFLOP per layer and frame)
+    dec_prof = [p_ for p_ in prof if len(p_) > 5 and p_[5] == "decoder_layer"]
+    dec_prof = [p_ for p_ in dec_prof if p_[4].startswith(("decattn:", "k256:", "projln:", "ffn")) or "x" in p_[4]]
     ffn_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("ffn")]       # the fused FFN block: its own kernel
     k256_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("k256:")]    # the decoder's row-resident K = 256 kernel
     pl_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("projln:")]    # out_proj + residual + LayerNorm launches
     all_prof = prof
     # the dominant kernel = the 128x128 tile kernel: every launch of it in the step, through the GEMM API and as the backbone's
     # pointwise convolutions ("pw:", the same instantiation: csrc/gemm_f16x3.hip dispatch<0, 0>)
-    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:")))]
+    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:", "decattn:")))]
     dur_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     flops = sum(p[2] for p in prof)
     alg_bytes = sum(p[3] for p in prof)
@@ -578,6 +583,33 @@ def main():
                     "the row-resident K = 256 kernel (both forms) and out_proj + LayerNorm",
             "achieved": both_fl / (both_ms * 1e-3) / 1e12, "frac": both_fl / (both_ms * 1e-3) / 1e12 / PEAKS[args.gemm][1],
             "share_of_step_time": (both_ms / PROFILE_STEPS) / (elapsed / args.steps * 1e3)}
+    if dec_prof:
+        T_ = cfg.MODEL.TRANSFORMER
+        rows = FRAMES_PER_GPU * T_.NUM_QUERIES * T_.NUM_POINTS
+        d_, F_, L_ = T_.HIDDEN_DIM, T_.DIM_FEEDFORWARD, T_.DEC_LAYERS
+        # per layer: ref_point_head 2 x (d x d), in_proj 3d + out_proj d (twice), offsets | logits 384 + out_proj d, FFN 2 x d x F,
+        # ctrl-point MLP 2 x (d x d) + d x 2
+        qside = 2.0 * rows * d_ * (2 * d_ + 2 * 4 * d_ + 384 + d_ + 2 * F_ + 2 * d_ + 2) * L_
+        dd = sum(p_[0].elapsed_time(p_[1]) for p_ in dec_prof) / PROFILE_STEPS * 1e-3
+        kinds = {}
+        for p_ in dec_prof:
+            k_ = p_[4].split(":")[0] if ":" in p_[4] else ("ffn" if p_[4].startswith("ffn") else "tile / fp32 GEMM")
+            if p_[4].startswith("decattn:"):
+                k_ = "decattn " + p_[4].split(":")[1]
+            e_ = kinds.setdefault(k_, [0, 0.0])
+            e_[0] += 1
+            e_[1] += p_[0].elapsed_time(p_[1])
+        line["roofline_decoder_qside"] = {
+            "bound": "mfma", "achieved": qside / dd / 1e12, "peak": PEAKS["f16x3"][1], "unit": "TFLOP/s",
+            "frac": qside / dd / 1e12 / PEAKS["f16x3"][1],
+            "algorithmic_gflop_per_frame": qside / FRAMES_PER_GPU / 1e9, "launches_per_step": len(dec_prof) // PROFILE_STEPS,
+            "us_per_step": dd * 1e6, "share_of_step_time": dd * 1e3 / (elapsed / args.steps * 1e3),
+            "by_kernel_us_per_step": {k_: {"launches": v_[0] // PROFILE_STEPS, "us": v_[1] * 1e3 / PROFILE_STEPS}
+                                      for k_, v_ in sorted(kinds.items())},
+            "note": "the six composite decoder layers' Q-side nn.Linear products (44.25 GFLOP per frame at 100 queries) over the "
+                    "summed HIP-event time of EVERY launch that performs one of them -- the fused self-attention blocks "
+                    "(csrc/dec_attn.hip) are counted whole, attention cores and LayerNorms included; MSDA sampling, the sine "
+                    "embedding and ref_sigmoid launches are not Q-side products and are left out.  north_star asks 0.60"}
     solo = rank == 0 and world == 1 and args.backbone == "r50" and args.emulate_world == 1
     if solo and not args.no_alt_backends:
         # the other two contraction back-ends on the same window, a few steps each (secondary figures, same process)

@@ -81,8 +81,9 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8& p0, 
     p1 = __builtin_bit_cast(half8, (u32x4{h0, h1, h2, h3}));
 }
 
-__device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned byte_offset, unsigned char* lds_frag) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)byte_offset, 0, 0, 0);
+// `lane_off` (vector) = this lane's 16 bytes inside a fragment, `frag_off` (scalar) = the fragment's offset in the image
+__device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned lane_off, unsigned frag_off, unsigned char* lds_frag) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)lane_off, (int)frag_off, 0, 0);
 }
 
 // registers 8 s .. 8 s + 7 of a 32x32 accumulator -> the two planes of k-step s of an operand fragment
@@ -106,7 +107,7 @@ __device__ __forceinline__ f32x16 mfma_x3(const half8 a_hi, const half8 a_lo, co
 #define DA_LOAD(dst, g)                                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                          \
         dst[i_] = *reinterpret_cast<const half8*>(base + ((g) * 8 + i_) * FRAG);
-#define DA_DMA(i) dma_fragment(rs_img, nsrc + (i) * 4 * FRAG, ndst + (i) * 4 * FRAG);
+#define DA_DMA(i) dma_fragment(rs_img, lane16, nsrc + (i) * 4 * FRAG, ndst + (i) * 4 * FRAG);
 #define DA_PIN3()                                         \
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
 
     const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, IMAGE_BYTES, 0x00020000);
     constexpr unsigned OOB = 0x7FFF0000u;                    // beyond num_records: the DMA writes zeros (into an unused stage)
+    const unsigned lane16 = lane * 16;
 
     // range bookkeeping: a running maximum of |value| over everything that is split into fp16 planes, and a NaN / Inf detector
     // over the outputs (o * 0 accumulates to NaN for a non-finite o).  NOT `bad |= !(|v| <= limit)` per value: the compiler defers
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
                 ra[2 * s + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
             }
             __builtin_amdgcn_sched_barrier(0);
-            for (int f = wave; f < 2 * CHUNK_FRAGS; f += 4) dma_fragment(rs_img, f * FRAG + lane * 16, smem + f * FRAG);
+            for (int f = wave; f < 2 * CHUNK_FRAGS; f += 4) dma_fragment(rs_img, lane16, f * FRAG, smem + f * FRAG);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < D / 16; ++s) {
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
 #define DA_STAGE_VARS(i)                                                                                      \
     const unsigned char* base = smem + ((i) % SLOTS) * CHUNK_BYTES + lane * 16;                               \
     const float* aux = reinterpret_cast<const float*>(smem + ((i) % SLOTS) * CHUNK_BYTES + W_FRAGS * FRAG);   \
-    const unsigned nsrc = (i) + 2 < STAGES ? (unsigned)((i) + 2) * CHUNK_BYTES + wave * FRAG + lane * 16 : OOB; \
+    const unsigned nsrc = (i) + 2 < STAGES ? (unsigned)((i) + 2) * CHUNK_BYTES + wave * FRAG : OOB;          \
     unsigned char* ndst = smem + (((i) + 2) % SLOTS) * CHUNK_BYTES + wave * FRAG;
     // end of a stage: everything older than this stage's nine requests (= stage i + 1, requested a stage ago) has landed --
     // loads return in issue order; stages that issue other vector-memory operations behind their requests wait for all

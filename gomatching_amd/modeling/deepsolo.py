@@ -301,6 +301,14 @@ class DeepSolo:
         inter_refs = []
         E = 256
         for lid, L in enumerate(self.dec):
+            refs, tgt = self._decoder_layer(lid, L, tgt, refs, values, geo, B, vr)
+            inter_refs.append(refs)
+        return tgt, inter_refs
+
+    def _decoder_layer(self, lid, L, tgt, refs, values, geo, B, vr):
+        nq, P, E = self.nq, self.P, 256
+        Q = B * nq * P
+        with ops.profile_scope("decoder_layer"):                 # bench.py: the launches that perform a layer's Q-side products
             # reference_points_input = reference_points * valid_ratios; the query position comes from level 0's (:470-473)
             qref = refs if vr is None else ops.scale_xy_(refs.clone(), *geo["vr0"])
             qpos = ops.point_pos_embed(qref, self.dim_t)
@@ -344,8 +352,7 @@ class DeepSolo:
             # reference refinement (:484-488)
             d = self._mlp3(tgt, self.ctrl_coord)
             refs = ops.ref_sigmoid(d, refs, 2)
-            inter_refs.append(refs)
-        return tgt, inter_refs
+        return refs, tgt
 
     @staticmethod
     def _out_norm(x, L, name, tgt):

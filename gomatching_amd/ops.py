@@ -3,6 +3,7 @@
 Every function launches hand-written HIP kernels from libgomatching_hip.so on torch's current stream;
 none has a CPU or torch-op fallback.
 """
+import contextlib
 import ctypes
 
 import numpy as np
@@ -21,6 +22,21 @@ def _L():
 # Optional launch profiler for bench.py's roofline leg: a list that receives (start_event, end_event, flops) for
 # every launch of the dominant kernel (the 128x128-tile plain GEMM).  None = no events recorded.
 _gemm_profile = None
+
+
+_profile_scope = ""
+
+
+@contextlib.contextmanager
+def profile_scope(name):
+    """Every profile record made inside the block carries `name` as its last element (bench.py: which launches belong to the
+    decoder layers)."""
+    global _profile_scope
+    old, _profile_scope = _profile_scope, name
+    try:
+        yield
+    finally:
+        _profile_scope = old
 
 
 def set_gemm_profile(collector):
@@ -127,9 +143,6 @@ def check_range_flag(device):
                                 "or the input was not finite; run with ops.GEMM_MODE = 'bf16x6'")
 
 
-import contextlib
-
-
 @contextlib.contextmanager
 def gemm_mode(mode):
     """Run a block (model construction and / or a forward pass) under another contraction back-end; the model's precision
@@ -194,7 +207,7 @@ def _gemm_split(A, W, bias, scale, A2, rows, R, relu, out, M, r_cols=None, r_per
         e1.record()
         nbytes = 4.0 * M * K + 2.0 * pl.shape[0] * N * pl.shape[2] + 4.0 * M * N \
             + (4.0 * (r_period or M) * rc if R is not None else 0.0)
-        prof.append((e0, e1, 2.0 * M * N * K, nbytes, "%dx%dx%d" % (M, N, K)))
+        prof.append((e0, e1, 2.0 * M * N * K, nbytes, "%dx%dx%d" % (M, N, K), _profile_scope))
     return out
 
 
@@ -272,7 +285,7 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N + (M * N if R is not None else 0)),
-                     "%dx%dx%d" % (M, N, K)))
+                     "%dx%dx%d" % (M, N, K), _profile_scope))
     return out
 
 
@@ -305,7 +318,7 @@ def conv2d_nhwc(x, w_ohwi, scale=None, shift=None, R=None, relu=False, stride=1,
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 _after = lambda: (e1.record(), prof.append((e0, e1, 2.0 * M * Cout * Cin, 4.0 * M * Cin + 4.0 * M * Cout * (
-                    2 if R is not None else 1) + 4.0 * Cout * Cin, "pw:%dx%dx%d" % (M, Cout, Cin))))
+                    2 if R is not None else 1) + 4.0 * Cout * Cin, "pw:%dx%dx%d" % (M, Cout, Cin), _profile_scope)))
             check(_L().gom_conv2d_nhwc_f32_f16x3(_p(x), _p(pl), pl.stride(0), pl.stride(1), _p(w_ohwi.inv_scale),
                                                  _p(scale), _p(shift), _p(R), 1 if relu else 0, _p(y), B, H, Wd, Cin,
                                                  Cout, KH, KW, stride, pad, _p(ws), nbytes, splits,
@@ -426,7 +439,7 @@ def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0,
     if prof is not None:
         e1.record()
         nbytes = 4.0 * M * lin.K * (2 if A2 is not None else 1) + lin.image.numel() + 4.0 * M * N + 4.0 * (r_period or M) * rc
-        prof.append((e0, e1, 2.0 * M * N * lin.K, nbytes, "k256:%dx%dx%d" % (M, N, lin.K)))
+        prof.append((e0, e1, 2.0 * M * N * lin.K, nbytes, "k256:%dx%dx%d" % (M, N, lin.K), _profile_scope))
     return out
 
 
@@ -477,7 +490,7 @@ def proj_ln(x, blk, R, out=None):
                                out.stride(0) if M > 1 else 256, M, _p(range_flag(x.device)), _stream()), "gom_proj_ln_f32")
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * 256 * 256, 12.0 * M * 256 + blk.image.numel(), "projln:%dx256x256" % M))
+        prof.append((e0, e1, 2.0 * M * 256 * 256, 12.0 * M * 256 + blk.image.numel(), "projln:%dx256x256" % M, _profile_scope))
     return out
 
 
@@ -549,7 +562,7 @@ def dec_attn(x, blk, groups, group_tokens, inner=1, pos=None, out=None):
         # the block's nn.Linear products (in_proj 768 + out_proj 256 columns) + QK^T and PV of every head
         flops = 2.0 * rows * 256 * 1024 + 4.0 * rows * group_tokens * 256
         nbytes = 4.0 * rows * 256 * (3 if pos is not None else 2) + blk.image.numel()
-        prof.append((e0, e1, flops, nbytes, "decattn:%s:%dx%d" % ("inter" if blk.inter else "intra", groups, group_tokens)))
+        prof.append((e0, e1, flops, nbytes, "decattn:%s:%dx%d" % ("inter" if blk.inter else "intra", groups, group_tokens), _profile_scope))
     return out
 
 
@@ -590,7 +603,7 @@ def ffn_fused_ln(x, ffn, out=None):
                                     ffn.D, ffn.F, _p(range_flag(x.device)), _stream()), "gom_ffn_fused_ln_f32")
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 4.0 * M * ffn.D * ffn.F, 8.0 * M * ffn.D + ffn.image.numel(), "ffn%dx%dx%d" % (M, ffn.D, ffn.F)))
+        prof.append((e0, e1, 4.0 * M * ffn.D * ffn.F, 8.0 * M * ffn.D + ffn.image.numel(), "ffn%dx%dx%d" % (M, ffn.D, ffn.F), _profile_scope))
     return out
 
 
