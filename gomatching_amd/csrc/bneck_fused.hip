@@ -1,0 +1,307 @@
+// Tail of a ResNet bottleneck block fused with the head of the next one (f16x3 split, fp32-class accuracy):
+//
+//   X  = relu( bn3(conv3_1x1(A)) + R )            A [M, K1] = the block's conv2 output, R [M, 4 K1] = its input / shortcut
+//   Y1 = relu( bn1'(conv1'_1x1(X)) )              the NEXT block's first convolution, MP output channels
+//
+// (Detectron2 BottleneckBlock, STRIDE_IN_1X1 = False, FrozenBN folded into scale / shift: gom_lstmatcher.py:42-61 builds it through
+// build_resnet_backbone)  As two launches the pair moves A + R + X (write) and then X AGAIN (read) + Y1: at res2
+// (K1 = 64, 890 000 pixels per 8 frames) 2.05 + 1.14 GB, the two launches together 0.6 ms -- both HBM streams.  Fused, the block's
+// output X is written once for the next residual and never read back: 2.28 GB.
+//
+// Structure = the fused FFN kernel's (ffn_fused.hip) with the hidden activation also leaving the chip: a workgroup = 4 waves =
+// 128 pixels, a wave's 32 pixels of A stay in registers as MFMA operand fragments; per chunk of 32 X-channels
+//     H^T[32 x 32 px]  = W3c . A^T                      (A operand = weight fragment from LDS, B = the pixels' fragments)
+//     v = H^T * scale + shift + R^T, relu  ->  stored to X (the lane is the pixel: four 16-byte pieces = its half of the 128-byte
+//                                               line of the chunk; the other half-wave writes the other half)
+//     Y1^T[MP x 32 px] += W1'[:, chunk] . v^T           (B operand = v straight from the accumulator registers after the fp16
+//                                               split; the k order that implies is baked into the weight image)
+// and the weights stream through a two-stage LDS ring by LDS-DMA from a fragment-linear image.  The channel counts are template
+// parameters; the small ones leave room for several workgroups per CU, which is what hides the HBM latency of the R / X streams.
+// Plane products in the tile kernel's order; range contract and *flag of gemm_f16x3.hip (A, and X as conv1's operand, within
+// fp16's range; checked in front of the ReLU of Y1).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CH = 32;                                   // X channels per chunk = one 128-byte line per pixel
+constexpr int FRAG = 1024;
+constexpr int BM = 128;
+
+struct BnArgs {
+    const float* A;
+    const unsigned char* img;
+    const float* R;
+    const float* sc1;                                        // [MP] folded scale (BN scale x 1 / weight row scale), shift of conv1'
+    const float* sh1;
+    float* X;
+    float* Y1;
+    int* flag;
+    int lda, ldr, ldx, ldy, M, chunks;
+};
+
+__device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) {
+    const f32x2 v = {x, y};
+    const half2_t h0 = __builtin_convertvector(v, half2_t);
+    const f32x2 b = __builtin_convertvector(h0, f32x2);
+    const f32x2 r = {x - b[0], y - b[1]};
+    const half2_t h1 = __builtin_convertvector(r, half2_t);
+    q0 = __builtin_bit_cast(unsigned int, h0);
+    q1 = __builtin_bit_cast(unsigned int, h1);
+}
+
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8& p0, half8& p1) {
+    unsigned int l0, l1, l2, l3, h0, h1, h2, h3;
+    split2(a[0], a[1], l0, h0);
+    split2(a[2], a[3], l1, h1);
+    split2(b[0], b[1], l2, h2);
+    split2(b[2], b[3], l3, h3);
+    p0 = __builtin_bit_cast(half8, (u32x4{l0, l1, l2, l3}));
+    p1 = __builtin_bit_cast(half8, (u32x4{h0, h1, h2, h3}));
+}
+
+__device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned lane_off, unsigned frag_off, unsigned char* lds_frag) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)lane_off, (int)frag_off, 0, 0);
+}
+
+template <int K1, int MP>
+struct Cfg {
+    static constexpr int W3_FRAGS = (K1 / 16) * 2;           // k-steps x planes
+    static constexpr int W1_FRAGS = (MP / 32) * 2 * 2;       // output tiles x k-steps x planes
+    static constexpr int STAGE_FRAGS = W3_FRAGS + W1_FRAGS + 1;
+    static constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+};
+
+template <int K1, int MP, int OCC>
+__global__ __launch_bounds__(256, OCC) void bneck_kernel(const BnArgs p) {
+    using C = Cfg<K1, MP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const long m = (long)blockIdx.x * BM + wave * 32 + fr;
+    const long row = m < p.M ? m : p.M - 1;                  // tail pixels recompute (and re-store) the last one: same bits
+    const unsigned lane16 = lane * 16;
+
+    const __amdgpu_buffer_rsrc_t rs_img =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, p.chunks * C::STAGE_BYTES, 0x00020000);
+    auto dma_stage = [&](int c, int slot) {
+        for (int f = wave; f < C::STAGE_FRAGS; f += 4)
+            dma_fragment(rs_img, lane16, (unsigned)c * C::STAGE_BYTES + f * FRAG, smem + slot * C::STAGE_BYTES + f * FRAG);
+    };
+
+    // ---- this wave's 32 pixels of A as B-operand fragments (whole K1), the first chunk's residual piece ----
+    float amax = 0.f, chk = 0.f;                             // running |value| of everything split into fp16 planes; NaN / Inf
+                                                             // detector (v * 0 accumulates to NaN): see dec_attn.hip
+    half8 xf[2][K1 / 16];
+    f32x4 rv[4];
+    {
+        const float* xr = p.A + (size_t)row * p.lda + fh * 8;
+        f32x4 ra[K1 / 8];
+#pragma unroll
+        for (int s = 0; s < K1 / 16; ++s) {
+            ra[2 * s] = *reinterpret_cast<const f32x4*>(xr + 16 * s);
+            ra[2 * s + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
+        }
+        const float* rr = p.R + (size_t)row * p.ldr + 4 * fh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(rr + 8 * q);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_stage(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < K1 / 16; ++s) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(ra[2 * s][e]), fabsf(ra[2 * s + 1][e])));
+            split8(ra[2 * s], ra[2 * s + 1], xf[0][s], xf[1][s]);
+        }
+        asm volatile("" : "+v"(amax));
+    }
+
+    f32x16 acc2[MP / 32];
+#pragma unroll
+    for (int t = 0; t < MP / 32; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc2[t][g] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float* xrow = p.X + (size_t)row * p.ldx + 4 * fh;
+    const float* rrow = p.R + (size_t)row * p.ldr + 4 * fh;
+    for (int c = 0; c < p.chunks; ++c) {
+        const int st = c & 1;
+        const unsigned char* base = smem + st * C::STAGE_BYTES + lane16;
+        const float* aux = reinterpret_cast<const float*>(smem + st * C::STAGE_BYTES + (C::W3_FRAGS + C::W1_FRAGS) * FRAG);
+        // the next stage's fragments and the next chunk's residual piece are requested first (they are the OLDEST vector-memory
+        // operations of the chunk: the counted wait at its end lets only this chunk's four X stores stay in flight)
+        if (c + 1 < p.chunks) dma_stage(c + 1, st ^ 1);
+        f32x4 rn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rn[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c + 1 < p.chunks) rn[q] = *reinterpret_cast<const f32x4*>(rrow + CH * (c + 1) + 8 * q);
+        }
+        // ---- H^T chunk = W3c . A^T ----
+        f32x16 acc1;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc1[g] = 0.f;
+#pragma unroll
+        for (int s = 0; s < K1 / 16; ++s) {
+            const half8 w_hi = *reinterpret_cast<const half8*>(base + (2 * s) * FRAG);
+            const half8 w_lo = *reinterpret_cast<const half8*>(base + (2 * s + 1) * FRAG);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_hi, xf[1][s], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_lo, xf[0][s], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_hi, xf[0][s], acc1, 0, 0, 0);
+        }
+        // ---- X chunk = relu(acc * scale + shift + R): stored, and split into the B fragments of the second product ----
+        half8 hf[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 v[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * u + qq;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(aux + 8 * q + 4 * fh);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(aux + CH + 8 * q + 4 * fh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // the tile kernel's epilogue arithmetic: acc * scale + shift + residual, then the ReLU; the finiteness
+                    // check sits in FRONT of the ReLU (fmaxf(NaN, 0) = 0 would hide an operand beyond fp16)
+                    const float t = acc1[4 * q + e] * sc[e] + sh[e] + rv[q][e];
+                    chk = fmaf(t, 0.f, chk);
+                    v[qq][e] = fmaxf(t, 0.f);
+                    amax = fmaxf(amax, v[qq][e]);
+                }
+                // (tail pixels re-store the last pixel's bits: the store is ALWAYS issued, the counted wait below relies on it)
+                *reinterpret_cast<f32x4*>(xrow + CH * c + 8 * q) = v[qq];
+            }
+            split8(v[0], v[1], hf[0][u], hf[1][u]);
+        }
+        // ---- Y1^T += W1'[:, chunk] . X^T ----
+#pragma unroll
+        for (int t = 0; t < MP / 32; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const half8 w_hi = *reinterpret_cast<const half8*>(base + (C::W3_FRAGS + (t * 2 + u) * 2) * FRAG);
+                const half8 w_lo = *reinterpret_cast<const half8*>(base + (C::W3_FRAGS + (t * 2 + u) * 2 + 1) * FRAG);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_hi, hf[1][u], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_lo, hf[0][u], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_hi, hf[0][u], acc2[t], 0, 0, 0);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[q] = rn[q];
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // everything but this chunk's four stores has landed
+        __syncthreads();
+    }
+
+    // ---- Y1 = relu(acc2 * scale + shift): lane = pixel, registers = channels 32 t + 8 q + 4 fh .. + 3 ----
+    float* yrow = p.Y1 + (size_t)row * p.ldy + 4 * fh;
+#pragma unroll
+    for (int t = 0; t < MP / 32; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = 32 * t + 8 * q + 4 * fh;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.sc1 + col);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.sh1 + col);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float tv = acc2[t][4 * q + e] * sc[e] + sh[e];
+                chk = fmaf(tv, 0.f, chk);                      // in front of the ReLU: NaN / Inf -> NaN
+                o[e] = fmaxf(tv, 0.f);
+            }
+            *reinterpret_cast<f32x4*>(yrow + 32 * t + 8 * q) = o;
+        }
+    if ((!(amax <= 65504.f) || !(chk == 0.f)) && p.flag) atomicOr(p.flag, 1);
+}
+
+// Fragment-linear weight image, per chunk c of 32 X-channels; element j of lane l = (r, h):
+//   f = 2 s + p                       (s < K1 / 16)          : plane p of W3s[32 c + r][16 s + 8 h + j]
+//   f = W3_FRAGS + 4 t + 2 u + p      (t < MP / 32, u < 2)   : plane p of W1s[32 t + r][32 c + 16 u + 8 (j >> 2) + 4 h + (j & 3)]
+//   f = W3_FRAGS + W1_FRAGS                                   : floats 0..31 = scale (BN scale x 1 / row scale of W3s), 32..63 = shift
+__global__ __launch_bounds__(256) void bneck_image_kernel(const unsigned short* __restrict__ p3, long ps3, int ld3,
+                                                          const float* __restrict__ inv3, const float* __restrict__ scale3,
+                                                          const float* __restrict__ shift3, const unsigned short* __restrict__ p1,
+                                                          long ps1, int ld1, int k1, int c4, int mp, unsigned short* __restrict__ img) {
+    const int w3f = (k1 / 16) * 2, w1f = (mp / 32) * 4, sf = w3f + w1f + 1;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)(c4 / CH) * sf * 512;
+    if (i >= total) return;
+    const int e = (int)(i % 512), f = (int)((i / 512) % sf), c = (int)(i / (512L * sf));
+    const int l = e >> 3, j = e & 7, r = l & 31, h = l >> 5;
+    if (f < w3f) {
+        const int s = f >> 1, pl = f & 1;
+        img[i] = p3[pl * ps3 + (size_t)(CH * c + r) * ld3 + 16 * s + 8 * h + j];
+    } else if (f < w3f + w1f) {
+        const int id = f - w3f, t = id >> 2, u = (id >> 1) & 1, pl = id & 1;
+        img[i] = p1[pl * ps1 + (size_t)(32 * t + r) * ld1 + CH * c + 16 * u + 8 * (j >> 2) + 4 * h + (j & 3)];
+    } else {
+        const int fi = e >> 1;
+        float v = 0.f;
+        if (fi < CH) v = inv3[CH * c + fi] * (scale3 ? scale3[CH * c + fi] : 1.f);   // exact: the row scale is a power of two
+        else if (fi < 2 * CH) v = shift3 ? shift3[CH * c + fi - CH] : 0.f;
+        const unsigned bits = __builtin_bit_cast(unsigned, v);
+        img[i] = (unsigned short)((e & 1) ? (bits >> 16) : (bits & 0xffffu));
+    }
+}
+
+template <int K1, int MP, int OCC>
+int launch(const BnArgs& a, hipStream_t s) {
+    using C = Cfg<K1, MP>;
+    auto kern = bneck_kernel<K1, MP, OCC>;
+    if (C::LDS_BYTES > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(a.M, BM)), dim3(256), C::LDS_BYTES, s, a);
+    return gom_launch_status();
+}
+
+bool served(int k1, int c4, int mp) {
+    if (c4 != 4 * k1) return false;
+    return (k1 == 64 && (mp == 64 || mp == 128)) || (k1 == 128 && (mp == 128 || mp == 256)) || (k1 == 256 && mp == 256);
+}
+
+}  // namespace
+
+extern "C" long gom_bneck_image_bytes(int k1, int c4, int mp) {
+    if (!served(k1, c4, mp)) return -1;
+    return (long)(c4 / CH) * ((k1 / 16) * 2 + (mp / 32) * 4 + 1) * FRAG;
+}
+
+extern "C" int gom_bneck_image(const void* w3_planes, long w3_plane_stride, int ld3, const float* w3_inv_scale, const float* scale3,
+                               const float* shift3, const void* w1_planes, long w1_plane_stride, int ld1, int k1, int c4, int mp,
+                               void* image, long image_bytes, void* stream) {
+    GOM_CHECK_ARG(w3_planes && w3_inv_scale && w1_planes && image && served(k1, c4, mp) && ld3 >= k1 && ld1 >= c4);
+    GOM_CHECK_ARG(image_bytes >= gom_bneck_image_bytes(k1, c4, mp));
+    const long total = (long)(c4 / CH) * ((k1 / 16) * 2 + (mp / 32) * 4 + 1) * 512;
+    hipLaunchKernelGGL(bneck_image_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)w3_planes, w3_plane_stride, ld3, w3_inv_scale, scale3, shift3,
+                       (const unsigned short*)w1_planes, w1_plane_stride, ld1, k1, c4, mp, (unsigned short*)image);
+    return gom_launch_status();
+}
+
+extern "C" int gom_bneck_f32(const float* A, int lda, const void* image, const float* R, int ldr, const float* scale1,
+                             const float* shift1, float* X, int ldx, float* Y1, int ldy, int M, int k1, int c4, int mp, int* flag,
+                             void* stream) {
+    GOM_CHECK_ARG(A && image && R && scale1 && shift1 && X && Y1 && M >= 0 && served(k1, c4, mp));
+    GOM_CHECK_ARG(lda >= k1 && ldr >= c4 && ldx >= c4 && ldy >= mp && (lda % 4) == 0 && (ldr % 4) == 0 && (ldx % 4) == 0 && (ldy % 4) == 0);
+    GOM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)R % 16) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y1 % 16) == 0 &&
+                  ((uintptr_t)image % 16) == 0 && ((uintptr_t)scale1 % 16) == 0 && ((uintptr_t)shift1 % 16) == 0);
+    if (M == 0) return GOM_OK;
+    BnArgs a{};
+    a.A = A; a.img = (const unsigned char*)image; a.R = R; a.sc1 = scale1; a.sh1 = shift1; a.X = X; a.Y1 = Y1; a.flag = flag;
+    a.lda = lda; a.ldr = ldr; a.ldx = ldx; a.ldy = ldy; a.M = M; a.chunks = c4 / CH;
+    hipStream_t s = (hipStream_t)stream;
+    if (k1 == 64 && mp == 64) return launch<64, 64, 3>(a, s);
+    if (k1 == 64 && mp == 128) return launch<64, 128, 3>(a, s);
+    if (k1 == 128 && mp == 128) return launch<128, 128, 2>(a, s);
+    if (k1 == 128 && mp == 256) return launch<128, 256, 1>(a, s);     // 98 KB of ring: one workgroup per CU
+    return launch<256, 256, 1>(a, s);
+}

@@ -52,6 +52,14 @@ class ResNet50:
                 for c in ("conv1", "conv2", "conv3"):
                     add(p + c)
                 self.blocks.append((stage, p, first_stride if i == 0 else 1, has_sc, i == nblk - 1))
+        # conv3 + residual + ReLU of block k fused with conv1 of block k + 1 (csrc/bneck_fused.hip) where the shapes are served
+        # (res2, res3, inside res4) under the f16x3 back-end: block k's output is written once and never read back by conv1
+        self.fused = {}
+        for (_, p, _, _, _), (_, pn, _, _, _) in zip(self.blocks[:-1], self.blocks[1:]):
+            w3, sc3, sh3 = self.convs[p + "conv3"]
+            w1, sc1, sh1 = self.convs[pn + "conv1"]
+            if ops.BneckFused.serves(w3, w1):
+                self.fused[p] = ops.BneckFused(w3, sc3, sh3, w1, sc1, sh1)
 
     def _conv(self, x, name, stride=1, pad=0, relu=False, R=None):
         w, sc, sh = self.convs[name]
@@ -66,11 +74,16 @@ class ResNet50:
             x = self._conv(x_nhwc4, "stem.conv1", stride=2, pad=3, relu=True)
             x = ops.maxpool3x3s2(x)
         outs = {}
+        y1 = None                                            # conv1 of this block, when the previous block's launch made it
         for stage, p, s, has_sc, last in self.blocks:
             sc = self._conv(x, p + "shortcut", stride=s) if has_sc else x
-            y = self._conv(x, p + "conv1", relu=True)
+            y = y1 if y1 is not None else self._conv(x, p + "conv1", relu=True)
             y = self._conv(y, p + "conv2", stride=s, pad=1, relu=True)
-            x = self._conv(y, p + "conv3", relu=True, R=sc)           # relu(conv3 + shortcut)
+            blk = self.fused.get(p)
+            if blk is not None:
+                x, y1 = ops.bneck_fused(y, blk, sc)                   # relu(conv3 + shortcut) and the next block's conv1
+            else:
+                x, y1 = self._conv(y, p + "conv3", relu=True, R=sc), None
             if last:
                 outs[stage] = x
         return {k: outs[k] for k in self.out_features}

@@ -494,6 +494,57 @@ def proj_ln(x, blk, R, out=None):
     return out
 
 
+BNECK_FUSED = _switch("BNECK_FUSED")   # f16x3 back-end: a bottleneck block's conv3 + residual + ReLU fused with the next block's conv1
+
+
+class BneckFused:
+    """conv3 (1x1, [c4, k1]) + folded BatchNorm + residual + ReLU of one ResNet bottleneck block and conv1 (1x1, [mp, c4]) +
+    folded BatchNorm + ReLU of the NEXT block prepared for gom_bneck_f32 (csrc/bneck_fused.hip): the block's output is written once
+    and never read back."""
+
+    def __init__(self, w3, scale3, shift3, w1, scale1, shift1):
+        assert isinstance(w3, SplitWeight) and isinstance(w1, SplitWeight) and w3.kind == "f16x3" and w1.kind == "f16x3"
+        self.k1, self.c4, self.mp = w3.K, w3.N, w1.N
+        assert w1.K == self.c4
+        nbytes = _L().gom_bneck_image_bytes(self.k1, self.c4, self.mp)
+        if nbytes < 0:
+            raise _lib_mod.GomError("fused bottleneck kernel does not serve %d -> %d -> %d" % (self.k1, self.c4, self.mp))
+        _chk_f32(scale3, shift3, scale1, shift1)
+        p3, p1 = w3.planes, w1.planes
+        self.image = torch.empty((nbytes,), dtype=torch.uint8, device=p3.device)
+        check(_L().gom_bneck_image(_p(p3), p3.stride(0), p3.stride(1), _p(w3.inv_scale), _p(scale3), _p(shift3), _p(p1), p1.stride(0),
+                                   p1.stride(1), self.k1, self.c4, self.mp, _p(self.image), nbytes, _stream()), "gom_bneck_image")
+        self.sc1 = (scale1 * w1.inv_scale).contiguous()          # exact: the row scale is a power of two (the tile kernel's product)
+        self.sh1 = shift1.contiguous()
+
+    @staticmethod
+    def serves(w3, w1):
+        return (BNECK_FUSED and GEMM_MODE == "f16x3" and isinstance(w3, SplitWeight) and isinstance(w1, SplitWeight)
+                and w3.kind == "f16x3" and w1.kind == "f16x3" and w1.K == w3.N
+                and _L().gom_bneck_image_bytes(w3.K, w3.N, w1.N) > 0)
+
+
+def bneck_fused(a, blk, R):
+    """(X, Y1) = (relu(bn3(conv3(a)) + R), relu(bn1'(conv1'(X)))) in one launch; a [B, H, W, k1], R [B, H, W, c4] NHWC."""
+    _chk_f32(a, R)
+    B, H, W, k1 = a.shape
+    assert k1 == blk.k1 and tuple(R.shape) == (B, H, W, blk.c4) and a.is_contiguous() and R.is_contiguous()
+    M = B * H * W
+    X = torch.empty((B, H, W, blk.c4), dtype=_f32, device=a.device)
+    Y1 = torch.empty((B, H, W, blk.mp), dtype=_f32, device=a.device)
+    prof = _gemm_profile if (_gemm_profile is not None and M > 0) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().gom_bneck_f32(_p(a), k1, _p(blk.image), _p(R), blk.c4, _p(blk.sc1), _p(blk.sh1), _p(X), blk.c4, _p(Y1), blk.mp, M,
+                             blk.k1, blk.c4, blk.mp, _p(range_flag(a.device)), _stream()), "gom_bneck_f32")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * blk.c4 * (blk.k1 + blk.mp), 4.0 * M * (blk.k1 + 2 * blk.c4 + blk.mp) + blk.image.numel(),
+                     "bneck:%dx%dx%dx%d" % (M, blk.k1, blk.c4, blk.mp), _profile_scope))
+    return X, Y1
+
+
 DEC_ATTN = _switch("DEC_ATTN")       # f16x3 back-end: the decoder's intra / inter self-attention blocks as one launch each
 DEC_ATTN_INTRA = _switch("DEC_ATTN_INTRA")
 DEC_ATTN_INTER = _switch("DEC_ATTN_INTER")

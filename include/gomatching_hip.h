@@ -151,6 +151,22 @@ int gom_proj_ln_f32(const float* X, int ldx, const void* image, const float* w_i
                     int ldr, const float* gamma, const float* beta, float eps, float* Y, int ldy, int M, int* flag,
                     void* stream);
 
+/* Tail of a ResNet bottleneck block fused with the head of the next (csrc/bneck_fused.hip; Detectron2 BottleneckBlock as built
+ * through gom_lstmatcher.py:42-61, STRIDE_IN_1X1 = False, FrozenBN folded):
+ *     X  = relu(scale3 * (A W3^T) + shift3 + R)       A [M, k1] conv2's output, R / X [M, c4 = 4 k1] (X must not alias R)
+ *     Y1 = relu(scale1 * (X W1^T) + shift1)           [M, mp]: the next block's conv1
+ * X is written once and never read back.  Served (k1, mp): (64, 64 | 128), (128, 128 | 256), (256, 256); gom_bneck_image_bytes
+ * returns -1 otherwise.  gom_bneck_image: one-time weight preparation from the gom_split_f16x2 planes of conv3's [c4, k1] and the
+ * next conv1's [mp, c4] matrices; scale3 / shift3 = conv3's folded BatchNorm (its weight row scales are folded in here), scale1
+ * must already hold conv1's folded BatchNorm scale TIMES its weight's inverse row scales.  f16x3 scheme, range contract and *flag
+ * of gom_gemm_f32_f16x3; X equals that kernel's conv3 output up to the ReLU'd last bit, Y1 to summation order. */
+long gom_bneck_image_bytes(int k1, int c4, int mp);
+int gom_bneck_image(const void* w3_planes, long w3_plane_stride, int ld3, const float* w3_inv_scale, const float* scale3,
+                    const float* shift3, const void* w1_planes, long w1_plane_stride, int ld1, int k1, int c4, int mp, void* image,
+                    long image_bytes, void* stream);
+int gom_bneck_f32(const float* A, int lda, const void* image, const float* R, int ldr, const float* scale1, const float* shift1,
+                  float* X, int ldx, float* Y1, int ldy, int M, int k1, int c4, int mp, int* flag, void* stream);
+
 /* The two self-attention blocks of a DeepSolo composite decoder layer, each as ONE launch (csrc/dec_attn.hip), replacing
  * nn.MultiheadAttention + residual + LayerNorm of deformable_transformer.py:386-394 (inter = 0: attention over the
  * `group_tokens` <= 32 points of a query, q = k = X + P, v = X; rows of a group are consecutive) and :396-404 (inter = 1:
