@@ -506,11 +506,11 @@ class BneckFused:
         assert isinstance(w3, SplitWeight) and isinstance(w1, SplitWeight) and w3.kind == "f16x3" and w1.kind == "f16x3"
         self.k1, self.c4, self.mp = w3.K, w3.N, w1.N
         assert w1.K == self.c4
+        _chk_f32(scale3, shift3, scale1, shift1)
+        p3, p1 = w3.planes, w1.planes
         nbytes = _L().gom_bneck_image_bytes(self.k1, self.c4, self.mp)
         if nbytes < 0:
             raise _lib_mod.GomError("fused bottleneck kernel does not serve %d -> %d -> %d" % (self.k1, self.c4, self.mp))
-        _chk_f32(scale3, shift3, scale1, shift1)
-        p3, p1 = w3.planes, w1.planes
         self.image = torch.empty((nbytes,), dtype=torch.uint8, device=p3.device)
         check(_L().gom_bneck_image(_p(p3), p3.stride(0), p3.stride(1), _p(w3.inv_scale), _p(scale3), _p(shift3), _p(p1), p1.stride(0),
                                    p1.stride(1), self.k1, self.c4, self.mp, _p(self.image), nbytes, _stream()), "gom_bneck_image")

@@ -155,7 +155,7 @@ int gom_proj_ln_f32(const float* X, int ldx, const void* image, const float* w_i
  * through gom_lstmatcher.py:42-61, STRIDE_IN_1X1 = False, FrozenBN folded):
  *     X  = relu(scale3 * (A W3^T) + shift3 + R)       A [M, k1] conv2's output, R / X [M, c4 = 4 k1] (X must not alias R)
  *     Y1 = relu(scale1 * (X W1^T) + shift1)           [M, mp]: the next block's conv1
- * X is written once and never read back.  Served (k1, mp): (64, 64 | 128), (128, 128 | 256), (256, 256); gom_bneck_image_bytes
+ * X is written once and never read back.  Served (k1, mp): (64, 64 | 128), (128, 128 | 256); gom_bneck_image_bytes
  * returns -1 otherwise.  gom_bneck_image: one-time weight preparation from the gom_split_f16x2 planes of conv3's [c4, k1] and the
  * next conv1's [mp, c4] matrices; scale3 / shift3 = conv3's folded BatchNorm (its weight row scales are folded in here), scale1
  * must already hold conv1's folded BatchNorm scale TIMES its weight's inverse row scales.  f16x3 scheme, range contract and *flag

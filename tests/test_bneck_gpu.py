@@ -8,7 +8,7 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("k1,mp,hw", [(64, 64, (13, 21)), (64, 128, (9, 30)), (128, 128, (12, 11)), (128, 256, (7, 19)),
-                                      (256, 256, (9, 15)), (64, 64, (125, 223))])
+                                      (64, 64, (125, 223))])
 def test_fused_pair_equals_two_launches(k1, mp, hw):
     from gomatching_amd import ops
     g = torch.Generator().manual_seed(k1 + mp + hw[0])
