@@ -275,7 +275,7 @@ def main():
             except Exception as e:                               # a scheduling aid only: never let it cost the run
                 print("bench: CU reservation for the tracker unavailable (%s: %s); continuing without" % (type(e).__name__, e),
                       file=sys.stderr, flush=True)
-                model._lane_stream = model._det_stream = None
+                model.reserve_tracker_cus(0)
         if not shifts:
             shifts["s"], shifts["r"] = calibrate(model, cal_inputs, frac=args.detect_frac)
         else:

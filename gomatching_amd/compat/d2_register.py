@@ -111,11 +111,17 @@ class GoMatchingMI355X(nn.Module):
         self._impl = None
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
-    def _version(self):
-        return tuple(p._version for p in self.parameters()) + (str(self._device),)
+    def _version(self, frozen_only=False):
+        return tuple(p._version for k, p in self.named_parameters() if not (frozen_only and k.startswith("roi_heads."))) \
+            + tuple(b._version for _, b in self.named_buffers()) + (str(self._device),)
 
-    def impl(self):
-        """The HIP model, rebuilt when a parameter changed (optimizer step, checkpoint load, .to())."""
+    def impl(self, for_training=False):
+        """The HIP model, rebuilt when a parameter changed (optimizer step, checkpoint load, .to()).  `for_training`: the caller
+        (training.forward_losses) uses only the FROZEN detector of the HIP model and reads the head from the live parameters, so
+        an optimizer step -- which bumps the versions of `roi_heads.*` only (freeze_layers.py:20-37) -- must not re-prepare the
+        backbone and DeepSolo every iteration; the first inference call after training sees the head's new versions and rebuilds."""
+        if for_training and self._impl is not None and getattr(self, "_impl_frozen_version", None) == self._version(True):
+            return self._impl
         v = self._version()
         if self._impl is None or self._impl_version != v:
             from ..modeling import GoMatching
@@ -125,6 +131,7 @@ class GoMatchingMI355X(nn.Module):
             sd = {k: t.detach() for k, t in self.state_dict().items()}
             self._impl = GoMatching(self.cfg, sd, device=dev)
             self._impl_version = v
+            self._impl_frozen_version = self._version(True)
         return self._impl
 
     def __getattr__(self, name):

@@ -356,14 +356,11 @@ extern "C" int gom_gemm_k256_rp_f32(const float* A, const float* A2, int lda, co
     a.lda = lda; a.ldr = ldr; a.ldc = ldc; a.M = M; a.chunks = chunks; a.cpg = cdiv(chunks, groups);
     a.r_chunks = R ? r_cols / CW : 0; a.relu = relu ? 1 : 0; a.r_period = r_period;
     const dim3 grid((unsigned)tiles, (unsigned)cdiv(chunks, a.cpg));
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_k256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)gemm_k256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-        attr_set = true;
-    }
+    // (the attribute is per DEVICE: set on every launch -- a process-wide flag would miss a second GPU; it costs ~1 us)
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_k256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)gemm_k256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
     // whole-line stores for long problems (>= one round of two workgroups per CU), see the kernel's header
     const bool lines = g_k256_lines < 0 ? tiles >= 512 : g_k256_lines != 0;
     if (lines) hipLaunchKernelGGL(gemm_k256_kernel<true>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, a);

@@ -89,12 +89,9 @@ extern "C" int gom_topk_tokens(const float* logits, int ld, const unsigned char*
                        invalid_logit, S, k, cand, chunks);
     auto kern = topk_merge_kernel;
     const int lds = MERGE_MAX * sizeof(unsigned long long);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-        attr_set = true;
-    }
+    // (the attribute is per DEVICE: set on every launch -- a process-wide flag would miss a second GPU; it costs ~1 us)
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(1024), lds, s, cand, chunks * k, k, S, idx_out, rows_out);
     return gom_launch_status();
 }

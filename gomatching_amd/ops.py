@@ -364,7 +364,17 @@ def masked_stream(mask_words, device):
     out = ctypes.c_void_p()
     with torch.cuda.device(device):
         check(_L().gom_stream_create_cu_mask(arr, len(mask_words), ctypes.byref(out)), "gom_stream_create_cu_mask")
-    return torch.cuda.ExternalStream(out.value, device=device)
+    st = torch.cuda.ExternalStream(out.value, device=device)
+    st._gom_handle = out.value                                 # ExternalStream does not own the queue: release_masked_stream
+    return st
+
+
+def release_masked_stream(st):
+    """Destroy the hardware queue behind a `masked_stream` (after a device synchronise: nothing may be queued on it)."""
+    h = getattr(st, "_gom_handle", None)
+    if h:
+        st._gom_handle = None
+        check(_L().gom_stream_destroy(ctypes.c_void_p(h)), "gom_stream_destroy")
 
 
 K256_GEMM = _switch("K256_GEMM")   # f16x3 back-end: K = 256 products on the row-resident kernel where it measures faster (below)

@@ -434,7 +434,7 @@ def forward_losses(model, batched_inputs):
     from . import ops
     from .predictor import new_time_cost
     if hasattr(model, "impl"):                                   # the META_ARCH wrapper: live nn.Parameters
-        impl = model.impl()
+        impl = model.impl(for_training=True)
         params = {k: p for k, p in model.named_parameters() if k.startswith("roi_heads.")}
     else:                                                        # the HIP model itself: its own trainable copies
         impl = model

@@ -47,4 +47,10 @@ def test_meta_arch_wrapper_reproduces_reference_ids():
     assert model.impl() is impl                                   # not rebuilt while the parameters are unchanged
     with torch.no_grad():
         model.roi_heads.rescoring_head.bias.add_(1.0)             # an optimizer step would do this
-    assert model.impl() is not impl
+    assert model.impl(for_training=True) is impl                  # the training entry only needs the FROZEN detector: kept
+    new = model.impl()                                            # inference sees the head's new version: rebuilt
+    assert new is not impl
+    with torch.no_grad():
+        model.backbone_conv_probe = None
+        next(p for k, p in model.named_parameters() if not k.startswith("roi_heads.")).add_(0.0)   # a frozen weight touched
+    assert model.impl(for_training=True) is not new               # ... now the training entry rebuilds as well
