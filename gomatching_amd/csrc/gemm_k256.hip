@@ -10,7 +10,9 @@
 // 128 VGPRs -- the fused FFN kernel's scheme, ffn_fused.hip), then per 32 output columns 48 MFMAs whose weight fragments stream
 // through a two-stage LDS ring by LDS-DMA from a fragment-linear image (no VALU, no bank conflicts, one barrier per 48 MFMAs),
 // and the accumulator goes straight to global memory (row of A = lane, 4 consecutive columns per register quad: 16-byte
-// stores).  blockIdx.y splits the columns so that a launch has ~2 workgroups per CU.
+// stores).  blockIdx.y can split the columns over several workgroups (col_groups; <= 0 = ~2 workgroups per CU): every group
+// then re-splits its rows, and in the step one group measured faster (689 vs 878 us for the decoder's 30 launches) -- the
+// product launches with col_groups = 1, tests force the others.
 // The plane products run in the tile kernel's order (A-lo x W-hi, A-hi x W-lo, A-hi x W-hi per 16-wide k-step, k ascending),
 // and the epilogue is the same fma: results are bit-identical to gom_gemm_f32_f16x3 (tests/test_gemm_k256_gpu.py).
 #include "common.h"

@@ -419,7 +419,9 @@ def k256_linear(w, bias=None):
 
 def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0, r_period=0):
     """act((x [+ A2]) @ W^T + b [+ R]) for `lin` = K256Linear or a (weight, bias) pair; r_period > 0: row m adds
-    R[m % r_period] (ops.gemm)."""
+    R[m % r_period] (ops.gemm).  `groups`: column groups of the row-resident kernel's launch; the product always launches ONE
+    (every workgroup splits its rows once and walks all columns): splitting the columns over more workgroups re-splits the
+    rows per group and measured slower in the step (the decoder's 30 launches: 689 -> 878 us, bench.py same box)."""
     if not isinstance(lin, K256Linear):
         return gemm(x, lin[0], bias=lin[1], A2=A2, R=R, relu=relu, r_cols=r_cols, out=out, r_period=r_period)
     M = x.shape[0]

@@ -51,6 +51,5 @@ def test_meta_arch_wrapper_reproduces_reference_ids():
     new = model.impl()                                            # inference sees the head's new version: rebuilt
     assert new is not impl
     with torch.no_grad():
-        model.backbone_conv_probe = None
         next(p for k, p in model.named_parameters() if not k.startswith("roi_heads.")).add_(0.0)   # a frozen weight touched
     assert model.impl(for_training=True) is not new               # ... now the training entry rebuilds as well
