@@ -29,10 +29,9 @@ struct Split2 {
     half2_t hi, lo;
 };
 __device__ __forceinline__ Split2 split2(float x, float y) {
-    const f32x2 v = {x, y};
-    const half2_t h0 = __builtin_convertvector(v, half2_t);
-    const f32x2 r = v - __builtin_convertvector(h0, f32x2);
-    return Split2{h0, __builtin_convertvector(r, half2_t)};
+    unsigned int hi, lo;
+    gom_split2_f16(x, y, hi, lo);
+    return Split2{__builtin_bit_cast(half2_t, hi), __builtin_bit_cast(half2_t, lo)};
 }
 #define SPLIT2_INTO(x, y, P0, P1, i)        \
     do {                                    \

@@ -61,15 +61,7 @@ struct DecArgs {
     int inner;                                               // inter: rows between consecutive tokens of a group (= points)
 };
 
-__device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) {
-    const f32x2 v = {x, y};
-    const half2_t h0 = __builtin_convertvector(v, half2_t);
-    const f32x2 b = __builtin_convertvector(h0, f32x2);
-    const f32x2 r = {x - b[0], y - b[1]};
-    const half2_t h1 = __builtin_convertvector(r, half2_t);
-    q0 = __builtin_bit_cast(unsigned int, h0);
-    q1 = __builtin_bit_cast(unsigned int, h1);
-}
+__device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) { gom_split2_f16(x, y, q0, q1); }
 
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8& p0, half8& p1) {
     unsigned int l0, l1, l2, l3, h0, h1, h2, h3;

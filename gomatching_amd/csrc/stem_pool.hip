@@ -43,14 +43,7 @@ struct StemArgs {
     int H, W, OH, OW, PH, PW, ldw, tiles_h, tiles_w;
 };
 
-__device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) {
-    const f32x2 v = {x, y};
-    const half2_t h0 = __builtin_convertvector(v, half2_t);
-    const f32x2 r = v - __builtin_convertvector(h0, f32x2);
-    const half2_t h1 = __builtin_convertvector(r, half2_t);
-    q0 = __builtin_bit_cast(unsigned int, h0);
-    q1 = __builtin_bit_cast(unsigned int, h1);
-}
+__device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) { gom_split2_f16(x, y, q0, q1); }
 __device__ __forceinline__ void split4(const f32x4 v, u32x2& p0, u32x2& p1) {
     unsigned int a0, a1, b0, b1;
     split2(v[0], v[1], a0, a1);

@@ -128,6 +128,31 @@ def test_gemm_split_epilogue_gather_and_extremes(kind):
         ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
 
 
+def test_f16x3_activation_split_equals_the_numpy_statement():
+    """The in-kernel split of an activation (v_cvt_pk_f16_f32 + one v_fma_mix_f32 per residual, csrc/common.h) gives the planes
+    of tests/test_f16x3_cpu.py's numpy statement: against an identity weight the product is x0 + x1 exactly (fp32 holds the
+    22-bit sum), for ordinary values, fp16 rounding ties, values below fp16's normal range and the largest legal magnitudes."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    K = 64
+    x = torch.randn(4096, K, generator=g) * torch.logspace(-9, 4.5, 4096).view(-1, 1)
+    x[0, :] = torch.tensor([1.0 + 2.0 ** -11, 2048.0 + 1.0, 65504.0, -65504.0] * (K // 4))       # exact ties, the range's edge
+    x[1, :] = torch.tensor([6e-8, -6e-8, 3e-5, 1e-30] * (K // 4))
+    x = x.clamp(-65504.0, 65504.0)
+    eye = torch.eye(K)
+    out = ops.gemm(x.to(DEV), ops.split_weight(eye.to(DEV), kind="f16x3")).cpu()
+    xn = x.numpy()
+    x0 = xn.astype(np.float16)
+    x1 = (xn - x0.astype(np.float32)).astype(np.float16)
+    ref = x0.astype(np.float32) + x1.astype(np.float32)
+    assert np.array_equal(out.numpy(), ref)
+    lin = ops.K256Linear(ops.split_weight(torch.eye(256).to(DEV), kind="f16x3"), None)            # the row-resident kernels' split
+    x4 = torch.cat([x, x, x, x], 1)
+    out4 = ops.linear(x4.to(DEV), lin, groups=1).cpu()
+    assert np.array_equal(out4.numpy(), np.concatenate([ref] * 4, 1))
+    ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
+
+
 def test_f16x3_range_flag_is_raised_in_front_of_every_relu():
     """An activation beyond fp16's range splits into (Inf, -Inf) planes whose products sum to NaN, and fmaxf(NaN, 0) = 0: every
     f16x3 epilogue with a ReLU checks the PRE-activation value, so such a result is flagged, never silently zeroed -- the tile
