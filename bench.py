@@ -43,7 +43,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha1()
     for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "proj_ln.hip", "msda.hip",
-                 "common.h"):
+                 "dec_attn.hip", "bneck_fused.hip", "common.h"):
         with open(os.path.join(ROOT, "gomatching_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -415,7 +415,8 @@ def main():
     all_prof = prof
     # the dominant kernel = the 128x128 tile kernel: every launch of it in the step, through the GEMM API and as the backbone's
     # pointwise convolutions ("pw:", the same instantiation: csrc/gemm_f16x3.hip dispatch<0, 0>)
-    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:", "decattn:")))]
+    bn_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("bneck:")]     # fused bottleneck tail + next head launches
+    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:", "decattn:", "bneck:")))]
     dur_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     flops = sum(p[2] for p in prof)
     alg_bytes = sum(p[3] for p in prof)
@@ -583,6 +584,19 @@ def main():
                     "the row-resident K = 256 kernel (both forms) and out_proj + LayerNorm",
             "achieved": both_fl / (both_ms * 1e-3) / 1e12, "frac": both_fl / (both_ms * 1e-3) / 1e12 / PEAKS[args.gemm][1],
             "share_of_step_time": (both_ms / PROFILE_STEPS) / (elapsed / args.steps * 1e3)}
+    if bn_prof:
+        bd = sum(p_[0].elapsed_time(p_[1]) for p_ in bn_prof)
+        bb, bf = sum(p_[3] for p_ in bn_prof), sum(p_[2] for p_ in bn_prof)
+        line["roofline_bneck"] = {
+            "bound": "hbm", "kernel": "bneck_kernel<K1,MP,OCC>", "achieved": bb / (bd * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
+            "frac": bb / (bd * 1e-3) / 1e12 / 8.0, "traffic": pmc_traffic("bneck_kernel"),
+            "mfma_view": {"achieved": bf / (bd * 1e-3) / 1e12, "peak": PEAKS["f16x3"][1], "unit": "TFLOP/s",
+                          "frac": bf / (bd * 1e-3) / 1e12 / PEAKS["f16x3"][1]},
+            "launches_per_step": len(bn_prof) // PROFILE_STEPS, "avg_launch_us": bd * 1e3 / len(bn_prof),
+            "share_of_step_time": (bd / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
+            "note": "conv3 + BN + residual + ReLU of a ResNet bottleneck block and conv1 + BN + ReLU of the next in one launch "
+                    "(res2 / res3: csrc/bneck_fused.hip): the block's output is written once and not read back by conv1; 26-50 "
+                    "FLOP per byte, an HBM-stream kernel"}
     if dec_prof:
         T_ = cfg.MODEL.TRANSFORMER
         rows = FRAMES_PER_GPU * T_.NUM_QUERIES * T_.NUM_POINTS

@@ -31,6 +31,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CH = 32;                                   // X channels per chunk = one 128-byte line per pixel
 constexpr int FRAG = 1024;
 constexpr int BM = 128;
+constexpr int XT_ROW = 36;                               // floats per pixel row of a wave's transpose tile (32 + 4: conflict-free b128)
+// a wave's transpose tile holds XTR = 32 or 16 of its pixels x 32 channels; with 16 the pixels pass in two halves (half the LDS:
+// one more workgroup per CU at the wider shapes; slower where the whole tile fits anyway -- 64 -> 256 -> 64: 422 vs 678 us)
 
 struct BnArgs {
     const float* A;
@@ -66,7 +69,9 @@ struct Cfg {
     static constexpr int W1_FRAGS = (MP / 32) * 2 * 2;       // output tiles x k-steps x planes
     static constexpr int STAGE_FRAGS = W3_FRAGS + W1_FRAGS + 1;
     static constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int XTR = (K1 == 64 && MP == 64) ? 32 : 16;
+    static constexpr int XT_BYTES = XTR * XT_ROW * 4;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES + 4 * XT_BYTES;
 };
 
 template <int K1, int MP, int OCC>
@@ -91,7 +96,20 @@ __global__ __launch_bounds__(256, OCC) void bneck_kernel(const BnArgs p) {
     float amax = 0.f, chk = 0.f;                             // running |value| of everything split into fp16 planes; NaN / Inf
                                                              // detector (v * 0 accumulates to NaN): see dec_attn.hip
     half8 xf[2][K1 / 16];
-    f32x4 rv[4];
+    // R in and X out move as WHOLE 128-byte lines: lane l handles 16-byte piece (l & 7) of pixels (l >> 3) + 8 i of the wave's 32
+    // (i = 0..3), i.e. a wave-instruction touches 8 lines -- the accumulator layout (lane = pixel, 16 bytes of its half of the
+    // line) touches 32 lines of 32 bytes, and the texture-address unit pays per line (profiles/r03_msda_ta_counters.txt: ~3.6 cycles):
+    // measured 538 -> see tools/bneck_bench.py.  The two layouts meet in a wave-private LDS tile (no barrier: one wave).
+    long crow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long mm = (long)blockIdx.x * BM + wave * 32 + (lane >> 3) + 8 * i;
+        crow[i] = mm < p.M ? mm : p.M - 1;
+    }
+    const int cpc = (lane & 7) * 4;
+    float* xt = reinterpret_cast<float*>(smem + 2 * C::STAGE_BYTES + wave * C::XT_BYTES);
+    constexpr int XTR = C::XTR, PASSES = 32 / XTR, RPP = XTR / 8;     // pixels per pass, passes, row-layout instructions per pass
+    f32x4 rv[4];                                             // the chunk's residual piece in the coalesced layout
     {
         const float* xr = p.A + (size_t)row * p.lda + fh * 8;
         f32x4 ra[K1 / 8];
@@ -100,9 +118,8 @@ __global__ __launch_bounds__(256, OCC) void bneck_kernel(const BnArgs p) {
             ra[2 * s] = *reinterpret_cast<const f32x4*>(xr + 16 * s);
             ra[2 * s + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
         }
-        const float* rr = p.R + (size_t)row * p.ldr + 4 * fh;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(rr + 8 * q);
+        for (int i = 0; i < 4; ++i) rv[i] = *reinterpret_cast<const f32x4*>(p.R + (size_t)crow[i] * p.ldr + cpc);
         __builtin_amdgcn_sched_barrier(0);
         dma_stage(0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -124,8 +141,6 @@ __global__ __launch_bounds__(256, OCC) void bneck_kernel(const BnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    float* xrow = p.X + (size_t)row * p.ldx + 4 * fh;
-    const float* rrow = p.R + (size_t)row * p.ldr + 4 * fh;
     for (int c = 0; c < p.chunks; ++c) {
         const int st = c & 1;
         const unsigned char* base = smem + st * C::STAGE_BYTES + lane16;
@@ -137,7 +152,23 @@ __global__ __launch_bounds__(256, OCC) void bneck_kernel(const BnArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             rn[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (c + 1 < p.chunks) rn[q] = *reinterpret_cast<const f32x4*>(rrow + CH * (c + 1) + 8 * q);
+            if (c + 1 < p.chunks) rn[q] = *reinterpret_cast<const f32x4*>(p.R + (size_t)crow[q] * p.ldr + CH * (c + 1) + cpc);
+        }
+        // this chunk's residual piece: coalesced layout -> the wave's LDS tile -> accumulator layout, XTR pixels at a time
+        f32x4 ra4[4];
+#pragma unroll
+        for (int hp = 0; hp < PASSES; ++hp) {
+#pragma unroll
+            for (int i = 0; i < RPP; ++i) *reinterpret_cast<f32x4*>(xt + ((lane >> 3) + 8 * i) * XT_ROW + cpc) = rv[RPP * hp + i];
+            // lanes exchange data through the tile: the wave barriers are CONVERGENT points the compiler may not move into the
+            // divergent halves -- without them it threaded `if (A) read; write; if (!A) read` into `if (A) {read; write} else
+            // {write; read}`, whose halves run one after the other: the second half's readers saw stale rows
+            __builtin_amdgcn_wave_barrier();
+            if (PASSES == 1 || (fr >> 4) == hp) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ra4[q] = *reinterpret_cast<const f32x4*>(xt + (fr & (XTR - 1)) * XT_ROW + 8 * q + 4 * fh);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         // ---- H^T chunk = W3c . A^T ----
         f32x16 acc1;
@@ -153,6 +184,7 @@ __global__ __launch_bounds__(256, OCC) void bneck_kernel(const BnArgs p) {
         }
         // ---- X chunk = relu(acc * scale + shift + R): stored, and split into the B fragments of the second product ----
         half8 hf[2][2];
+        f32x4 vx[4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             f32x4 v[2];
@@ -165,15 +197,30 @@ __global__ __launch_bounds__(256, OCC) void bneck_kernel(const BnArgs p) {
                 for (int e = 0; e < 4; ++e) {
                     // the tile kernel's epilogue arithmetic: acc * scale + shift + residual, then the ReLU; the finiteness
                     // check sits in FRONT of the ReLU (fmaxf(NaN, 0) = 0 would hide an operand beyond fp16)
-                    const float t = acc1[4 * q + e] * sc[e] + sh[e] + rv[q][e];
+                    const float t = acc1[4 * q + e] * sc[e] + sh[e] + ra4[q][e];
                     chk = fmaf(t, 0.f, chk);
                     v[qq][e] = fmaxf(t, 0.f);
                     amax = fmaxf(amax, v[qq][e]);
                 }
-                // (tail pixels re-store the last pixel's bits: the store is ALWAYS issued, the counted wait below relies on it)
-                *reinterpret_cast<f32x4*>(xrow + CH * c + 8 * q) = v[qq];
+                vx[q] = v[qq];
             }
             split8(v[0], v[1], hf[0][u], hf[1][u]);
+        }
+        // the X chunk leaves as whole lines, XTR pixels at a time through the tile (tail pixels re-store the last pixel's bits: the
+        // four stores are ALWAYS issued, the counted wait below relies on it)
+#pragma unroll
+        for (int hp = 0; hp < PASSES; ++hp) {
+            if (PASSES == 1 || (fr >> 4) == hp) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(xt + (fr & (XTR - 1)) * XT_ROW + 8 * q + 4 * fh) = vx[q];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < RPP; ++i) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(xt + ((lane >> 3) + 8 * i) * XT_ROW + cpc);
+                *reinterpret_cast<f32x4*>(p.X + (size_t)crow[RPP * hp + i] * p.ldx + CH * c + cpc) = o;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         // ---- Y1^T += W1'[:, chunk] . X^T ----
 #pragma unroll
@@ -294,7 +341,7 @@ extern "C" int gom_bneck_f32(const float* A, int lda, const void* image, const f
     a.lda = lda; a.ldr = ldr; a.ldx = ldx; a.ldy = ldy; a.M = M; a.chunks = c4 / CH;
     hipStream_t s = (hipStream_t)stream;
     if (k1 == 64 && mp == 64) return launch<64, 64, 3>(a, s);
-    if (k1 == 64 && mp == 128) return launch<64, 128, 3>(a, s);
+    if (k1 == 64 && mp == 128) return launch<64, 128, 2>(a, s);        // 59 KB of LDS: two workgroups per CU
     if (k1 == 128 && mp == 128) return launch<128, 128, 2>(a, s);
     return launch<128, 256, 1>(a, s);                        // 98 KB of ring: one workgroup per CU
 }

@@ -19,6 +19,8 @@ def per_kernel(path, counter, api_grids):
             name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
             name = name.split("(")[0].replace(" ", "")
             agg[name].append(float(r["Counter_Value"]))
+            if name.startswith("bneck_kernel<"):             # every instantiation of the fused bottleneck kernel together as well
+                agg["bneck_kernel"].append(float(r["Counter_Value"]))
             if name.startswith("gemm_f16x3_kernel<128,128,0,0") or name.startswith("gemm_bf16x6_kernel<128,128,0,0") or \
                     name.startswith("gemm_f32_kernel<128,128,64,64,0,0"):
                 if api_grids:                                # the two populations of the instantiation, apart as well
@@ -32,14 +34,14 @@ def kernel_source_hash():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha1()
     for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "proj_ln.hip", "msda.hip",
-                 "common.h"):
+                 "dec_attn.hip", "bneck_fused.hip", "common.h"):
         with open(os.path.join(root, "gomatching_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
 def main():
-    tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
     api_grids = set(json.load(open(sys.argv[4]))) if len(sys.argv) > 4 else set()      # work-items of the GEMM-API launches
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE", api_grids), per_kernel(sys.argv[2], "WRITE_SIZE", api_grids)
     out = {"_meta": {"kernel_source_hash": kernel_source_hash(), "round": tag,

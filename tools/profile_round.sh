@@ -2,7 +2,7 @@
 # Round profiles (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats, the two PMC passes, per-shape GEMM
 # trace.  Everything lands under gpurun_out/final/; copy what is judged into profiles/.
 #   usage: bash tools/profile_round.sh [tag]
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/final
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
