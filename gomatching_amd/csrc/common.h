@@ -49,3 +49,70 @@ __device__ __forceinline__ void gom_split2_f16(float x, float y, unsigned int& h
     const gom_f2 r = {rx, ry};
     lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(r, gom_h2));
 }
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// eight fp32 values -> one MFMA operand fragment piece per plane (hi, lo)
+__device__ __forceinline__ void gom_split8_f16(const f32x4 a, const f32x4 b, half8& p0, half8& p1) {
+    typedef unsigned int gom_u4 __attribute__((ext_vector_type(4)));
+    unsigned int l0, l1, l2, l3, h0, h1, h2, h3;
+    gom_split2_f16(a[0], a[1], l0, h0);
+    gom_split2_f16(a[2], a[3], l1, h1);
+    gom_split2_f16(b[0], b[1], l2, h2);
+    gom_split2_f16(b[2], b[3], l3, h3);
+    p0 = __builtin_bit_cast(half8, (gom_u4{l0, l1, l2, l3}));
+    p1 = __builtin_bit_cast(half8, (gom_u4{h0, h1, h2, h3}));
+}
+
+// A wave's 32 rows x 256 fp32 -> the two fp16 planes of its MFMA operand fragments: lane (r = lane & 31, h = lane >> 5) ends up
+// with floats 16 s + 8 h .. + 7 of row r for every k-step s, xf[plane][s].  Loading that layout straight from memory makes every
+// wave-instruction touch 32 lines (16-byte pieces of 32 rows), and the texture-address unit pays per LINE (~3.6 cycles,
+// profiles/r03_msda_ta_counters.txt): the 128 such instructions of a 128-row tile cost it ~14 000 cycles -- which is what the
+// prologue of every row-resident kernel measured (ffn_fused.hip: 14.2k).  Here the rows are loaded as WHOLE lines (a wave-
+// instruction = W floats of 256 / W rows: 8 lines) and change layout in a wave-private LDS scratch of 32 x W fp32 (16-byte
+// pieces XOR-swizzled by the row: conflict-free both ways), W of a row's 256 floats at a time.  `row_a(r)` / `row_b(r)` return
+// the address of row r (0..31) of the wave; ADD: the fragments are those of row_a + row_b.  `amax` = running largest magnitude
+// (the f16x3 range check).  The wave barriers keep the compiler from moving the exchange into divergent code.
+// `after_first_loads()` runs once, behind the first part's loads (where a kernel requests its first weight stage: the rows are
+// then ahead of it in the memory queue and the first split runs while the weights are still on their way).
+template <int W, bool ADD, typename FA, typename FB, typename FH>
+__device__ __forceinline__ void gom_rows_to_fragments(FA row_a, FB row_b, float* scratch, int lane, half8 (&xf)[2][16], float& amax,
+                                                      FH after_first_loads) {
+    constexpr int PC = W / 4;                                // 16-byte pieces of a row part
+    constexpr int RPI = 64 / PC;                             // rows per wave-instruction
+    constexpr int NI = 32 / RPI;                             // wave-instructions per part
+    const int pc = lane % PC, r0 = lane / PC;
+    const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int part = 0; part < 256 / W; ++part) {
+        f32x4 v[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = r0 + RPI * i;
+            v[i] = *reinterpret_cast<const f32x4*>(row_a(r) + part * W + pc * 4);
+            if constexpr (ADD) v[i] += *reinterpret_cast<const f32x4*>(row_b(r) + part * W + pc * 4);
+        }
+        if (part == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            after_first_loads();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = r0 + RPI * i;
+            *reinterpret_cast<f32x4*>(scratch + r * W + ((pc ^ (r & (PC - 1))) << 2)) = v[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < W / 16; ++s) {
+            const int p0 = 4 * s + 2 * fh;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(scratch + fr * W + ((p0 ^ (fr & (PC - 1))) << 2));
+            const f32x4 b = *reinterpret_cast<const f32x4*>(scratch + fr * W + (((p0 + 1) ^ (fr & (PC - 1))) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(a[e]), fabsf(b[e])));
+            gom_split8_f16(a, b, xf[0][part * (W / 16) + s], xf[1][part * (W / 16) + s]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    asm volatile("" : "+v"(amax));                           // decided here (dec_attn.hip: deferred compares spill)
+}

@@ -116,26 +116,22 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         unsigned char* dst = smem + stage * STAGE_BYTES;
         for (int f = wave; f < STAGE_FRAGS; f += 4) dma_fragment(rs_img, src + f * FRAG, dst + f * FRAG);
     };
-    dma_stage(0, 0);
 
     // ---- this wave's 32 rows of X as B-operand fragments: lane (r, h) holds X[row r][16 s + 8 h .. + 7], two planes -------
+    // (whole-line loads + a layout change in the ring's second slot, which the first stage does not use: common.h)
     int range_bad = 0;                                       // an operand beyond fp16's range (gemm_f16x3.hip contract)
     half8 xf[2][D / 16];
     {
-        long r = row0 + fr;
-        if (r > p.M - 1) r = p.M - 1;                         // tail rows recompute the last row (never stored)
-        const float* xr = p.X + (size_t)r * p.ldx + fh * 8;
-#pragma unroll
-        for (int s = 0; s < D / 16; ++s) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) range_bad |= !(fabsf(a[e]) <= 65504.f) | !(fabsf(b[e]) <= 65504.f);
-            split8(a, b, xf[0][s], xf[1][s]);
-        }
+        float xmax = 0.f;
+        auto xrow = [&](int r) {
+            long m = row0 + r;
+            if (m > p.M - 1) m = p.M - 1;                     // tail rows recompute the last row (never stored)
+            return p.X + (size_t)m * p.ldx;
+        };
+        gom_rows_to_fragments<128, false>(xrow, xrow, reinterpret_cast<float*>(smem + STAGE_BYTES) + wave * (32 * 128), lane, xf, xmax,
+                                          [&]() { dma_stage(0, 0); });
+        range_bad = !(xmax <= 65504.f);
     }
-    asm volatile("" : "+v"(range_bad));                      // decided HERE: left alone the compiler keeps the raw rows in
-                                                             // ~90 accumulator registers through the loop to compare them after it
 
     f32x16 acc2[D / 32];
 #pragma unroll

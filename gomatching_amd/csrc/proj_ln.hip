@@ -93,23 +93,23 @@ __global__ __launch_bounds__(256, 1) void proj_ln_kernel(const ProjArgs p) {
     if (p.stagger > 0 && blockIdx.x < 256)
         for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, STAGES * STAGE_BYTES, 0x00020000);
-    // stage 0: 64 fragments, sixteen per wave (fragments wave, wave + 4, ...)
-    for (int f = wave; f < STAGE_FRAGS; f += 4) dma_fragment(rs_img, f * FRAG + lane * 16, smem + f * FRAG);
-
+    // this wave's 32 rows as operand fragments (whole-line loads + a layout change in the ring's second slot: common.h); stage 0
+    // -- 64 fragments, sixteen per wave (fragments wave, wave + 4, ...) -- is requested behind the first loads
     int range_bad = 0;
     half8 xf[2][D / 16];
     {
-        long r = row0 + fr;
-        if (r > p.M - 1) r = p.M - 1;                         // tail rows recompute the last row (never stored)
-        const float* xr = p.X + (size_t)r * p.ldx + fh * 8;
-#pragma unroll
-        for (int s = 0; s < D / 16; ++s) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) range_bad |= !(fabsf(a[e]) <= 65504.f) | !(fabsf(b[e]) <= 65504.f);
-            split8(a, b, xf[0][s], xf[1][s]);
-        }
+        float xmax = 0.f;
+        auto xrow = [&](int r) {
+            long m = row0 + r;
+            if (m > p.M - 1) m = p.M - 1;                     // tail rows recompute the last row (never stored)
+            return p.X + (size_t)m * p.ldx;
+        };
+        gom_rows_to_fragments<128, false>(xrow, xrow, reinterpret_cast<float*>(smem + STAGE_BYTES) + wave * (32 * 128), lane, xf, xmax,
+                                          [&]() {
+                                              for (int f = wave; f < STAGE_FRAGS; f += 4)
+                                                  dma_fragment(rs_img, f * FRAG + lane * 16, smem + f * FRAG);
+                                          });
+        range_bad = !(xmax <= 65504.f);
     }
 
     f32x16 acc[D / 32];
