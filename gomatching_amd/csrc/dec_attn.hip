@@ -198,58 +198,31 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
     // those compares to the end of the kernel and keeps (spills) every compared value until then -- 1000 registers of scratch.
     float amax = 0.f, chk = 0.f;
     half8 xf[2][D / 16];
-    // this wave's rows as operand fragments: lane (r, h) holds x[row r][16 s + 8 h .. + 7], two planes (gemm_k256.hip)
-    auto load_rows = [&](bool with_pos) {
-        const float* xr = p.X + (size_t)row * p.ldx + fh * 8;
-        if (with_pos) {
-            const float* x2 = p.P + (size_t)row * p.ldp + fh * 8;
-            // a quarter's loads must not be requested before the previous quarter is split: the pointers pass through an
-            // empty asm that reads the last split result (sched_barrier alone lets the adds and splits sink below all loads)
-#pragma unroll
-            for (int hk = 0; hk < 4; ++hk) {                 // four quarters of K: 64 raw registers in flight, not 256
-                f32x4 ra[D / 32], rb[D / 32];
-#pragma unroll
-                for (int i = 0; i < D / 64; ++i) {
-                    const int s = hk * (D / 64) + i;
-                    ra[2 * i] = *reinterpret_cast<const f32x4*>(xr + 16 * s);
-                    ra[2 * i + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
-                    rb[2 * i] = *reinterpret_cast<const f32x4*>(x2 + 16 * s);
-                    rb[2 * i + 1] = *reinterpret_cast<const f32x4*>(x2 + 16 * s + 4);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < D / 64; ++i) {
-                    const int s = hk * (D / 64) + i;
-                    const f32x4 a = ra[2 * i] + rb[2 * i], b = ra[2 * i + 1] + rb[2 * i + 1];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(a[e]), fabsf(b[e])));
-                    split8(a, b, xf[0][s], xf[1][s]);
-                }
-                asm volatile("" : "+v"(xr), "+v"(x2), "+v"(amax) : "v"(xf[1][hk * (D / 64) + D / 64 - 1]) : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
+    // this wave's rows as operand fragments: lane (r, h) holds x[row r][16 s + 8 h .. + 7], two planes -- whole-line loads and a
+    // layout change in a ring slot that holds no stage at that moment (common.h gom_rows_to_fragments).  Token slot r of the wave
+    // (0..31) -> its row; slots beyond the group's tokens recompute token 0 of the group (masked as keys, never stored)
+    auto slot_row = [&](int r) -> long {
+        if constexpr (!INTER) {
+            const long gi = (long)blockIdx.x * 4 + wave;
+            const long g = gi < p.groups ? gi : p.groups - 1;
+            return g * p.G + (r < p.G ? r : 0);
         } else {
-            // (kernel start) the rows are requested FIRST, the ring's first two stages behind them: the split below runs while
-            // the 72 KB of weights are still on their way
-            f32x4 ra[D / 8];
-#pragma unroll
-            for (int s = 0; s < D / 16; ++s) {
-                ra[2 * s] = *reinterpret_cast<const f32x4*>(xr + 16 * s);
-                ra[2 * s + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            for (int f = wave; f < 2 * CHUNK_FRAGS; f += 4) dma_fragment(rs_img, lane16, f * FRAG, smem + f * FRAG);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < D / 16; ++s) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(ra[2 * s][e]), fabsf(ra[2 * s + 1][e])));
-                split8(ra[2 * s], ra[2 * s + 1], xf[0][s], xf[1][s]);
-            }
-            asm volatile("" : "+v"(amax));
+            const long gi = blockIdx.x;
+            const long b = gi / p.inner, pp = gi % p.inner;
+            const int mine = p.G - wave * p.per_wave;
+            const long tq = (r < p.per_wave && r < mine) ? (long)wave * p.per_wave + r : 0;
+            return (b * p.G + tq) * p.inner + pp;
         }
     };
-    load_rows(false);
+    auto xrow = [&](int r) { return p.X + (size_t)slot_row(r) * p.ldx; };
+    auto prow = [&](int r) { return p.P + (size_t)slot_row(r) * p.ldp; };
+    {
+        // kernel start: the ring's first two stages are requested behind the first loads, slot 2 is the scratch
+        float* scratch = reinterpret_cast<float*>(smem + 2 * CHUNK_BYTES) + wave * (32 * 64);
+        gom_rows_to_fragments<64, false>(xrow, xrow, scratch, lane, xf, amax, [&]() {
+            for (int f = wave; f < 2 * CHUNK_FRAGS; f += 4) dma_fragment(rs_img, lane16, f * FRAG, smem + f * FRAG);
+        });
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -343,7 +316,12 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
         }
         // ---- sweep 2: q | k of (tgt + query_pos) per head (stages 8 + 2 h, 9 + 2 h), attention in registers ----
         __builtin_amdgcn_sched_barrier(0);
-        load_rows(true);
+        {
+            // (stage 8 sits in slot 2, stage 9 in slot 0; slot 1 held stage 7 and is free until stage 8 requests stage 10 into it)
+            float* scratch = reinterpret_cast<float*>(smem + 1 * CHUNK_BYTES) + wave * (32 * 64);
+            gom_rows_to_fragments<64, true>(xrow, prow, scratch, lane, xf, amax, [&]() {});
+        }
+        __syncthreads();                                     // stage 8's product requests stage 10 into slot 1: every wave's scratch
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h = 0; h < NH; ++h) {

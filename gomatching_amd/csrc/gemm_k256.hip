@@ -92,53 +92,29 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
         for (int f = wave; f < CHUNK_FRAGS; f += 4) dma_fragment(rs_img, src + f * FRAG, dst + f * FRAG);
     };
     constexpr unsigned OOB = 0x7FFF0000u;                    // beyond num_records: the DMA writes zeros (into an unused stage)
-    dma_stage(c0, 0);
 
     // ---- this wave's 32 rows as operand fragments: lane (r, h) holds A[row r][16 s + 8 h .. + 7], two planes ----
+    // (whole-line loads + a layout change in the ring's second slot, 64 of a row's floats at a time; the first stage is requested
+    // behind the first loads: common.h gom_rows_to_fragments)
     int bad = 0;
     half8 xf[2][KD / 16];
     {
-        // every load of a phase is issued before the first split: the prologue is one round of memory latency, not sixteen
-        const float* xr = p.A + (size_t)row * p.lda + fh * 8;
-        if (p.A2) {                                          // (A + A2) in two halves of K (registers): one uniform branch
-            const float* x2 = p.A2 + (size_t)row * p.lda + fh * 8;
-#pragma unroll
-            for (int hk = 0; hk < 2; ++hk) {
-                f32x4 ra[KD / 16], rb[KD / 16];
-#pragma unroll
-                for (int i = 0; i < KD / 32; ++i) {
-                    const int s = hk * (KD / 32) + i;
-                    ra[2 * i] = *reinterpret_cast<const f32x4*>(xr + 16 * s);
-                    ra[2 * i + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
-                    rb[2 * i] = *reinterpret_cast<const f32x4*>(x2 + 16 * s);
-                    rb[2 * i + 1] = *reinterpret_cast<const f32x4*>(x2 + 16 * s + 4);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < KD / 32; ++i) {
-                    const int s = hk * (KD / 32) + i;
-                    const f32x4 a = ra[2 * i] + rb[2 * i], b = ra[2 * i + 1] + rb[2 * i + 1];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bad |= !(fabsf(a[e]) <= 65504.f) | !(fabsf(b[e]) <= 65504.f);
-                    split8(a, b, xf[0][s], xf[1][s]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            f32x4 ra[KD / 8];
-#pragma unroll
-            for (int s = 0; s < KD / 16; ++s) {
-                ra[2 * s] = *reinterpret_cast<const f32x4*>(xr + 16 * s);
-                ra[2 * s + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < KD / 16; ++s) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bad |= !(fabsf(ra[2 * s][e]) <= 65504.f) | !(fabsf(ra[2 * s + 1][e]) <= 65504.f);
-                split8(ra[2 * s], ra[2 * s + 1], xf[0][s], xf[1][s]);
-            }
-        }
+        float xmax = 0.f;
+        const long wrow0 = (long)blockIdx.x * BM + wave * 32;
+        auto arow = [&](int r) {
+            long m = wrow0 + r;
+            if (m > p.M - 1) m = p.M - 1;                     // tail rows recompute (and re-store) the last row: same bits
+            return p.A + (size_t)m * p.lda;
+        };
+        auto a2row = [&](int r) {
+            long m = wrow0 + r;
+            if (m > p.M - 1) m = p.M - 1;
+            return p.A2 + (size_t)m * p.lda;
+        };
+        float* scratch = reinterpret_cast<float*>(smem + CHUNK_BYTES) + wave * (32 * 64);
+        if (p.A2) gom_rows_to_fragments<64, true>(arow, a2row, scratch, lane, xf, xmax, [&]() { dma_stage(c0, 0); });
+        else gom_rows_to_fragments<64, false>(arow, arow, scratch, lane, xf, xmax, [&]() { dma_stage(c0, 0); });
+        bad = !(xmax <= 65504.f);
     }
 
     f32x16 acc;
