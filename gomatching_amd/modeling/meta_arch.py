@@ -821,10 +821,7 @@ class GoMatching:
         so both lanes stay symmetric over the eight XCDs (the XCD-aware tile orders of the detector's kernels keep working).
         n_cus = 0 undoes the reservation.  Not worth it on one GPU, where the tracker of 8 frames is 2 ms of a 36 ms step."""
         torch.cuda.synchronize(self.device)
-        for st in (getattr(self, "_lane_stream", None), getattr(self, "_det_stream", None)):
-            if st is not None:                                   # the previous reservation's two hardware queues
-                ops.release_masked_stream(st)
-        self._lane_stream = self._det_stream = None
+        self._lane_stream = self._det_stream = None              # (the queues stay cached per mask in ops.masked_stream)
         if n_cus <= 0:
             return
         total = torch.cuda.get_device_properties(self.device).multi_processor_count
@@ -1054,8 +1051,6 @@ class GoMatching:
         if h:
             torch.cuda.synchronize(self.device)                  # its buffers may still be read by queued kernels
             ops._L().gom_tracker_destroy(h)
-        if getattr(self, "_lane_stream", None) is not None or getattr(self, "_det_stream", None) is not None:
-            self.reserve_tracker_cus(0)                          # gives the CU-masked queues back
 
     def __del__(self):
         try:

@@ -357,24 +357,25 @@ def groupnorm32_into(x, gamma, beta, out_view, out_batch_stride, eps=1e-5):
                                         eps, _stream()), "gom_groupnorm32_nhwc_f32")
 
 
+_masked_streams = {}
+
+
 def masked_stream(mask_words, device):
-    """A torch stream (ExternalStream over gom_stream_create_cu_mask) restricted to the CUs of `mask_words` (list of uint32)."""
-    import ctypes
-    arr = (ctypes.c_uint32 * len(mask_words))(*[int(w) & 0xFFFFFFFF for w in mask_words])
-    out = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        check(_L().gom_stream_create_cu_mask(arr, len(mask_words), ctypes.byref(out)), "gom_stream_create_cu_mask")
-    st = torch.cuda.ExternalStream(out.value, device=device)
-    st._gom_handle = out.value                                 # ExternalStream does not own the queue: release_masked_stream
+    """A torch stream (ExternalStream over gom_stream_create_cu_mask) restricted to the CUs of `mask_words` (list of uint32).
+    One hardware queue per (device, mask) for the life of the process: a re-reservation with the same split gets the same queue
+    back, so repeated reservations do not accumulate queues.  The queues are deliberately never destroyed: torch's caching
+    allocator remembers every stream a block was allocated or recorded on and records an event there when the block is freed --
+    possibly long after a reservation ended (gom_stream_destroy under it aborts the process in HIPEvent::record)."""
+    key = (_dev_index(device), tuple(int(w) & 0xFFFFFFFF for w in mask_words))
+    st = _masked_streams.get(key)
+    if st is None:
+        arr = (ctypes.c_uint32 * len(mask_words))(*key[1])
+        out = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            check(_L().gom_stream_create_cu_mask(arr, len(mask_words), ctypes.byref(out)), "gom_stream_create_cu_mask")
+        st = torch.cuda.ExternalStream(out.value, device=device)
+        _masked_streams[key] = st
     return st
-
-
-def release_masked_stream(st):
-    """Destroy the hardware queue behind a `masked_stream` (after a device synchronise: nothing may be queued on it)."""
-    h = getattr(st, "_gom_handle", None)
-    if h:
-        st._gom_handle = None
-        check(_L().gom_stream_destroy(ctypes.c_void_p(h)), "gom_stream_destroy")
 
 
 K256_GEMM = _switch("K256_GEMM")   # f16x3 back-end: K = 256 products on the row-resident kernel where it measures faster (below)
@@ -711,13 +712,26 @@ def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq, valid_ratios
         _L().gom_msda_set_lane_distributed(1 if MSDA_LANES else 0)
         _msda_lanes_set[0] = MSDA_LANES
     out = torch.empty((B * Lq, 256), dtype=_f32, device=raw.device)
+    prof = _gemm_profile if _gemm_profile is not None else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        S_rows = value2d.shape[0]
+        # the value map once + raw offsets | logits + output (fp32); 2 * Lq * 8 heads * 16 samples * 4 corners * 32
+        _after = lambda: (e1.record(), prof.append((e0, e1, 2.0 * B * Lq * 8 * 16 * 4 * 32,
+                                                    4.0 * (S_rows * 256 + B * Lq * (384 + 256)), "msda:%dx%d" % (B, Lq),
+                                                    _profile_scope)))
+    else:
+        _after = lambda: None
     if valid_ratios is not None:
         check(_L().gom_msda_fused_forward_vr(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride,
                                              value2d.stride(0), _p(shapes), _p(lsi), _p(valid_ratios), _p(out), B, Lq,
                                              _stream()), "gom_msda_fused_forward_vr")
+        _after()
         return out
     check(_L().gom_msda_fused_forward(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride, value2d.stride(0),
                                       _p(shapes), _p(lsi), _p(out), B, Lq, _stream()), "gom_msda_fused_forward")
+    _after()
     return out
 
 

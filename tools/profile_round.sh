@@ -6,8 +6,6 @@ tag=${1:-r03}
 out=gpurun_out/final
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 600 python3 bench.py --steps 20 --warmup 3 > $out/${tag}_bench_final.json 2> $out/bench_final.err
-echo "bench rc $?"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-alt-backends > $out/${tag}_bench_under_rocprof.json 2> $out/stats.err
 echo "stats rc $?"
 cp $out/stats/stats_kernel_stats.csv $out/${tag}_kernel_stats.csv 2>/dev/null
@@ -18,6 +16,9 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $ou
 echo "write rc $?"
 python3 tools/pmc_traffic.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv $tag $out/gemm_api_grids.json | head -14
 cp profiles/pmc_traffic.json $out/pmc_traffic.json
+# the round's bench line AFTER the PMC passes: `roofline.traffic` then carries the counters of this very build
+timeout 600 python3 bench.py --steps 20 --warmup 3 > $out/${tag}_bench_final.json 2> $out/bench_final.err
+echo "bench rc $?"
 rm -rf $out/pmc_fetch $out/pmc_write
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/shapes -o s -- python3 tools/gemm_shapes.py > $out/${tag}_gemm_shapes_hip_events.log 2> $out/shapes.err
 echo "shapes rc $?"
