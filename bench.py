@@ -408,8 +408,8 @@ def main():
     # (M = frames x queries x points rows: ref_point_head, the self-attention blocks, cross-attention offsets | logits and
     # out_proj, FFN, the ctrl-point MLP) against those products' algorithmic FLOPs (7.375 GFLOP per layer and frame)
     dec_prof = [p_ for p_ in prof if len(p_) > 5 and p_[5] == "decoder_layer"]
-    dec_prof = [p_ for p_ in dec_prof if p_[4].startswith(("decattn:", "k256:", "projln:", "ffn")) or "x" in p_[4]]
-    ffn_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("ffn")]       # the fused FFN block: its own kernel
+    dec_prof = [p_ for p_ in dec_prof if not p_[4].startswith("msda:")]             # (sampling is not a Q-side product)
+    ffn_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("ffn") and not p_[4].startswith("ffn-mlp2:")]   # the fused FFN block
     k256_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("k256:")]    # the decoder's row-resident K = 256 kernel
     pl_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("projln:")]    # out_proj + residual + LayerNorm launches
     all_prof = prof
@@ -622,6 +622,8 @@ def main():
         kinds = {}
         for p_ in dec_prof:
             k_ = p_[4].split(":")[0] if ":" in p_[4] else ("ffn" if p_[4].startswith("ffn") else "tile / fp32 GEMM")
+            if p_[4].startswith("ffn-mlp2:"):
+                k_ = "two-layer perceptron (ffn_fused, PLAIN)"
             if p_[4].startswith("decattn:"):
                 k_ = "decattn " + p_[4].split(":")[1]
             e_ = kinds.setdefault(k_, [0, 0.0])

@@ -55,6 +55,7 @@ struct FfnArgs {
     int* flag;
     float eps;
     int ldx, ldy, M, chunks, stagger;
+    int relu_out;                                            // PLAIN form: ReLU behind the second layer
 };
 
 // sum over the 16 lanes of a DPP row, result in every lane: quad swaps (xor 1, xor 2), then the two mirrors
@@ -94,6 +95,11 @@ __device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)byte_offset, 0, 0, 0);
 }
 
+// PLAIN = true: a two-layer perceptron  Y = [relu](relu(X W1^T + b1) W2^T + b2)  -- no residual, no LayerNorm -- on the same
+// pipeline: the decoder's ref_point_head (deformable_transformer.py:470-473, adet/modeling/model/utils.py MLP) and the first two
+// layers of its three-layer coordinate / boundary heads (:484-488, detection_transformer_wobackbone.py:238-253) at
+// M = frames x queries x points rows, where two launches of the row-resident GEMM cost two workgroup latencies.
+template <bool PLAIN>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -268,7 +274,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         const long m = (long)blockIdx.x * BM + wave * 32 + 4 * g + rsel;
         const long mc = m < p.M ? m : p.M - 1;                  // tail rows recompute the last row, never stored
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xres[g][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)mc * p.ldx + (sub + 16 * k) * 4);
+        for (int k = 0; k < 4; ++k) {
+            if constexpr (PLAIN) xres[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            else xres[g][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)mc * p.ldx + (sub + 16 * k) * 4);
+        }
     }
     __syncthreads();
     // Row pass: FOUR rows per wave-instruction, 16 lanes per row, each lane four 16-byte column chunks (sub, sub + 16, ...):
@@ -281,8 +290,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         const int col = (sub + 16 * k) * 4;
         s2[k] = *reinterpret_cast<const f32x4*>(p.s2 + col);
         b2[k] = *reinterpret_cast<const f32x4*>(p.b2 + col);
-        ga[k] = *reinterpret_cast<const f32x4*>(p.gamma + col);
-        be[k] = *reinterpret_cast<const f32x4*>(p.beta + col);
+        if constexpr (!PLAIN) {
+            ga[k] = *reinterpret_cast<const f32x4*>(p.gamma + col);
+            be[k] = *reinterpret_cast<const f32x4*>(p.beta + col);
+        }
     }
     int bad = range_bad;
     // Four row groups at a time: their sixteen staged chunks are read in one batch (one LDS latency, not sixteen).
@@ -303,6 +314,17 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         for (int gi = 0; gi < 4; ++gi) {
             const int g = 4 * gh + gi;
             const long m = (long)blockIdx.x * BM + wave * 32 + 4 * g + rsel;
+            if constexpr (PLAIN) {
+                const float lo = p.relu_out ? 0.f : -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f32x4 o = v[gi][k] * s2[k] + b2[k];
+                    bad |= !(fabsf(o[0]) <= 3.4e38f) | !(fabsf(o[1]) <= 3.4e38f) | !(fabsf(o[2]) <= 3.4e38f) | !(fabsf(o[3]) <= 3.4e38f);
+                    o = f32x4{fmaxf(o[0], lo), fmaxf(o[1], lo), fmaxf(o[2], lo), fmaxf(o[3], lo)};   // (the check sits in front)
+                    if (m < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + (sub + 16 * k) * 4) = o;
+                }
+                continue;
+            }
             float sum = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -391,8 +413,25 @@ extern "C" int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, 
     a.flag = flag; a.eps = eps; a.ldx = ldx; a.ldy = ldy; a.M = M; a.chunks = d_hidden / CH;
     a.stagger = cdiv(M, BM) >= 1024 ? 8 : 0;                 // >= 4 rounds of workgroups
     // (the attribute is per DEVICE: set on every launch -- a process-wide flag would miss a second GPU; it costs ~1 us)
-    hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    return gom_launch_status();
+}
+
+extern "C" int gom_mlp2_fused_f32(const float* X, int ldx, const void* image, const float* w2_inv_scale, const float* b2,
+                                  int relu_out, float* Y, int ldy, int M, int d_model, int d_hidden, int* flag, void* stream) {
+    GOM_CHECK_ARG(X && image && w2_inv_scale && b2 && Y);
+    GOM_CHECK_ARG(M >= 0 && d_model == D && d_hidden > 0 && (d_hidden % CH) == 0);
+    GOM_CHECK_ARG(ldx >= D && ldy >= D && (ldx % 4) == 0 && (ldy % 4) == 0);
+    GOM_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)image % 16) == 0 &&
+                  ((uintptr_t)w2_inv_scale % 16) == 0 && ((uintptr_t)b2 % 16) == 0);
+    if (M == 0) return GOM_OK;
+    FfnArgs a{};
+    a.X = X; a.img = (const unsigned char*)image; a.s2 = w2_inv_scale; a.b2 = b2; a.Y = Y; a.flag = flag; a.ldx = ldx; a.ldy = ldy;
+    a.M = M; a.chunks = d_hidden / CH; a.stagger = cdiv(M, BM) >= 1024 ? 8 : 0; a.relu_out = relu_out ? 1 : 0;
+    hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+    hipLaunchKernelGGL(ffn_fused_kernel<true>, dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return gom_launch_status();
 }

@@ -130,6 +130,14 @@ class DeepSolo:
         self.dec_value = qlin((ops.prep_weight(torch.cat([g(n + ".weight") for n in vp], 0).contiguous()),
                                torch.cat([g(n + ".bias") for n in vp], 0).contiguous()))
         self.ref_point_head = [qlin(lin(t + "decoder.ref_point_head.layers.%d" % i)) for i in range(2)]
+
+        def mlp2(name, relu_out):                            # two 256 x 256 layers as ONE launch (f16x3 back-end), else None
+            return ops.mlp2_block(g(name + ".layers.0.weight"), g(name + ".layers.0.bias"), g(name + ".layers.1.weight"),
+                                  g(name + ".layers.1.bias"), relu_out)
+
+        self.ref_point_mlp2 = mlp2(t + "decoder.ref_point_head", False)
+        self.ctrl_coord_mlp2 = mlp2("ctrl_point_coord.0", True)
+        self.boundary_mlp2 = mlp2("boundary_offset.0", True)
         self.bezier_coord = [lin("bezier_proposal_coord.layers.%d" % i) for i in range(3)]
         self.bezier_class = lin("bezier_proposal_class")
         self.ctrl_coord = [qlin(lin("ctrl_point_coord.0.layers.%d" % i)) for i in range(3)]      # last layer (N = 2): a pair
@@ -312,8 +320,11 @@ class DeepSolo:
             # reference_points_input = reference_points * valid_ratios; the query position comes from level 0's (:470-473)
             qref = refs if vr is None else ops.scale_xy_(refs.clone(), *geo["vr0"])
             qpos = ops.point_pos_embed(qref, self.dim_t)
-            qpos = ops.linear(qpos, self.ref_point_head[0], relu=True)
-            qpos = ops.linear(qpos, self.ref_point_head[1])
+            if self.ref_point_mlp2 is not None:
+                qpos = ops.mlp2_fused(qpos, self.ref_point_mlp2)
+            else:
+                qpos = ops.linear(qpos, self.ref_point_head[0], relu=True)
+                qpos = ops.linear(qpos, self.ref_point_head[1])
             # intra-instance attention over the 25 points of each query (deformable_transformer.py:386-394)
             attn = None
             if L["intra_block"] is not None and P <= 32:
@@ -369,6 +380,9 @@ class DeepSolo:
         return ops.msda_fused(raw, ref, value_view, geo["S"] * ld_value, geo["shapes"], geo["lsi"], B, Lq, vr)
 
     def _mlp3(self, x, layers):
+        blk = self.ctrl_coord_mlp2 if layers is self.ctrl_coord else self.boundary_mlp2 if layers is self.boundary else None
+        if blk is not None:
+            return ops.linear(ops.mlp2_fused(x, blk), layers[2])
         h = ops.linear(x, layers[0], relu=True)
         h = ops.linear(h, layers[1], relu=True)
         return ops.linear(h, layers[2])

@@ -652,6 +652,52 @@ class FusedFFN:
         self.D, self.F = D_, F_
 
 
+FUSED_MLP2 = _switch("FUSED_MLP2")   # f16x3 back-end: the decoder's two-layer 256 -> 256 -> 256 perceptrons as one launch
+
+
+class FusedMLP2:
+    """linear -> ReLU -> linear [-> ReLU] with 256 inputs and outputs prepared for gom_mlp2_fused_f32 (the fused FFN kernel's
+    pipeline without residual / LayerNorm)."""
+
+    def __init__(self, w1, b1, w2, b2, relu_out):
+        F_, D_ = w1.shape
+        assert tuple(w2.shape) == (D_, F_) and D_ == 256
+        nbytes = _L().gom_ffn_fused_image_bytes(D_, F_)
+        if nbytes < 0:
+            raise _lib_mod.GomError("fused two-layer perceptron does not serve %d -> %d -> %d" % (D_, F_, D_))
+        s1, s2 = split_weight(w1.contiguous(), kind="f16x3"), split_weight(w2.contiguous(), kind="f16x3")
+        self.image = torch.empty((nbytes,), dtype=torch.uint8, device=w1.device)
+        p1, p2 = s1.planes, s2.planes
+        check(_L().gom_ffn_fused_image(_p(p1), p1.stride(0), p1.stride(1), _p(s1.inv_scale), _p(b1), _p(p2), p2.stride(0),
+                                       p2.stride(1), D_, F_, _p(self.image), nbytes, _stream()), "gom_ffn_fused_image")
+        self.inv2, self.b2, self.relu_out, self.D, self.F = s2.inv_scale, b2.contiguous(), bool(relu_out), D_, F_
+
+
+def mlp2_block(w1, b1, w2, b2, relu_out):
+    """FusedMLP2 when the back-end and shapes allow (fp32 weights [256, 256] twice), else None."""
+    if FUSED_MLP2 and FUSED_FFN and GEMM_MODE == "f16x3" and tuple(w1.shape) == (256, 256) and tuple(w2.shape) == (256, 256):
+        return FusedMLP2(w1, b1, w2, b2, relu_out)
+    return None
+
+
+def mlp2_fused(x, blk):
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == 256 and x.dtype == _f32
+    M = x.shape[0]
+    out = torch.empty((M, 256), dtype=_f32, device=x.device)
+    prof = _gemm_profile if (_gemm_profile is not None and M > 0) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().gom_mlp2_fused_f32(_p(x), x.stride(0) if M > 1 else 256, _p(blk.image), _p(blk.inv2), _p(blk.b2),
+                                  1 if blk.relu_out else 0, _p(out), 256, M, blk.D, blk.F, _p(range_flag(x.device)), _stream()),
+          "gom_mlp2_fused_f32")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 4.0 * M * blk.D * blk.F, 8.0 * M * blk.D + blk.image.numel(), "ffn-mlp2:%dx%dx%d" % (M, blk.D, blk.F),
+                     _profile_scope))
+    return out
+
+
 def ffn_fused_ln(x, ffn, out=None):
     """LayerNorm(x + FFN(x)) in one launch (csrc/ffn_fused.hip); x [M, 256] row-strided."""
     assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == ffn.D and x.dtype == _f32

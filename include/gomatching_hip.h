@@ -226,6 +226,12 @@ int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, const float
                          const float* gamma, const float* beta, float eps, float* Y, int ldy, int M, int d_model,
                          int d_hidden, int* flag, void* stream);
 
+/* The same kernel as a plain two-layer perceptron, Y = [relu](relu(X W1^T + b1) W2^T + b2), X / Y [M, 256] (csrc/ffn_fused.hip,
+ * PLAIN form): the decoder's ref_point_head (deformable_transformer.py:470-473) and the first two layers of the three-layer
+ * coordinate / boundary heads (:484-488, detection_transformer_wobackbone.py:238-253).  `image` = gom_ffn_fused_image. */
+int gom_mlp2_fused_f32(const float* X, int ldx, const void* image, const float* w2_inv_scale, const float* b2, int relu_out,
+                       float* Y, int ldy, int M, int d_model, int d_hidden, int* flag, void* stream);
+
 /* Split-K form for convolutions with few output tiles and a long K (input_proj[3]: 3x3 s2 2048 -> 256 on res5, M = 3584,
  * K = 18432): `splits` K-slices run as separate workgroups into workspace [splits][M][Cout] fp32, a second kernel sums
  * them in slice order (deterministic) and applies the epilogue.  gom_conv_bf16x6_splits: recommended slice count, 0 =

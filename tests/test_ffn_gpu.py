@@ -76,3 +76,28 @@ def test_fused_ffn_flags_an_activation_beyond_fp16():
     torch.cuda.synchronize()
     with pytest.raises(lib.GomError):
         ops.check_range_flag(DEV)
+
+
+@pytest.mark.parametrize("M,relu_out", [(1, False), (300, True), (20000, False), (4099, True)])
+def test_two_layer_perceptron_form(M, relu_out):
+    """The fused FFN kernel as a plain 256 -> 256 -> 256 perceptron (ref_point_head, the first two layers of the coordinate /
+    boundary heads) against two launches of the row-resident GEMM and float64."""
+    from gomatching_amd import ops
+    g = torch.Generator().manual_seed(M)
+    dev = "cuda"
+    w1 = (torch.randn(256, 256, generator=g) / 16).to(dev)
+    b1 = (torch.randn(256, generator=g) * 0.1).to(dev)
+    w2 = (torch.randn(256, 256, generator=g) / 16).to(dev)
+    b2 = (torch.randn(256, generator=g) * 0.1).to(dev)
+    x = torch.randn(M, 256, generator=g).to(dev)
+    blk = ops.FusedMLP2(w1, b1, w2, b2, relu_out)
+    got = ops.mlp2_fused(x, blk)
+    h = ops.gemm(x, ops.split_weight(w1, kind="f16x3"), bias=b1, relu=True)
+    two = ops.gemm(h, ops.split_weight(w2, kind="f16x3"), bias=b2, relu=relu_out)
+    ops.check_range_flag(torch.device(dev, torch.cuda.current_device()))
+    assert float((got - two).abs().max()) < 1e-5
+    d = lambda t: t.double().cpu()
+    y = torch.relu(d(x) @ d(w1).t() + d(b1)) @ d(w2).t() + d(b2)
+    if relu_out:
+        y = torch.relu(y)
+    assert float((d(got) - y).abs().max()) < 2e-5
