@@ -28,7 +28,7 @@ constexpr int PTH = 3, PTW = 8;                   // pooled pixels per workgroup
 constexpr int TH = 2 * PTH + 1, TW = 2 * PTW + 1; // convolution patch under them: 7 x 17
 constexpr int PITCH = BN + 4;                     // staged patch row (floats)
 constexpr int A_PLANE = BM * ROW_BYTES, W_PLANE = BN * ROW_BYTES;
-constexpr int LDS_LOOP = 2 * (A_PLANE + W_PLANE), LDS_EPI = BM * PITCH * 4;
+constexpr int LDS_LOOP = 2 * (((2 * (TH - 1) + KS) * (2 * (TW - 1) + KS) + 1) * 8 + 16) + 2 * W_PLANE, LDS_EPI = BM * PITCH * 4;
 constexpr int LDS_BYTES = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
 
 struct StemArgs {
@@ -54,8 +54,6 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2& p0, u32x2& p1) {
 
 __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                                // [2][128][80 B]
-    unsigned char* Ws = smem + 2 * A_PLANE;                  // [2][64][80 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;                 // 2 x 2 waves: 64 rows x 32 columns each
 
@@ -70,53 +68,41 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemArgs p) {
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)RANGE, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, (int)RANGE, 0x00020000);
 
-    // A: unit i of this thread = tile row (tid >> 3) + 32 i, tap (tid & 7) of the k-tile; one tap = one pixel's four channels
-    const int kq = tid & 7;
-    int a_ih0[4], a_iw0[4], a_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 3) + i * 32;
-        const int ty = row / TW, tx = row - ty * TW;
-        const int oh = oh0 + ty, ow = ow0 + tx;
-        const bool ok = row < TH * TW && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
-        a_ih0[i] = ok ? oh * 2 - 3 : -(1 << 28);             // invalid pixel: every tap fails the bounds test, reads zeros
-        a_iw0[i] = ow * 2 - 3;
-        a_off[i] = ((b * p.H + oh * 2 - 3) * p.W + a_iw0[i]) * 16;
+    // ---- the INPUT patch under the tile, staged once: 19 x 39 pixels x 4 channels as two fp16 planes (8 bytes per pixel and
+    // plane; out-of-image pixels and one spare slot hold zeros).  The A operand of every tap is read straight from it: before,
+    // every k-tile gathered its 128 x 8 taps from global memory (16 bytes per lane, ~16 lines per wave-instruction, 28
+    // instructions per wave and tile: the texture-address unit, which pays per line, was the busy unit -- 6.4k of its cycles per
+    // tile against 2.7k of MFMA issue), split them and stored them to LDS again.  Same values, same k order: the same bits. ----
+    constexpr int PH_IN = 2 * (TH - 1) + KS, PW_IN = 2 * (TW - 1) + KS;      // 19 x 39
+    constexpr int NPIX = PH_IN * PW_IN, ZERO_PIX = NPIX;                      // + one all-zero pixel for the taps beyond 49
+    constexpr int PP_PLANE = ((NPIX + 1) * 8 + 15) / 16 * 16;
+    unsigned char* PP = smem;                                                 // [2 planes][NPIX + 1][4 fp16]
+    unsigned char* Ws = smem + 2 * PP_PLANE;                                  // [2 planes][64 rows x ROW_BYTES]
+    {
+        const int ih0 = 2 * oh0 - 3, iw0 = 2 * ow0 - 3;
+        for (int t = tid; t <= NPIX; t += 256) {
+            const int py = t / PW_IN, px = t - py * PW_IN;
+            const int ih = ih0 + py, iw = iw0 + px;
+            unsigned off = (unsigned)(((b * p.H + ih) * p.W + iw) * 16);
+            if (t == ZERO_PIX || !(((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W))) off = INVALID;
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+            u32x2 p0, p1;
+            split4(v, p0, p1);
+            *reinterpret_cast<u32x2*>(PP + t * 8) = p0;
+            *reinterpret_cast<u32x2*>(PP + PP_PLANE + t * 8) = p1;
+        }
     }
     const int wq = tid & 3;
     const unsigned w_off = (unsigned)((tid >> 2) * p.ldw + wq * 8) * 2u;     // 64 rows x four 16-byte chunks: one unit per thread
     const unsigned w_plane_bytes = (unsigned)(p.w_plane_stride * 2);
-
-    f32x4 a_reg[4];
     u32x4 w_reg[2];
-    auto load_A = [&](int kt) {
-        const int tap = kt * 8 + kq;
-        const int kh = tap / KS, kw = tap - kh * KS;
-        const int koff = (kh * p.W + kw) * 16;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-            unsigned off = (unsigned)(a_off[i] + koff);
-            if (tap >= TAPS || !(((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W))) off = INVALID;
-            a_reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
-        }
-    };
     auto load_W = [&](int kt) {
         const unsigned koff = (unsigned)(kt * BK) * 2u;      // planes are zero-padded to ldw (a multiple of 32)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
             w_reg[pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(w_off + koff + pl * w_plane_bytes), 0, 0);
     };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (tid >> 3) + i * 32;
-            u32x2 p0, p1;
-            split4(a_reg[i], p0, p1);
-            unsigned char* d = As + row * ROW_BYTES + kq * 8;
-            *reinterpret_cast<u32x2*>(d) = p0;
-            *reinterpret_cast<u32x2*>(d + A_PLANE) = p1;
-        }
+    auto store_W = [&]() {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
             *reinterpret_cast<u32x4*>(Ws + pl * W_PLANE + (tid >> 2) * ROW_BYTES + wq * 16) = w_reg[pl];
@@ -128,17 +114,35 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
-    const unsigned char* a_base = As + (wr * 64 + fr) * ROW_BYTES + fh * 16;
+    // patch pixel under tap (0, 0) of this lane's two tile rows (rows beyond the 7 x 17 patch compute on pixel 0: never used)
+    int rb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wr * 64 + i * 32 + fr;
+        const int ty = row / TW, tx = row - ty * TW;
+        rb[i] = row < TH * TW ? (2 * ty) * PW_IN + 2 * tx : 0;
+    }
     const unsigned char* w_base = Ws + (wc * 32 + fr) * ROW_BYTES + fh * 16;
-    auto compute = [&]() {
+    auto compute = [&](int kt) {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
+            // k-step 2 kt + ks: this half-wave's eight k values = taps t0, t0 + 1 (four channels each)
+            const int t0 = (2 * kt + ks) * 4 + 2 * fh;
+            int po[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int tap = t0 + j, kh = tap / KS, kw = tap - kh * KS;
+                po[j] = tap < TAPS ? kh * PW_IN + kw : -1;
+            }
             half8 af[2][2];
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    af[pl][i] = *reinterpret_cast<const half8*>(a_base + pl * A_PLANE + i * 32 * ROW_BYTES + ks * 32);
+                for (int i = 0; i < 2; ++i) {
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(PP + pl * PP_PLANE + (po[0] < 0 ? ZERO_PIX : rb[i] + po[0]) * 8);
+                    const u32x2 hi = *reinterpret_cast<const u32x2*>(PP + pl * PP_PLANE + (po[1] < 0 ? ZERO_PIX : rb[i] + po[1]) * 8);
+                    af[pl][i] = __builtin_bit_cast(half8, (u32x4{lo[0], lo[1], hi[0], hi[1]}));
+                }
             const half8 b0 = *reinterpret_cast<const half8*>(w_base + ks * 32);
             const half8 b1 = *reinterpret_cast<const half8*>(w_base + W_PLANE + ks * 32);
 #pragma unroll
@@ -153,19 +157,15 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemArgs p) {
     };
 
     constexpr int NK = (TAPS * 4 + BK - 1) / BK;             // 7 k-tiles
-    load_A(0);
     load_W(0);
-    store_tile();
-    __syncthreads();
+    store_W();
+    __syncthreads();                                         // the patch and the first weight tile are staged
     for (int kt = 0; kt < NK; ++kt) {
-        if (kt + 1 < NK) {
-            load_W(kt + 1);
-            load_A(kt + 1);
-        }
-        compute();
+        if (kt + 1 < NK) load_W(kt + 1);
+        compute(kt);
         __syncthreads();
         if (kt + 1 < NK) {
-            store_tile();
+            store_W();
             __syncthreads();
         }
     }
