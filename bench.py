@@ -535,7 +535,7 @@ def main():
         ff = sum(p_[2] for p_ in ffn_prof)
         line["roofline_fused_ffn"] = {
             "bound": "mfma", "kernel": "ffn_fused_kernel", "achieved": ff / (fd * 1e-3) / 1e12, "peak": PEAKS["f16x3"][1],
-            "unit": "TFLOP/s", "frac": ff / (fd * 1e-3) / 1e12 / PEAKS["f16x3"][1], "traffic": pmc_traffic("ffn_fused_kernel"),
+            "unit": "TFLOP/s", "frac": ff / (fd * 1e-3) / 1e12 / PEAKS["f16x3"][1], "traffic": pmc_traffic("ffn_fused_kernel<false>") or pmc_traffic("ffn_fused_kernel"),
             "launches_per_step": len(ffn_prof) // PROFILE_STEPS, "avg_launch_us": fd * 1e3 / len(ffn_prof),
             "share_of_step_time": (fd / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
             "note": "linear1 + ReLU + linear2 + residual + LayerNorm of every encoder / decoder layer in one launch: 2 KB of HBM "
