@@ -11,8 +11,9 @@
 //   * a wave owns up to 32 tokens of ONE attention group (intra: the 25 points of a query; inter: a quarter of the queries of
 //     a (frame, point)) as MFMA operand fragments in 128 VGPRs, as in gemm_k256.hip / ffn_fused.hip; a workgroup = 4 waves =
 //     four intra groups or one inter group; one wave per SIMD with the whole register file;
-//   * the in-projection weights stream through a two-stage LDS ring by MUBUF LDS-DMA from a fragment-linear image, one 33 KB
-//     stage per (head, q | k | v): q and k are computed TRANSPOSED (lane = token, registers = the head's 32 features), v STRAIGHT
+//   * the in-projection weights stream through a three-slot LDS ring by MUBUF LDS-DMA from a fragment-linear image (stage i + 2
+//     is requested while stage i computes; nine fragments per wave and stage, so the end-of-stage wait is a counted one), one
+//     36 KB stage per (head, q | k | v): q and k are computed TRANSPOSED (lane = token, registers = the head's 32 features), v STRAIGHT
 //     (lane = feature, registers = tokens) -- which are exactly the operand layouts the attention products want:
 //         S^T[key, query] = K . Q^T     A = K accumulators (lane = key), B = Q accumulators (lane = query); the k index runs
 //                                       over the head's features in ACCUMULATOR order, the same permutation on both sides
@@ -42,7 +43,6 @@ constexpr int CHUNK_BYTES = CHUNK_FRAGS * FRAG;          // 36 KB
 constexpr int STAGES = 3 * NH + NH;                      // 24 projection chunks + 8 out_proj stages
 constexpr int SLOTS = 3;                                 // ring depth: stage i + 2 is requested while stage i computes
 constexpr int RING_BYTES = SLOTS * CHUNK_BYTES;
-constexpr int WS_WAVE_BYTES = NH * 4 * FRAG;             // intra: a wave's V^T fragments of every head, parked in global memory
 constexpr int XCH_BYTES = 4 * 8 * FRAG;                  // inter: K (4) + V^T (4) fragments of each of the four waves, one head
 constexpr int IMAGE_BYTES = STAGES * CHUNK_BYTES;
 
@@ -51,7 +51,6 @@ struct DecArgs {
     const float* P;                                          // query_pos (intra) or null
     const unsigned char* img;
     float* Y;
-    unsigned char* ws;                                       // intra: WS_WAVE_BYTES per wave of the launch
     int* flag;
     float eps, scale;
     int ldx, ldp, ldy;
@@ -296,10 +295,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
     };
 
     if constexpr (!INTER) {
-        // ---- sweep 1: V of every head (stages 0 .. 7).  Its A-operand fragments (16 registers per head) are PARKED in global
-        // memory, lane-linear, 32 KB per wave (L2-resident), and fetched back a head at a time in sweep 2: with them in registers
-        // beside the rows' fragments and O^T the kernel spilled a thousand registers to scratch (3.2 KB per lane) ----
-        unsigned char* wsw = p.ws + ((size_t)blockIdx.x * 4 + wave) * WS_WAVE_BYTES + lane * 16;
+        // ---- sweep 1: V of every head (stages 0 .. 7), kept as A-operand fragments in of[h] until the head's attention ----
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             DA_STAGE_VARS(h)
@@ -308,11 +304,8 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
             for (int g = 0; g < 16; ++g) acc[g] = 0.f;
             DA_STAGE(DA_MFMA_S)
             finish_s(acc, aux);
-            half8 vf[2][2];
-            acc_to_frags(acc, vf);
-#pragma unroll
-            for (int f = 0; f < 4; ++f) *reinterpret_cast<half8*>(wsw + (h * 4 + f) * FRAG) = vf[f >> 1][f & 1];
-            DA_STAGE_END_ALL()
+            acc_to_frags(acc, of[h]);
+            DA_STAGE_END()
         }
         // ---- sweep 2: q | k of (tgt + query_pos) per head (stages 8 + 2 h, 9 + 2 h), attention in registers ----
         __builtin_amdgcn_sched_barrier(0);
@@ -325,9 +318,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            half8 qf[2][2], kf[2][2], vf[2][2];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) vf[f >> 1][f & 1] = *reinterpret_cast<const half8*>(wsw + (h * 4 + f) * FRAG);
+            half8 qf[2][2], kf[2][2];
             {
                 DA_STAGE_VARS(NH + 2 * h)
                 f32x16 acc;
@@ -360,10 +351,10 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) o[g] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) o = mfma_x3(vf[ks][0], vf[ks][1], pf[ks][0], pf[ks][1], o);
+            for (int ks = 0; ks < 2; ++ks) o = mfma_x3(of[h][ks][0], of[h][ks][1], pf[ks][0], pf[ks][1], o);
 #pragma unroll
             for (int g = 0; g < 16; ++g) o[g] *= inv;
-            acc_to_frags(o, of[h]);
+            acc_to_frags(o, of[h]);                          // V of this head is dead: its registers take O^T
         }
     } else {
         // ---- per head: q, k, v of tgt (stages 3 h, 3 h + 1, 3 h + 2); K and V^T fragments shared through LDS ----
@@ -617,24 +608,15 @@ extern "C" int gom_dec_attn_image(const void* in_planes, long in_plane_stride, i
     return gom_launch_status();
 }
 
-extern "C" long gom_dec_attn_workspace_bytes(int groups, int inter) {
-    if (groups < 0) return -1;
-    return inter ? 0 : (long)cdiv(groups, 4) * 4 * WS_WAVE_BYTES;
-}
-
 extern "C" int gom_dec_attn_f32(const float* X, int ldx, const float* P, int ldp, const void* image, float eps, float* Y, int ldy,
-                                int groups, int group_tokens, int inner, int inter, void* workspace, long workspace_bytes,
-                                int* flag, void* stream) {
+                                int groups, int group_tokens, int inner, int inter, int* flag, void* stream) {
     GOM_CHECK_ARG(X && image && Y && groups >= 0 && group_tokens > 0);
     GOM_CHECK_ARG(ldx >= D && ldy >= D && (ldx % 4) == 0 && (ldy % 4) == 0 && (!P || (ldp >= D && (ldp % 4) == 0)));
     GOM_CHECK_ARG(((uintptr_t)X % 16) == 0 && (!P || ((uintptr_t)P % 16) == 0) && ((uintptr_t)Y % 16) == 0 &&
                   ((uintptr_t)image % 16) == 0);
     GOM_CHECK_ARG(inter ? (!P && inner > 0 && group_tokens <= 128) : (P && group_tokens <= 32));
-    GOM_CHECK_ARG(inter || (workspace && ((uintptr_t)workspace % 16) == 0 &&
-                            workspace_bytes >= gom_dec_attn_workspace_bytes(groups, 0)));
     if (groups == 0) return GOM_OK;
     DecArgs a{};
-    a.ws = (unsigned char*)workspace;
     a.X = X; a.P = P; a.img = (const unsigned char*)image; a.Y = Y; a.flag = flag; a.eps = eps; a.scale = 1.0f / sqrtf(32.f); a.ldx = ldx; a.ldp = ldp; a.ldy = ldy;
     a.groups = groups; a.G = group_tokens; a.per_wave = cdiv(group_tokens, 4); a.inner = inner;
     const int lds = inter ? RING_BYTES + XCH_BYTES : RING_BYTES;

@@ -46,8 +46,7 @@ SIGNATURES = {
     "gom_bneck_f32": (I, [P, I, P, P, I, P, P, P, I, P, I, I, I, I, I, P, P]),
     "gom_dec_attn_image_bytes": (L, [I, I]),
     "gom_dec_attn_image": (I, [P, L, I, P, P, P, L, I, P, P, P, P, I, P, L, P]),
-    "gom_dec_attn_workspace_bytes": (L, [I, I]),
-    "gom_dec_attn_f32": (I, [P, I, P, I, P, F, P, I, I, I, I, I, P, L, P, P]),
+    "gom_dec_attn_f32": (I, [P, I, P, I, P, F, P, I, I, I, I, I, P, P]),
     "gom_proj_ln_image_bytes": (L, [I, I]),
     "gom_proj_ln_image": (I, [P, L, I, I, I, P, L, P]),
     "gom_proj_ln_f32": (I, [P, I, P, P, P, P, I, P, P, F, P, I, I, P, P]),

@@ -608,10 +608,6 @@ def dec_attn(x, blk, groups, group_tokens, inner=1, pos=None, out=None):
     assert x.shape[0] >= rows
     if out is None:
         out = torch.empty((x.shape[0], 256), dtype=_f32, device=x.device)
-    ws, ws_bytes = None, 0
-    if not blk.inter:                                        # V fragments parked per wave (csrc/dec_attn.hip), 32 KB per group
-        ws_bytes = _L().gom_dec_attn_workspace_bytes(groups, 0)
-        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=x.device)
     prof = _gemm_profile if (_gemm_profile is not None and rows > 0) else None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -620,7 +616,7 @@ def dec_attn(x, blk, groups, group_tokens, inner=1, pos=None, out=None):
                                 (pos.stride(0) if pos.shape[0] > 1 else 256) if pos is not None else 0, _p(blk.image),
                                 blk.eps, _p(out),
                                 out.stride(0) if out.shape[0] > 1 else 256, groups, group_tokens, inner,
-                                1 if blk.inter else 0, _p(ws), ws_bytes, _p(range_flag(x.device)), _stream()), "gom_dec_attn_f32")
+                                1 if blk.inter else 0, _p(range_flag(x.device)), _stream()), "gom_dec_attn_f32")
     if prof is not None:
         e1.record()
         # the block's nn.Linear products (in_proj 768 + out_proj 256 columns) + QK^T and PV of every head

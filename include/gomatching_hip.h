@@ -178,15 +178,12 @@ int gom_bneck_f32(const float* A, int lda, const void* image, const float* R, in
  * planes of in_proj_weight [768, 256] (+ inverse row scales, in_proj_bias) and out_proj.weight [256, 256] (+ inverse row
  * scales, bias) and the LayerNorm's gamma / beta [256]. */
 long gom_dec_attn_image_bytes(int d_model, int heads);
-/* inter = 0 parks the V fragments of its groups in `workspace` (gom_dec_attn_workspace_bytes(groups, 0) bytes, 16-byte aligned,
- * contents irrelevant before and after the launch); inter = 1 needs none. */
-long gom_dec_attn_workspace_bytes(int groups, int inter);
 int gom_dec_attn_image(const void* in_planes, long in_plane_stride, int ld_in, const float* in_inv_scale, const float* in_bias,
                        const void* out_planes, long out_plane_stride, int ld_out, const float* out_inv_scale,
                        const float* out_bias, const float* gamma, const float* beta, int inter, void* image, long image_bytes,
                        void* stream);
 int gom_dec_attn_f32(const float* X, int ldx, const float* P, int ldp, const void* image, float eps, float* Y, int ldy, int groups,
-                     int group_tokens, int inner, int inter, void* workspace, long workspace_bytes, int* flag, void* stream);
+                     int group_tokens, int inner, int inter, int* flag, void* stream);
 
 /* Row-resident K = 256 form of gom_gemm_f32_f16x3 for SHORT problems (the decoder's Q-side nn.Linear layers at
  * M = frames x queries x points rows: deformable_transformer.py:386-422,470-488), csrc/gemm_k256.hip:

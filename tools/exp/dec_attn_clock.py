@@ -56,7 +56,7 @@ def main():
     from gomatching_amd import ops
     so = ctypes.CDLL(SO)
     vp, ci, cl = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
-    so.gom_dec_attn_f32.argtypes = [vp, ci, vp, ci, vp, ctypes.c_float, vp, ci, ci, ci, ci, ci, vp, cl, vp, vp]
+    so.gom_dec_attn_f32.argtypes = [vp, ci, vp, ci, vp, ctypes.c_float, vp, ci, ci, ci, ci, ci, vp, vp]
     so.dec_attn_clock_read.argtypes = [vp]
     dev = "cuda"
     B, nq, P = 8, 100, 25
@@ -72,10 +72,9 @@ def main():
     for inter in (0, 1):
         blk = ops.DecAttnBlock(in_w, in_b, out_w, out_b, gamma, beta, bool(inter))
         groups, G, inner = (B * P, nq, P) if inter else (B * nq, P, 1)
-        ws = torch.empty((max(16, (groups + 3) // 4 * 4 * 32768),), dtype=torch.uint8, device=dev)
         for _ in range(3):
             rc = so.gom_dec_attn_f32(x.data_ptr(), 256, 0 if inter else pos.data_ptr(), 0 if inter else 256, blk.image.data_ptr(), 1e-5,
-                                     y.data_ptr(), 256, groups, G, inner, inter, ws.data_ptr(), ws.numel(), flag.data_ptr(), None)
+                                     y.data_ptr(), 256, groups, G, inner, inter, flag.data_ptr(), None)
             assert rc == 0, rc
         torch.cuda.synchronize()
         assert so.dec_attn_clock_read(host.ctypes.data) == 0
