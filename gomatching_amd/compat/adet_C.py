@@ -10,9 +10,11 @@ Same two callables, same argument order, same preconditions and error type as th
   * batch % min(batch, im2col_step) == 0                            (ms_deform_attn_cuda.cu:50-52)
   * inputs borrowed, output freshly allocated in value's dtype/device, launch on the caller's current stream.
 The op is also registered with the dispatcher as `torch.ops.gomatching.ms_deform_attn_forward` ("preferred").
-Differences, stated rather than hidden: fp32 only (the reference also dispatches fp64, ms_deform_attn_cuda.cu:64) and the
-shipped shape 8 heads x 32 channels x 4 levels x 4 points only -- anything else raises RuntimeError instead of running;
-`ms_deform_attn_backward` raises NotImplementedError (DeepSolo is frozen in every shipped config, configs/*.yaml:3)."""
+float32 and float64 (the reference's AT_DISPATCH_FLOATING_TYPES, ms_deform_attn_cuda.cu:64), any heads / channels / levels /
+points: the shipped shape (8 x 32 x 4 x 4, fp32) runs msda.hip's wave-per-query kernel, everything else and the backward the
+general kernels of msda_any.hip.  `ms_deform_attn_backward` returns [grad_value, grad_sampling_loc, grad_attn_weight] as the
+reference's does (ms_deform_attn_cuda.cu:83-156), so the reference's own `MSDeformAttnFunction` (ms_deform_attn.py:20-37)
+trains through this module unchanged; the dispatcher op carries the same backward for `torch.ops` callers."""
 import sys
 
 import torch
@@ -36,8 +38,8 @@ def _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, 
     step = min(batch, int(im2col_step))
     if step <= 0 or batch % step != 0:
         raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (batch, step))       # :50-52
-    if value.dtype != torch.float32:
-        raise RuntimeError("ms_deform_attn_forward on MI355X serves float32 only (got %s)" % value.dtype)
+    if value.dtype not in (torch.float32, torch.float64):              # the dispatch macro's own refusal (:64)
+        raise RuntimeError('"ms_deform_attn_forward_cuda" not implemented for \'%s\'' % str(value.dtype).replace("torch.", ""))
 
 
 @torch.library.custom_op(_NS + "::ms_deform_attn_forward", mutates_args=())
@@ -61,9 +63,44 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
                                                        int(im2col_step))
 
 
+@torch.library.custom_op(_NS + "::ms_deform_attn_backward", mutates_args=())
+def _bwd_op(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
+            attn_weight: torch.Tensor, grad_output: torch.Tensor, im2col_step: int) -> list[torch.Tensor]:
+    _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    if not grad_output.is_contiguous():
+        raise RuntimeError("grad_output tensor has to be contiguous")              # ms_deform_attn_cuda.cu:99
+    if not grad_output.is_cuda:
+        raise RuntimeError("grad_output must be a CUDA tensor")                    # :106
+    try:
+        return list(_ops.ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                                 grad_output, im2col_step))
+    except GomError as e:
+        raise RuntimeError(str(e)) from e
+
+
+@_bwd_op.register_fake
+def _(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
+    return [torch.empty_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)]
+
+
+def _setup_context(ctx, inputs, output):
+    ctx.save_for_backward(*inputs[:5])
+    ctx.im2col_step = inputs[5]
+
+
+def _backward(ctx, grad_output):
+    value, shapes, lsi, loc, w = ctx.saved_tensors
+    gv, gl, gw = torch.ops.gomatching.ms_deform_attn_backward(value, shapes, lsi, loc, w, grad_output.contiguous(),
+                                                              ctx.im2col_step)
+    return gv, None, None, gl, gw, None
+
+
+_op.register_autograd(_backward, setup_context=_setup_context)
+
+
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
-    raise NotImplementedError("ms_deform_attn_backward: DeepSolo is frozen on the GoMatching path (configs/*.yaml:3); the "
-                              "MI355X library ships the forward op only")
+    return torch.ops.gomatching.ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                                        grad_output, int(im2col_step))
 
 
 def install(name="adet._C"):

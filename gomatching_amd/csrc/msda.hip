@@ -382,8 +382,11 @@ extern "C" int gom_ms_deform_attn_forward(const float* value, const int64_t* spa
                                           int num_heads, int channels, int num_levels, int num_query,
                                           int num_point, void* stream) {
     GOM_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && output);
-    // the shape the whole DeepSolo family uses; anything else is refused loudly rather than run slowly
-    GOM_CHECK_ARG(num_heads == HEADS && channels == CH && num_levels == LEVELS && num_point == 4);
+    // the shape the whole DeepSolo family uses runs here; anything else on the general kernel (msda_any.hip)
+    if (!(num_heads == HEADS && channels == CH && num_levels == LEVELS && num_point == 4))
+        return gom_ms_deform_attn_forward_any(GOM_DTYPE_F32, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                              output, batch, spatial_size, num_heads, channels, num_levels, num_query,
+                                              num_point, stream);
     GOM_CHECK_ARG(batch > 0 && spatial_size > 0 && num_query > 0);
     const long nq = (long)batch * num_query;
     hipLaunchKernelGGL((msda_fwd_kernel<4>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,

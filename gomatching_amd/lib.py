@@ -23,6 +23,8 @@ SIGNATURES = {
     "gom_abi_version": (I, []),
     "gom_built_for_arch": (ctypes.c_char_p, []),
     "gom_ms_deform_attn_forward": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "gom_ms_deform_attn_forward_any": (I, [I, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "gom_ms_deform_attn_backward": (I, [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "gom_ms_deform_attn_forward_strided": (I, [P, L, I, P, P, P, P, P, I, I, P]),
     "gom_msda_set_lane_distributed": (I, [I]),
     "gom_msda_fused_forward": (I, [P, I, P, P, L, I, P, P, P, I, I, P]),

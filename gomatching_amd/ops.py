@@ -714,21 +714,69 @@ def ffn_fused_ln(x, ffn, out=None):
 
 
 # ------------------------------------------------------------------------------------------ MSDA
-def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
-    """Same signature as the reference's adet._C.ms_deform_attn_forward (im2col_step accepted, unused)."""
-    _chk_f32(value, sampling_loc, attn_weight)
+def _msda_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, *more):
+    """Preconditions of the native op (ms_deform_attn_cuda.cu:28-52) + the dtype code of its dispatch (:64)."""
+    ts = (value, sampling_loc, attn_weight) + more
+    if value.dtype not in (_f32, torch.float64):
+        raise _lib_mod.GomError("ms_deform_attn: float32 or float64 tensors only (got %s)" % value.dtype)
+    for t in ts:
+        if t.dtype != value.dtype or not t.is_cuda or not t.is_contiguous():
+            raise _lib_mod.GomError("expected a contiguous %s CUDA tensor, got %s %s contiguous=%s" % (
+                value.dtype, t.dtype, t.device, t.is_contiguous()))
     if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
         raise _lib_mod.GomError("spatial_shapes / level_start_index must be int64")
     if not (spatial_shapes.is_cuda and level_start_index.is_cuda and spatial_shapes.is_contiguous()
             and level_start_index.is_contiguous()):
         raise _lib_mod.GomError("spatial_shapes / level_start_index must be contiguous CUDA tensors")
     B, S, M, D = value.shape
-    _, Lq, _, Lv, Pn, _ = sampling_loc.shape
-    out = torch.empty((B, Lq, M * D), dtype=_f32, device=value.device)
-    check(_L().gom_ms_deform_attn_forward(_p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_loc),
-                                          _p(attn_weight), _p(out), B, S, M, D, Lv, Lq, Pn, _stream()),
-          "gom_ms_deform_attn_forward")
+    _, Lq, M2, Lv, Pn, two = sampling_loc.shape
+    if (sampling_loc.shape[0] != B or M2 != M or two != 2 or tuple(attn_weight.shape) != (B, Lq, M, Lv, Pn)
+            or spatial_shapes.shape[0] != Lv or level_start_index.shape[0] != Lv):
+        raise _lib_mod.GomError("ms_deform_attn: value [B,S,M,D], sampling_loc [B,Lq,M,L,P,2], attn_weight [B,Lq,M,L,P], "
+                                "spatial_shapes [L,2], level_start_index [L] disagree")
+    return 0 if value.dtype == _f32 else 1, (B, S, M, D, Lv, Lq, Pn)
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    """Same signature as the reference's adet._C.ms_deform_attn_forward (im2col_step accepted, unused): any heads / channels /
+    levels / points, float32 or float64 (third_party/adet/layers/csrc/DeformAttn/ms_deform_attn_cuda.cu:20-80)."""
+    code, dims = _msda_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    B, S, M, D, Lv, Lq, Pn = dims
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    if code == 0:           # the 1:1 entry: the shipped shape on the wave-per-query kernel, anything else on the general one
+        check(_L().gom_ms_deform_attn_forward(_p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_loc),
+                                              _p(attn_weight), _p(out), B, S, M, D, Lv, Lq, Pn, _stream()),
+              "gom_ms_deform_attn_forward")
+    else:
+        check(_L().gom_ms_deform_attn_forward_any(code, _p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_loc),
+                                                  _p(attn_weight), _p(out), B, S, M, D, Lv, Lq, Pn, _stream()),
+              "gom_ms_deform_attn_forward_any")
     return out
+
+
+def ms_deform_attn_forward_any(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    """The general kernel whatever the shape (tests compare it with the wave-per-query kernel on the shipped shape)."""
+    code, dims = _msda_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    B, S, M, D, Lv, Lq, Pn = dims
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    check(_L().gom_ms_deform_attn_forward_any(code, _p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_loc),
+                                              _p(attn_weight), _p(out), B, S, M, D, Lv, Lq, Pn, _stream()),
+          "gom_ms_deform_attn_forward_any")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):
+    """adet._C.ms_deform_attn_backward (ms_deform_attn_cuda.cu:83-156): (grad_value, grad_sampling_loc, grad_attn_weight)."""
+    code, dims = _msda_args(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output)
+    B, S, M, D, Lv, Lq, Pn = dims
+    if grad_output.numel() != B * Lq * M * D:
+        raise _lib_mod.GomError("ms_deform_attn_backward: grad_output must hold [B, Lq, M*D] elements")
+    gv, gl, gw = torch.empty_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+    check(_L().gom_ms_deform_attn_backward(code, _p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_loc),
+                                           _p(attn_weight), _p(grad_output), _p(gv), _p(gl), _p(gw), B, S, M, D, Lv, Lq, Pn,
+                                           _stream()),
+          "gom_ms_deform_attn_backward")
+    return gv, gl, gw
 
 
 def ms_deform_attn_forward_strided(value2d, batch_stride, shapes, lsi, loc, w, B, Lq):

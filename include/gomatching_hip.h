@@ -31,6 +31,9 @@ extern "C" {
 #define GOM_ERR_UNSUPPORTED 2
 #define GOM_ERR_HIP_BASE 1000
 
+#define GOM_DTYPE_F32 0
+#define GOM_DTYPE_F64 1
+
 #define GOM_ABI_VERSION 1
 int gom_abi_version(void);
 /* gfx arch string of device 0's code object target, e.g. "gfx950" (static storage). */
@@ -44,11 +47,32 @@ const char* gom_built_for_arch(void);
  *   level_start_index [num_levels] int64 ; sampling_loc [batch, num_query, heads, levels, points, 2] ;
  *   attn_weight [batch, num_query, heads, levels, points] ; output [batch, num_query, heads*channels]
  * The caller owns `output` (the reference allocates it with at::zeros; every element is written here).
- * im2col_step has no equivalent: the whole batch is one launch. */
+ * im2col_step has no equivalent: the whole batch is one launch.  Any shape: 8 heads x 32 channels x 4 levels x 4 points
+ * (every shipped config) runs the wave-per-query kernel of msda.hip, anything else the general kernel of msda_any.hip. */
 int gom_ms_deform_attn_forward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                const float* sampling_loc, const float* attn_weight, float* output, int batch,
                                int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                                int num_point, void* stream);
+
+/* The reference's dispatch on the value dtype (AT_DISPATCH_FLOATING_TYPES, ms_deform_attn_cuda.cu:64): dtype =
+ * GOM_DTYPE_F32 | GOM_DTYPE_F64 is the element type of value, sampling_loc, attn_weight and output; anything else
+ * -> GOM_ERR_UNSUPPORTED (the macro throws there).  Always the general kernel. */
+int gom_ms_deform_attn_forward_any(int dtype, const void* value, const int64_t* spatial_shapes,
+                                   const int64_t* level_start_index, const void* sampling_loc, const void* attn_weight,
+                                   void* output, int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                   int num_query, int num_point, void* stream);
+
+/* Replaces std::vector<at::Tensor> ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc,
+ * attn_weight, grad_output, im2col_step)  (ms_deform_attn.h:41-61 -> ms_deform_attn_cuda.cu:83-156 ->
+ * ms_deform_im2col_cuda.cuh:301-921).  grad_output [batch, num_query, heads*channels]; the three gradients have the
+ * shapes of value / sampling_loc / attn_weight, are owned by the caller and need NO zero fill (grad_value is cleared
+ * in-stream here, the other two are written exactly once per element).  grad_value accumulates with hardware float
+ * atomics, as the reference's does: its last bits depend on the order the waves arrive in. */
+int gom_ms_deform_attn_backward(int dtype, const void* value, const int64_t* spatial_shapes,
+                                const int64_t* level_start_index, const void* sampling_loc, const void* attn_weight,
+                                const void* grad_output, void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
+                                int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                int num_point, void* stream);
 
 /* Same op, value read in place from a wider row-major buffer (row / batch strides in floats). */
 int gom_ms_deform_attn_forward_strided(const float* value, long value_batch_stride, int value_row_stride,

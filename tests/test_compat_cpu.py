@@ -18,8 +18,12 @@ def test_adet_C_preconditions_and_dispatcher_registration():
         adet_C.ms_deform_attn_forward(v, shapes, lsi, loc, w, 64)
     with pytest.raises(RuntimeError, match="contiguous"):        # :28-32
         adet_C.ms_deform_attn_forward(v.transpose(1, 2), shapes, lsi, loc, w, 64)
-    with pytest.raises(NotImplementedError):
-        adet_C.ms_deform_attn_backward(v, shapes, lsi, loc, w, v, 64)
+    with pytest.raises(RuntimeError, match="CUDA"):              # the backward asserts the same (:92-106)
+        adet_C.ms_deform_attn_backward(v, shapes, lsi, loc, w, torch.zeros(2, 5, 256), 64)
+    assert hasattr(torch.ops.gomatching, "ms_deform_attn_backward")
+    gv, gl, gw = torch.ops.gomatching.ms_deform_attn_backward(*(x.to("meta") for x in (v, shapes, lsi, loc, w,
+                                                                                        torch.zeros(2, 5, 256))), 64)
+    assert gv.shape == v.shape and gl.shape == loc.shape and gw.shape == w.shape
     # shape inference through the dispatcher (meta tensors): [B, Lq, M*D]
     out = torch.ops.gomatching.ms_deform_attn_forward(v.to("meta"), shapes.to("meta"), lsi.to("meta"), loc.to("meta"),
                                                       w.to("meta"), 64)

@@ -24,8 +24,11 @@ def test_adet_C_module_on_the_reference_fixture(case):
     with pytest.raises(RuntimeError, match="im2col_step"):
         adet_C.ms_deform_attn_forward(*three, 2)
     assert torch.equal(adet_C.ms_deform_attn_forward(*three, 3)[0], out[0])
-    with pytest.raises(RuntimeError, match="float32"):
-        adet_C.ms_deform_attn_forward(args[0].double(), args[1], args[2], args[3].double(), args[4].double(), 64)
+    # the reference dispatches on the dtype (ms_deform_attn_cuda.cu:64): float64 runs, half is refused by the macro
+    out64 = adet_C.ms_deform_attn_forward(args[0].double(), args[1], args[2], args[3].double(), args[4].double(), 64)
+    assert out64.dtype == torch.float64 and float((out64.cpu() - t(g[case + "_out"]).double()).abs().max()) <= 2e-6
+    with pytest.raises(RuntimeError, match="not implemented for 'float16'"):
+        adet_C.ms_deform_attn_forward(args[0].half(), args[1], args[2], args[3].half(), args[4].half(), 64)
 
 
 def test_meta_arch_wrapper_reproduces_reference_ids():

@@ -157,3 +157,18 @@ def test_oracle_vs_reference_full_size(name):
     assert int(g["S"][0]) == taps["memory"].shape[1]
     err, moved = compare(g, out, taps["topk"].reshape(-1), T.NUM_QUERIES, T.NUM_POINTS, tol=2e-5, what="oracle " + name)
     assert moved == 0
+
+
+@pytest.mark.parametrize("case", ["odd_f64", "odd_f32", "wide_f64", "one_f32", "ship_f64", "ship_f32"])
+def test_msda_general_form_and_gradients(case):
+    """Any heads / channels / levels / points, fp32 and fp64: the oracle's op and its autograd gradients against the outputs
+    and gradients of the reference's own ms_deform_attn_core_pytorch (oracle/gen_golden_msda_any.py)."""
+    g = golden("msda_any.npz")
+    v, loc, w = (t(g[case + k]).requires_grad_(True) for k in ("_value", "_loc", "_w"))
+    out = O.ms_deform_attn_forward(v, t(g[case + "_shapes"]), t(g[case + "_lsi"]), loc, w)
+    gv, gl, gw = torch.autograd.grad(out, (v, loc, w), t(g[case + "_gout"]))
+    tol = 1e-12 if v.dtype == torch.float64 else TOL
+    for got, key in ((out.detach(), "_out"), (gv, "_grad_value"), (gl, "_grad_loc"), (gw, "_grad_w")):
+        exp = g[case + key]
+        assert got.numpy().dtype == exp.dtype
+        np.testing.assert_allclose(got.numpy(), exp, atol=tol * max(1.0, float(np.abs(exp).max())), rtol=0)
