@@ -101,6 +101,48 @@ __global__ __launch_bounds__(256) void ref_sigmoid_kernel(const float* __restric
     out[i] = sigmoidf(delta[q * ld_delta + c] + inv_sigmoid(ref[q * 2 + (c & 1)]));
 }
 
+// The tail of a decoder layer's reference refinement and the head of the next layer's query position as ONE launch
+// (deformable_transformer.py:484-488, then :470-473 + :25-37 of the following layer): a wave per point,
+//   delta = h . W3^T + b3        (the last, 256 -> 2 layer of ctrl_point_coord's MLP; h = the two hidden layers' output)
+//   ref'  = sigmoid(delta + inverse_sigmoid(ref))
+//   pos   = sine embedding of ref' * (sx, sy)                    (skipped when pos == nullptr: the last layer)
+// instead of an N = 2 GEMM launch, ref_sigmoid_kernel and point_pos_kernel (three dispatches for 10 KB of arithmetic).
+__global__ __launch_bounds__(256) void ref_update_kernel(const float* __restrict__ h, int ld_h, const float* __restrict__ W3,
+                                                         const float* __restrict__ b3, const float* __restrict__ ref,
+                                                         const float* __restrict__ dim_t, float sx, float sy,
+                                                         float* __restrict__ new_ref, float* __restrict__ pos, long Q) {
+    const int lane = threadIdx.x & 63;
+    const f32x4 w0 = *(const f32x4*)(W3 + lane * 4), w1 = *(const f32x4*)(W3 + 256 + lane * 4);
+    const f32x4 dt = *(const f32x4*)(dim_t + ((lane * 4) & 127));
+    const float bx = b3[0], by = b3[1];
+    for (long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6); q < Q; q += (long)gridDim.x * 4) {
+        const f32x4 v = *(const f32x4*)(h + q * ld_h + lane * 4);
+        float dx = v[0] * w0[0], dy = v[0] * w1[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            dx = fmaf(v[i], w0[i], dx);
+            dy = fmaf(v[i], w1[i], dy);
+        }
+        dx = wave_sum(dx) + bx;
+        dy = wave_sum(dy) + by;
+        const float rx = sigmoidf(dx + inv_sigmoid(ref[q * 2])), ry = sigmoidf(dy + inv_sigmoid(ref[q * 2 + 1]));
+        if (lane == 0) {
+            new_ref[q * 2] = rx;
+            new_ref[q * 2 + 1] = ry;
+        }
+        if (pos) {
+            const float e = (lane < 32 ? rx * sx : ry * sy) * 6.283185307179586f;       // channels [0,128) <- x, [128,256) <- y
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = e / dt[i];
+                o[i] = (i & 1) ? cosf(a) : sinf(a);
+            }
+            *(f32x4*)(pos + q * 256 + lane * 4) = o;
+        }
+    }
+}
+
 // A8: per-token proposal validity for an unpadded level pyramid (deformable_transformer.py:113-133):
 // valid[s] = all of ((col+0.5)/W, (row+0.5)/H) in (0.01, 0.99).
 __global__ __launch_bounds__(256) void proposal_valid_kernel(const int64_t* __restrict__ shapes,
@@ -278,6 +320,19 @@ extern "C" int gom_ref_sigmoid_f32(const float* delta, int ld_delta, const float
     GOM_CHECK_ARG(delta && ref && out && num_points >= 0 && (C == 2 || C == 4) && ld_delta >= C);
     if (num_points == 0) return GOM_OK;
     hipLaunchKernelGGL(ref_sigmoid_kernel, GOM_GRID(num_points * C), delta, ld_delta, ref, out, num_points, C);
+    return gom_launch_status();
+}
+
+extern "C" int gom_ref_update_f32(const float* h, int ld_h, const float* W3, const float* b3, const float* ref,
+                                  const float* dim_t128, float sx, float sy, float* new_ref, float* pos, long num_points,
+                                  void* stream) {
+    GOM_CHECK_ARG(h && W3 && b3 && ref && dim_t128 && new_ref && num_points >= 0 && ld_h >= 256 && (ld_h % 4) == 0);
+    GOM_CHECK_ARG(((uintptr_t)h % 16) == 0 && ((uintptr_t)W3 % 16) == 0 && ((uintptr_t)dim_t128 % 16) == 0 &&
+                  (pos == nullptr || ((uintptr_t)pos % 16) == 0));
+    if (num_points == 0) return GOM_OK;
+    const long blocks = (num_points + 3) / 4;
+    hipLaunchKernelGGL(ref_update_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, h,
+                       ld_h, W3, b3, ref, dim_t128, sx, sy, new_ref, pos, num_points);
     return gom_launch_status();
 }
 

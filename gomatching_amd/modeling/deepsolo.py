@@ -308,18 +308,21 @@ class DeepSolo:
         refs = refs.view(Q, 2)
         inter_refs = []
         E = 256
+        emb = None                   # the layer's point embedding, when the previous layer's refinement launch already made it
         for lid, L in enumerate(self.dec):
-            refs, tgt = self._decoder_layer(lid, L, tgt, refs, values, geo, B, vr)
+            refs, tgt, emb = self._decoder_layer(lid, L, tgt, refs, values, geo, B, vr, emb, lid + 1 < len(self.dec))
             inter_refs.append(refs)
         return tgt, inter_refs
 
-    def _decoder_layer(self, lid, L, tgt, refs, values, geo, B, vr):
+    def _decoder_layer(self, lid, L, tgt, refs, values, geo, B, vr, emb=None, more=False):
         nq, P, E = self.nq, self.P, 256
         Q = B * nq * P
         with ops.profile_scope("decoder_layer"):                 # bench.py: the launches that perform a layer's Q-side products
             # reference_points_input = reference_points * valid_ratios; the query position comes from level 0's (:470-473)
-            qref = refs if vr is None else ops.scale_xy_(refs.clone(), *geo["vr0"])
-            qpos = ops.point_pos_embed(qref, self.dim_t)
+            if emb is None:
+                qref = refs if vr is None else ops.scale_xy_(refs.clone(), *geo["vr0"])
+                emb = ops.point_pos_embed(qref, self.dim_t)
+            qpos = emb
             if self.ref_point_mlp2 is not None:
                 qpos = ops.mlp2_fused(qpos, self.ref_point_mlp2)
             else:
@@ -360,10 +363,15 @@ class DeepSolo:
                 h = ops.gemm(tgt, L["lin1"][0], bias=L["lin1"][1], relu=True)
                 x = ops.gemm(h, L["lin2"][0], bias=L["lin2"][1], R=tgt)
                 tgt = ops.layernorm(x, *L["norm3"])
-            # reference refinement (:484-488)
-            d = self._mlp3(tgt, self.ctrl_coord)
-            refs = ops.ref_sigmoid(d, refs, 2)
-        return refs, tgt
+            # reference refinement (:484-488); with the MLP's hidden layers fused, its N = 2 layer, the sigmoid update and the NEXT
+            # layer's point embedding (:470-473) are one launch
+            if ops.REF_UPDATE and self.ctrl_coord_mlp2 is not None:
+                refs, emb = ops.ref_update(ops.mlp2_fused(tgt, self.ctrl_coord_mlp2), self.ctrl_coord[2], refs, self.dim_t,
+                                           None if vr is None else geo["vr0"], want_pos=more)
+            else:
+                d = self._mlp3(tgt, self.ctrl_coord)
+                refs, emb = ops.ref_sigmoid(d, refs, 2), None
+        return refs, tgt, emb
 
     @staticmethod
     def _out_norm(x, L, name, tgt):
@@ -392,7 +400,9 @@ class DeepSolo:
         ref = inter_refs[self.n_dec - 2]
         cls = ops.gemm(hs, self.ctrl_class[0], bias=self.ctrl_class[1])                       # [Q,1]
         text = ops.gemm(hs, self.ctrl_text[0], bias=self.ctrl_text[1])                        # [Q,voc+1]
-        ctrl = ops.ref_sigmoid(self._mlp3(hs, self.ctrl_coord), ref, 2)
+        # pred_ctrl_points IS the last layer's refined reference: the same (shared, detection_transformer_wobackbone.py:141-155)
+        # MLP on the same hs plus the same inverse_sigmoid(reference), through the same sigmoid (deformable_transformer.py:484-488)
+        ctrl = inter_refs[self.n_dec - 1]
         bd = ops.ref_sigmoid(self._mlp3(hs, self.boundary), ref, 4)
         return {"pred_logits": cls, "pred_text_logits": text, "pred_ctrl_points": ctrl, "pred_bd_points": bd,
                 "query_features": hs}

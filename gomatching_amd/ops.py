@@ -974,6 +974,25 @@ def ref_sigmoid(delta, ref, C):
     return out
 
 
+REF_UPDATE = _switch("REF_UPDATE")   # decoder: last MLP layer (N = 2) + reference refinement + next layer's point embedding, one launch
+
+
+def ref_update(h, last, ref, dim_t, scale=None, want_pos=True):
+    """(new_ref [Q,2], pos [Q,256] | None): sigmoid(h @ W3^T + b3 + inverse_sigmoid(ref)) and the sine embedding of the new
+    reference points (times `scale` = the level-0 valid ratios of a padded batch); `last` = the (weight [2,256], bias) pair."""
+    W3, b3 = last
+    _chk_f32(ref, W3, b3, dim_t)
+    assert h.dim() == 2 and h.stride(1) == 1 and h.shape[1] == 256 and h.dtype == _f32 and tuple(W3.shape) == (2, 256)
+    Q = ref.numel() // 2
+    assert h.shape[0] == Q
+    new_ref = torch.empty_like(ref)
+    pos = torch.empty((Q, 256), dtype=_f32, device=ref.device) if want_pos else None
+    sx, sy = scale if scale is not None else (1.0, 1.0)
+    check(_L().gom_ref_update_f32(_p(h), h.stride(0) if Q > 1 else 256, _p(W3), _p(b3), _p(ref), _p(dim_t), float(sx), float(sy),
+                                  _p(new_ref), _p(pos), Q, _stream()), "gom_ref_update_f32")
+    return new_ref, pos
+
+
 def proposal_valid(shapes, lsi, S, vshapes=None):
     out = torch.empty((S,), dtype=torch.uint8, device=shapes.device)
     if vshapes is not None:

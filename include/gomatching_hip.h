@@ -314,6 +314,12 @@ int gom_point_pos_embed_f32(const float* pts, const float* dim_t128, float* out,
 /* out[q,c] = sigmoid(delta[q*ld_delta + c] + inverse_sigmoid(ref[q, c%2])), C in {2,4}. */
 int gom_ref_sigmoid_f32(const float* delta, int ld_delta, const float* ref, float* out, long num_points, int C,
                         void* stream);
+/* Reference refinement of a decoder layer + the next layer's point position embedding in one launch
+ * (deformable_transformer.py:484-488, :470-473): new_ref[q] = sigmoid(h[q] . W3^T + b3 + inverse_sigmoid(ref[q])),
+ * W3 [2,256]; pos [Q,256] (may be NULL) = gom_point_pos_embed_f32 of new_ref * (sx, sy). */
+int gom_ref_update_f32(const float* h, int ld_h, const float* W3, const float* b3, const float* ref,
+                       const float* dim_t128, float sx, float sy, float* new_ref, float* pos, long num_points,
+                       void* stream);
 int gom_proposal_valid(const int64_t* spatial_shapes, const int64_t* level_start_index, int num_levels,
                        unsigned char* valid, long S, void* stream);
 int gom_encoder_reference_points(const int64_t* spatial_shapes, const int64_t* level_start_index, int num_levels,

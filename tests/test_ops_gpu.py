@@ -609,3 +609,29 @@ def test_gemm_periodic_residual_equals_broadcast_table():
             ops.gemm(A, torch.randn((N, 256), device=DEV), R=table, r_period=S)
     finally:
         ops.GEMM_MODE = old
+
+
+def test_ref_update_equals_the_three_launches_it_replaces():
+    """N = 2 linear + ref_sigmoid + point_pos_embed (deformable_transformer.py:484-488, :470-473) as one launch: the same
+    reference points up to the dot product's summation order, the same embedding arithmetic on them."""
+    from gomatching_amd import ops
+    torch.manual_seed(3)
+    Q = 2500 * 3 + 7
+    h = torch.randn(Q, 256, device=DEV)
+    W3, b3 = torch.randn(2, 256, device=DEV) * 0.05, torch.randn(2, device=DEV) * 0.1
+    ref = torch.rand(Q, 2, device=DEV)
+    ref[:5] = torch.tensor([[0.0, 1.0], [1.0, 0.0], [1e-7, 0.5], [0.5, 1 - 1e-7], [0.3, 0.3]], device=DEV)   # the eps clamps
+    dim_t = 10000 ** (2 * torch.div(torch.arange(128, dtype=torch.float32), 2, rounding_mode="trunc") / 128)
+    dim_t = dim_t.to(DEV)
+    exp_ref = ops.ref_sigmoid(ops.gemm(h, W3, bias=b3), ref, 2)
+    for scale in (None, (0.75, 0.9)):
+        new_ref, pos = ops.ref_update(h, (W3, b3), ref, dim_t, scale)
+        assert float((new_ref - exp_ref).abs().max()) <= 2e-6
+        scaled = new_ref if scale is None else ops.scale_xy_(new_ref.clone(), *scale)
+        assert torch.equal(pos, ops.point_pos_embed(scaled, dim_t))          # same arithmetic on the same points: same bits
+    only_ref, none = ops.ref_update(h, (W3, b3), ref, dim_t, want_pos=False)
+    assert none is None and torch.equal(only_ref, new_ref)
+    wide = torch.randn(Q, 512, device=DEV)                                   # a column slice of a wider buffer (row stride 512)
+    got, _ = ops.ref_update(wide[:, 256:], (W3, b3), ref, dim_t, want_pos=False)
+    exp, _ = ops.ref_update(wide[:, 256:].contiguous(), (W3, b3), ref, dim_t, want_pos=False)
+    assert torch.equal(got, exp)
