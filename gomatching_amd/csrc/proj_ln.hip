@@ -46,6 +46,9 @@ struct ProjArgs {
     int* flag;
     float eps;
     int ldx, ldr, ldy, M, stagger;
+    const float* dot_w;                                      // dot form: out[m] = <Y[m, :], dot_w> + dot_b, Y itself is not stored
+    float* dot_out;
+    float dot_b;
 };
 
 __device__ __forceinline__ float row16_sum(float v) {        // sum over the 16 lanes of a DPP row, result in every lane
@@ -195,6 +198,10 @@ __global__ __launch_bounds__(256, 1) void proj_ln_kernel(const ProjArgs p) {
         ga[k] = *reinterpret_cast<const f32x4*>(p.gamma + col);
         be[k] = *reinterpret_cast<const f32x4*>(p.beta + col);
     }
+    f32x4 dw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        dw[k] = p.dot_out ? *reinterpret_cast<const f32x4*>(p.dot_w + (sub + 16 * k) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     int bad = range_bad;
 #pragma unroll 2
     for (int g = 0; g < 8; ++g) {
@@ -207,8 +214,8 @@ __global__ __launch_bounds__(256, 1) void proj_ln_kernel(const ProjArgs p) {
         for (int k = 0; k < 4; ++k) {
             const int ch = sub + 16 * k;
             const f32x4 y = *reinterpret_cast<const f32x4*>(stg + lr * D + ((ch ^ (lr & 7)) << 2));
-            const f32x4 r = *reinterpret_cast<const f32x4*>(p.R + (size_t)mc * p.ldr + ch * 4);
-            v[k] = y * sc[k] + bi[k] + r;                       // the tile kernel's epilogue: fma(acc, scale, bias) + residual
+            const f32x4 r = p.R ? *reinterpret_cast<const f32x4*>(p.R + (size_t)mc * p.ldr + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v[k] = p.R ? y * sc[k] + bi[k] + r : y * sc[k] + bi[k];   // the tile kernel's epilogue: fma(acc, scale, bias) [+ residual]
             sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
         }
         const float mean = row16_sum(sum) * (1.f / D);
@@ -219,11 +226,17 @@ __global__ __launch_bounds__(256, 1) void proj_ln_kernel(const ProjArgs p) {
             q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
         }
         const float rstd = rsqrtf(row16_sum(q) * (1.f / D) + p.eps);
+        float dot = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const f32x4 o = v[k] * rstd * ga[k] + be[k];
             bad |= !(fabsf(o[0]) <= 3.4e38f) | !(fabsf(o[1]) <= 3.4e38f) | !(fabsf(o[2]) <= 3.4e38f) | !(fabsf(o[3]) <= 3.4e38f);
-            if (m < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + (sub + 16 * k) * 4) = o;
+            if (p.dot_out) dot += (o[0] * dw[k][0] + o[1] * dw[k][1]) + (o[2] * dw[k][2] + o[3] * dw[k][3]);
+            else if (m < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + (sub + 16 * k) * 4) = o;
+        }
+        if (p.dot_out) {                                     // uniform
+            dot = row16_sum(dot) + p.dot_b;
+            if (sub == 0 && m < p.M) p.dot_out[m] = dot;
         }
     }
     if (bad && p.flag) atomicOr(p.flag, 1);                  // an operand left fp16's range (gemm_f16x3.hip contract)
@@ -261,11 +274,21 @@ extern "C" int gom_proj_ln_image(const void* w_planes, long w_plane_stride, int 
     return gom_launch_status();
 }
 
+static int proj_ln_launch(ProjArgs a, hipStream_t stream) {
+    a.stagger = cdiv(a.M, BM) >= 1024 ? 4 : 0;               // >= 4 rounds of workgroups
+    // (the attribute is per DEVICE: set on every launch -- a process-wide flag would miss a second GPU; it costs ~1 us)
+    hipError_t e = hipFuncSetAttribute((const void*)proj_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+    hipLaunchKernelGGL(proj_ln_kernel, dim3((unsigned)cdiv(a.M, BM)), dim3(256), LDS_BYTES, stream, a);
+    return gom_launch_status();
+}
+
+// R may be NULL: Y = LayerNorm(X W^T + b) (the encoder's enc_output + enc_output_norm pair, deformable_transformer.py:171-172)
 extern "C" int gom_proj_ln_f32(const float* X, int ldx, const void* image, const float* w_inv_scale, const float* bias,
                                const float* R, int ldr, const float* gamma, const float* beta, float eps, float* Y, int ldy,
                                int M, int* flag, void* stream) {
-    GOM_CHECK_ARG(X && image && w_inv_scale && R && gamma && beta && Y && M >= 0);
-    GOM_CHECK_ARG(ldx >= D && ldr >= D && ldy >= D && (ldx % 4) == 0 && (ldr % 4) == 0 && (ldy % 4) == 0);
+    GOM_CHECK_ARG(X && image && w_inv_scale && gamma && beta && Y && M >= 0);
+    GOM_CHECK_ARG(ldx >= D && (!R || ldr >= D) && ldy >= D && (ldx % 4) == 0 && (ldr % 4) == 0 && (ldy % 4) == 0);
     GOM_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)R % 16) == 0 && ((uintptr_t)Y % 16) == 0 &&
                   ((uintptr_t)image % 16) == 0 && ((uintptr_t)w_inv_scale % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) &&
                   ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0);
@@ -273,10 +296,24 @@ extern "C" int gom_proj_ln_f32(const float* X, int ldx, const void* image, const
     ProjArgs a{};
     a.X = X; a.img = (const unsigned char*)image; a.inv = w_inv_scale; a.bias = bias; a.R = R; a.gamma = gamma; a.beta = beta;
     a.Y = Y; a.flag = flag; a.eps = eps; a.ldx = ldx; a.ldr = ldr; a.ldy = ldy; a.M = M;
-    a.stagger = cdiv(M, BM) >= 1024 ? 4 : 0;                 // >= 4 rounds of workgroups
-    // (the attribute is per DEVICE: set on every launch -- a process-wide flag would miss a second GPU; it costs ~1 us)
-    hipError_t e = hipFuncSetAttribute((const void*)proj_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-    hipLaunchKernelGGL(proj_ln_kernel, dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
-    return gom_launch_status();
+    return proj_ln_launch(a, (hipStream_t)stream);
+}
+
+// out[m] = < LayerNorm(X[m] W^T + b) * gamma + beta , dot_w > + dot_b: the encoder's proposal class logit of EVERY token
+// (deformable_transformer.py:171-175 enc_output -> enc_output_norm -> bezier_class_embed) without the normalised rows ever
+// reaching HBM -- the 100 winners per frame are recomputed by gom_proj_ln_f32 on their gathered rows (same bits, row by row).
+extern "C" int gom_proj_ln_dot_f32(const float* X, int ldx, const void* image, const float* w_inv_scale, const float* bias,
+                                   const float* gamma, const float* beta, float eps, const float* dot_w, float dot_b,
+                                   float* out, int M, int* flag, void* stream) {
+    GOM_CHECK_ARG(X && image && w_inv_scale && gamma && beta && dot_w && out && M >= 0);
+    GOM_CHECK_ARG(ldx >= D && (ldx % 4) == 0);
+    GOM_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)image % 16) == 0 && ((uintptr_t)w_inv_scale % 16) == 0 &&
+                  (!bias || ((uintptr_t)bias % 16) == 0) && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 &&
+                  ((uintptr_t)dot_w % 16) == 0);
+    if (M == 0) return GOM_OK;
+    ProjArgs a{};
+    a.X = X; a.img = (const unsigned char*)image; a.inv = w_inv_scale; a.bias = bias; a.R = nullptr; a.gamma = gamma;
+    a.beta = beta; a.Y = nullptr; a.flag = flag; a.eps = eps; a.ldx = ldx; a.M = M;
+    a.dot_w = dot_w; a.dot_b = dot_b; a.dot_out = out;
+    return proj_ln_launch(a, (hipStream_t)stream);
 }

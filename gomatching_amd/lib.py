@@ -52,6 +52,7 @@ SIGNATURES = {
     "gom_proj_ln_image_bytes": (L, [I, I]),
     "gom_proj_ln_image": (I, [P, L, I, I, I, P, L, P]),
     "gom_proj_ln_f32": (I, [P, I, P, P, P, P, I, P, P, F, P, I, I, P, P]),
+    "gom_proj_ln_dot_f32": (I, [P, I, P, P, P, P, P, F, P, F, P, I, P, P]),
     "gom_gemm_k256_image_bytes": (L, [I, I]),
     "gom_gemm_k256_image": (I, [P, L, I, P, P, I, I, P, L, P]),
     "gom_gemm_k256_f32": (I, [P, P, I, P, P, I, I, I, P, I, I, I, I, I, P, P]),
@@ -80,7 +81,7 @@ SIGNATURES = {
     "gom_pos_encoding_2d_f32": (I, [P, P, P, I, I, P]),
     "gom_point_pos_embed_f32": (I, [P, P, P, L, P]),
     "gom_ref_sigmoid_f32": (I, [P, I, P, P, L, I, P]),
-    "gom_ref_update_f32": (I, [P, I, P, P, P, P, ctypes.c_float, ctypes.c_float, P, P, L, P]),
+    "gom_ref_update_f32": (I, [P, I, P, P, P, P, F, F, P, P, L, P]),
     "gom_proposal_valid": (I, [P, P, I, P, L, P]),
     "gom_encoder_reference_points": (I, [P, P, I, P, L, P]),
     "gom_bezier_reference_points": (I, [P, P, P, P, I, P, P, I, L, I, I, I, P]),

@@ -140,6 +140,12 @@ class DeepSolo:
         self.boundary_mlp2 = mlp2("boundary_offset.0", True)
         self.bezier_coord = [lin("bezier_proposal_coord.layers.%d" % i) for i in range(3)]
         self.bezier_class = lin("bezier_proposal_class")
+        # enc_output + enc_output_norm + the class logit of every token as ONE launch under the f16x3 back-end (csrc/proj_ln.hip,
+        # dot form): the normalised rows never reach HBM, the nq winners' rows are recomputed from their gathered memory rows
+        self.enc_output_ln = ops.proj_ln_block(self.enc_output, self.enc_output_norm) if ops.PROPOSAL_DOT else None
+        if self.enc_output_ln is not None:
+            self._cls_w = self.bezier_class[0].reshape(256).contiguous()
+            self._cls_b = float(self.bezier_class[1].reshape(-1)[0])
         self.ctrl_coord = [qlin(lin("ctrl_point_coord.0.layers.%d" % i)) for i in range(3)]      # last layer (N = 2): a pair
         self.ctrl_class = lin("ctrl_point_class.0")
         self.ctrl_text = lin("ctrl_point_text.0")
@@ -233,8 +239,11 @@ class DeepSolo:
         """Class logit of a zeroed memory row (what every invalid-proposal token gets in the reference)."""
         if self._invalid_logit is None:
             z = torch.zeros((1, 256), dtype=_f32, device=self.device)
-            om = ops.layernorm(ops.gemm(z, self.enc_output[0], bias=self.enc_output[1]), *self.enc_output_norm)
-            self._invalid_logit = ops.gemm(om, self.bezier_class[0], bias=self.bezier_class[1]).view(1)
+            if self.enc_output_ln is not None:
+                self._invalid_logit = ops.proj_ln_dot(z, self.enc_output_ln, self._cls_w, self._cls_b).view(1)
+            else:
+                om = ops.layernorm(ops.gemm(z, self.enc_output[0], bias=self.enc_output[1]), *self.enc_output_norm)
+                self._invalid_logit = ops.gemm(om, self.bezier_class[0], bias=self.bezier_class[1]).view(1)
         return self._invalid_logit
 
     # --------------------------------------------------------------------------------- pieces
@@ -284,12 +293,19 @@ class DeepSolo:
     def proposals(self, memory, geo, B):
         """A8: class logits for every token, top-k, Bezier proposals of the winners -> 25 reference points."""
         S = geo["S"]
-        om = ops.layernorm(ops.gemm(memory, self.enc_output[0], bias=self.enc_output[1]), *self.enc_output_norm)
-        enc_class = ops.gemm(om, self.bezier_class[0], bias=self.bezier_class[1])              # [B*S, 1]
+        if self.enc_output_ln is not None:
+            enc_class = ops.proj_ln_dot(memory, self.enc_output_ln, self._cls_w, self._cls_b).view(-1, 1)   # [B*S, 1]
+        else:
+            om = ops.layernorm(ops.gemm(memory, self.enc_output[0], bias=self.enc_output[1]), *self.enc_output_norm)
+            enc_class = ops.gemm(om, self.bezier_class[0], bias=self.bezier_class[1])          # [B*S, 1]
         topk, rows = ops.topk_tokens(enc_class, B, S, self.nq, valid=geo["valid"],
                                      invalid_logit=self.invalid_logit(), with_rows=True)
         rows = rows.view(-1)                       # coordinate MLP on the nq winning rows per frame only
-        h = ops.gemm(om, self.bezier_coord[0][0], bias=self.bezier_coord[0][1], rows=rows, relu=True)
+        if self.enc_output_ln is not None:
+            om_sel = ops.proj_ln(ops.gather_rows(memory, rows), self.enc_output_ln, None)
+            h = ops.gemm(om_sel, self.bezier_coord[0][0], bias=self.bezier_coord[0][1], relu=True)
+        else:
+            h = ops.gemm(om, self.bezier_coord[0][0], bias=self.bezier_coord[0][1], rows=rows, relu=True)
         h = ops.gemm(h, self.bezier_coord[1][0], bias=self.bezier_coord[1][1], relu=True)
         coord_sel = ops.gemm(h, self.bezier_coord[2][0], bias=self.bezier_coord[2][1])          # [B*nq, 8]
         refs = ops.bezier_reference_points(coord_sel, topk, geo["shapes"], geo["lsi"], self.bernstein, B, S, self.nq,

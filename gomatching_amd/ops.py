@@ -488,9 +488,9 @@ def proj_ln_block(pair, norm):
 
 
 def proj_ln(x, blk, R, out=None):
-    """LayerNorm(x @ W^T + b + R) * gamma + beta in one launch; x, R [M, 256] row-strided."""
+    """LayerNorm(x @ W^T + b [+ R]) * gamma + beta in one launch; x, R [M, 256] row-strided (R may be None)."""
     assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == 256 and x.dtype == _f32
-    assert R.shape == x.shape and R.stride(1) == 1 and R.dtype == _f32
+    assert R is None or (R.shape == x.shape and R.stride(1) == 1 and R.dtype == _f32)
     M = x.shape[0]
     if out is None:
         out = torch.empty((M, 256), dtype=_f32, device=x.device)
@@ -499,11 +499,37 @@ def proj_ln(x, blk, R, out=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     check(_L().gom_proj_ln_f32(_p(x), x.stride(0) if M > 1 else 256, _p(blk.image), _p(blk.W.inv_scale), _p(blk.bias), _p(R),
-                               R.stride(0) if M > 1 else 256, _p(blk.gamma), _p(blk.beta), blk.eps, _p(out),
-                               out.stride(0) if M > 1 else 256, M, _p(range_flag(x.device)), _stream()), "gom_proj_ln_f32")
+                               (R.stride(0) if M > 1 else 256) if R is not None else 0, _p(blk.gamma), _p(blk.beta), blk.eps,
+                               _p(out), out.stride(0) if M > 1 else 256, M, _p(range_flag(x.device)), _stream()),
+          "gom_proj_ln_f32")
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * 256 * 256, 12.0 * M * 256 + blk.image.numel(), "projln:%dx256x256" % M, _profile_scope))
+        prof.append((e0, e1, 2.0 * M * 256 * 256, (12.0 if R is not None else 8.0) * M * 256 + blk.image.numel(),
+                     "projln:%dx256x256" % M, _profile_scope))
+    return out
+
+
+PROPOSAL_DOT = _switch("PROPOSAL_DOT")   # f16x3 back-end: enc_output + norm + class logit of every token as one launch
+
+
+def proj_ln_dot(x, blk, w, b):
+    """[M] = <LayerNorm(x @ W^T + b) * gamma + beta, w> + b in one launch (the normalised rows are not stored); w [256] fp32
+    device tensor, b a Python float."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == 256 and x.dtype == _f32
+    _chk_f32(w)
+    assert w.numel() == 256
+    M = x.shape[0]
+    out = torch.empty((M,), dtype=_f32, device=x.device)
+    prof = _gemm_profile if (_gemm_profile is not None and M > 0) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().gom_proj_ln_dot_f32(_p(x), x.stride(0) if M > 1 else 256, _p(blk.image), _p(blk.W.inv_scale), _p(blk.bias),
+                                   _p(blk.gamma), _p(blk.beta), blk.eps, _p(w), float(b), _p(out), M, _p(range_flag(x.device)),
+                                   _stream()), "gom_proj_ln_dot_f32")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * 256 * 257, 4.0 * M * 257 + blk.image.numel(), "projln:%dx256x256" % M, _profile_scope))
     return out
 
 

@@ -174,6 +174,13 @@ int gom_proj_ln_image(const void* w_planes, long w_plane_stride, int ldw, int n,
 int gom_proj_ln_f32(const float* X, int ldx, const void* image, const float* w_inv_scale, const float* bias, const float* R,
                     int ldr, const float* gamma, const float* beta, float eps, float* Y, int ldy, int M, int* flag,
                     void* stream);
+/* R may be NULL in gom_proj_ln_f32 (Y = LayerNorm(X W^T + b): enc_output + enc_output_norm, deformable_transformer.py:171-172).
+ * Dot form: out[m] = <LayerNorm(X[m] W^T + b) * gamma + beta, dot_w[256]> + dot_b -- the proposal class logit of every encoder
+ * token (:171-175) with the normalised rows never stored; the winners' rows are recomputed by gom_proj_ln_f32 on the gathered
+ * rows (row-independent arithmetic: the same bits). */
+int gom_proj_ln_dot_f32(const float* X, int ldx, const void* image, const float* w_inv_scale, const float* bias,
+                        const float* gamma, const float* beta, float eps, const float* dot_w, float dot_b, float* out, int M,
+                        int* flag, void* stream);
 
 /* Tail of a ResNet bottleneck block fused with the head of the next (csrc/bneck_fused.hip; Detectron2 BottleneckBlock as built
  * through gom_lstmatcher.py:42-61, STRIDE_IN_1X1 = False, FrozenBN folded):

@@ -69,3 +69,34 @@ def test_proj_ln_strided_rows_wide_range_weights_in_place_and_range_flag():
         assert lib.load().gom_proj_ln_image_bytes(256, 512) == -1 and lib.load().gom_proj_ln_image_bytes(256, 256) == 4 * 65536
     finally:
         ops.GEMM_MODE = old
+
+
+@pytest.mark.parametrize("M", [1, 130, 37171])
+def test_no_residual_and_dot_form(M):
+    """R = None: LayerNorm(x W^T + b) (enc_output + enc_output_norm, deformable_transformer.py:171-172); dot form: the class
+    logit <LayerNorm(...), w> + b of every row without storing the rows (:175) -- against fp64, against the stored rows of the
+    same kernel, and row-independent (a gathered subset gives the same bits)."""
+    from gomatching_amd import ops
+    old, ops.GEMM_MODE = ops.GEMM_MODE, "f16x3"
+    try:
+        t = _case(M, seed=M + 1)
+        x, _, w, b, ga, be = [v.to(DEV) for v in t]
+        blk = ops.ProjLN(ops.split_weight(w, kind="f16x3"), b, ga, be)
+        g = torch.Generator().manual_seed(9)
+        cw, cb = torch.randn((256,), generator=g).to(DEV) * 0.1, -1.25
+        y = ops.proj_ln(x, blk, None)
+        logit = ops.proj_ln_dot(x, blk, cw, cb)
+        torch.cuda.synchronize()
+        ops.check_range_flag(DEV)
+        d = lambda v: v.double()
+        ref = torch.nn.functional.layer_norm(d(t[0]) @ d(t[2]).T + d(t[3]), (256,), d(t[4]), d(t[5]), 1e-5)
+        assert float((y.cpu().double() - ref).abs().max()) <= 2e-5
+        assert float((logit.cpu().double() - (ref @ cw.cpu().double() + cb)).abs().max()) <= 2e-5
+        assert float((logit - (y @ cw + cb)).abs().max()) <= 4e-6           # the same rows, the dot in another order
+        assert torch.equal(y, ops.proj_ln(x, blk, torch.zeros_like(x)))       # + 0 residual: the same bits
+        if M > 200:
+            rows = torch.randperm(M, generator=g)[:100].to(DEV)
+            assert torch.equal(ops.proj_ln(x[rows].contiguous(), blk, None), y[rows])
+            assert torch.equal(ops.proj_ln_dot(x[rows].contiguous(), blk, cw, cb), logit[rows])
+    finally:
+        ops.GEMM_MODE = old
