@@ -75,9 +75,11 @@ __device__ __forceinline__ void gom_split8_f16(const f32x4 a, const f32x4 b, hal
 // (the f16x3 range check).  The wave barriers keep the compiler from moving the exchange into divergent code.
 // `after_first_loads()` runs once, behind the first part's loads (where a kernel requests its first weight stage: the rows are
 // then ahead of it in the memory queue and the first split runs while the weights are still on their way).
-template <int W, bool ADD, typename FA, typename FB, typename FH>
-__device__ __forceinline__ void gom_rows_to_fragments(FA row_a, FB row_b, float* scratch, int lane, half8 (&xf)[2][16], float& amax,
-                                                      FH after_first_loads) {
+// K32 = true: the fragments of the 16x16x32 MFMA shape instead -- lane (n = lane & 15, kg = lane >> 4) ends up with floats
+// 32 s + 8 kg .. + 7 of row 16 R + n for every 32-wide k-step s and row group R, xf[plane][8 R + s].
+template <int W, bool ADD, bool K32, typename FA, typename FB, typename FH>
+__device__ __forceinline__ void gom_rows_to_fragments_t(FA row_a, FB row_b, float* scratch, int lane, half8 (&xf)[2][16], float& amax,
+                                                        FH after_first_loads) {
     constexpr int PC = W / 4;                                // 16-byte pieces of a row part
     constexpr int RPI = 64 / PC;                             // rows per wave-instruction
     constexpr int NI = 32 / RPI;                             // wave-instructions per part
@@ -103,16 +105,37 @@ __device__ __forceinline__ void gom_rows_to_fragments(FA row_a, FB row_b, float*
             *reinterpret_cast<f32x4*>(scratch + r * W + ((pc ^ (r & (PC - 1))) << 2)) = v[i];
         }
         __builtin_amdgcn_wave_barrier();
+        if constexpr (K32) {
+            const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
-        for (int s = 0; s < W / 16; ++s) {
-            const int p0 = 4 * s + 2 * fh;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(scratch + fr * W + ((p0 ^ (fr & (PC - 1))) << 2));
-            const f32x4 b = *reinterpret_cast<const f32x4*>(scratch + fr * W + (((p0 + 1) ^ (fr & (PC - 1))) << 2));
+            for (int s = 0; s < W / 32; ++s)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(a[e]), fabsf(b[e])));
-            gom_split8_f16(a, b, xf[0][part * (W / 16) + s], xf[1][part * (W / 16) + s]);
+                for (int R = 0; R < 2; ++R) {
+                    const int row = 16 * R + n, p0 = 8 * s + 2 * kg;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(scratch + row * W + ((p0 ^ (row & (PC - 1))) << 2));
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(scratch + row * W + (((p0 + 1) ^ (row & (PC - 1))) << 2));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(a[e]), fabsf(b[e])));
+                    gom_split8_f16(a, b, xf[0][8 * R + part * (W / 32) + s], xf[1][8 * R + part * (W / 32) + s]);
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < W / 16; ++s) {
+                const int p0 = 4 * s + 2 * fh;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(scratch + fr * W + ((p0 ^ (fr & (PC - 1))) << 2));
+                const f32x4 b = *reinterpret_cast<const f32x4*>(scratch + fr * W + (((p0 + 1) ^ (fr & (PC - 1))) << 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(a[e]), fabsf(b[e])));
+                gom_split8_f16(a, b, xf[0][part * (W / 16) + s], xf[1][part * (W / 16) + s]);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
     asm volatile("" : "+v"(amax));                           // decided here (dec_attn.hip: deferred compares spill)
+}
+
+template <int W, bool ADD, typename FA, typename FB, typename FH>
+__device__ __forceinline__ void gom_rows_to_fragments(FA row_a, FB row_b, float* scratch, int lane, half8 (&xf)[2][16], float& amax,
+                                                      FH after_first_loads) {
+    gom_rows_to_fragments_t<W, ADD, false>(row_a, row_b, scratch, lane, xf, amax, after_first_loads);
 }

@@ -9,22 +9,28 @@
 // HBM-bound at ~500 TFLOP/s even with perfect kernels.  Fused, the hidden activations never leave the CU: 2 KB per row.
 //
 // Structure (one workgroup = 4 waves = 128 rows, one wave per SIMD with the whole 512-register file):
-//   * each wave owns 32 rows.  Their two fp16 planes (x = x0 + x1, 22 significand bits: gemm_f16x3.hip) stay in 128 VGPRs for
-//     the whole kernel, already in the MFMA operand layout;
+//   * each wave owns 32 rows = two row groups of 16.  Their two fp16 planes (x = x0 + x1, 22 significand bits: gemm_f16x3.hip)
+//     stay in 128 VGPRs for the whole kernel, already in the MFMA operand layout;
+//   * MFMA shape v_mfma_f32_16x16x32_f16: on random data the chip holds a higher clock under it than under 32x32x16 at equal
+//     cycles per FLOP -- 1.22x the FLOP/s in a bare loop with this kernel's operand traffic, 1.3x with its VALU share beside
+//     it (tools/exp/mfma_shape_probe.py; MI355X_MICROARCH.md "DVFS give-back" item 7).  Same fragments per chunk, same LDS
+//     bytes per FLOP, same register budget; a k-step is 32 wide, so per output element the plane products are summed per 32
+//     (not 16) inputs: fp32-class like the tile kernel's order, not its bits (tests hold both to the same fp64 tolerance);
 //   * both products are computed TRANSPOSED so that the row of X is the LANE of every accumulator:
 //       H^T[32 hidden x 32 rows]  = W1c[32 x 256] . X^T        (A = weight fragment from LDS, B = X fragment in registers)
 //       Y^T[256 x 32 rows]       += W2[:, chunk] . H^T          (A = weight fragment from LDS, B = H^T)
-//     The accumulator of the first product IS the B operand of the second once its registers 8u..8u+7 are converted to fp16
-//     (cdna_hip_programming.md §3, "An accumulator tile as the next MFMA's operand"): no LDS round trip, no shuffle.  The k
-//     order that conversion implies (slot (h, j) of k-step u <-> hidden unit 16u + 8(j>>2) + 4h + (j&3)) is baked into the
-//     weight image, which costs nothing: the weights are constants;
+//     The accumulators of the first product ARE the B operand of the second once converted to fp16: lane (row n, group g) holds
+//     hidden units 16 Hh + 4 g + i of the chunk (Hh = 0, 1; i = 0..3) -- exactly the eight k-slots the 32-wide k-step of the
+//     second product wants from it (cdna_hip_programming.md §3, "An accumulator tile as the next MFMA's operand"): no LDS round
+//     trip, no shuffle.  The k order that implies (slot j of lane group g <-> hidden unit 16 (j >> 2) + 4 g + (j & 3)) is baked
+//     into the weight image, which costs nothing: the weights are constants;
 //   * the weights (2 x 2 planes x F x 256 fp16 = 2 MB at F = 1024, L2-resident) stream through a two-stage LDS ring by LDS-DMA
-//     (`global_load_lds_dwordx4`), one 65 KB stage per 32 hidden units.  The image is FRAGMENT-LINEAR: every MFMA operand
+//     (`buffer_load_dwordx4 ... lds`), one 65 KB stage per 32 hidden units.  The image is FRAGMENT-LINEAR: every MFMA operand
 //     fragment is one contiguous KB in the order the lanes read it, so the DMA is a linear copy and every ds_read_b128 is
 //     conflict-free by construction;
-//   * epilogue: Y^T goes through the (now free) LDS ring to row-major, then one wave per row applies the weight scale, bias,
-//     residual and the LayerNorm of norm.hip (same two-pass arithmetic) and stores whole 1 KB rows.
-// MFMA work per 128 rows: 4 waves x 3072 v_mfma_f32_32x32x16_f16; LDS reads 2/3 KB per MFMA; L2 -> LDS 2 MB.
+//   * epilogue: Y^T goes through the (now free) LDS ring to row-major, then 16 lanes per row apply the weight scale, bias,
+//     residual and the LayerNorm of norm.hip (same two-pass arithmetic) and store whole 1 KB rows.
+// MFMA work per 128 rows: 4 waves x 6144 v_mfma_f32_16x16x32_f16; LDS reads 1/3 KB per MFMA; L2 -> LDS 2 MB.
 #include "common.h"
 
 namespace {
@@ -34,11 +40,15 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ f32x4 mfma16(const half8 a, const half8 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
 constexpr int D = 256;                                   // model width (fixed: every shipped config)
 constexpr int CH = 32;                                   // hidden units per weight chunk
 constexpr int FRAG = 1024;                               // bytes of one MFMA operand fragment (64 lanes x 8 fp16)
-constexpr int W1_FRAGS = (D / 16) * 2;                   // k-steps x planes
-constexpr int W2_FRAGS = (D / 32) * (CH / 16) * 2;       // n-tiles x k-steps x planes
+constexpr int W1_FRAGS = (D / 32) * (CH / 16) * 2;       // k-steps of 32 x hidden groups of 16 x planes
+constexpr int W2_FRAGS = (D / 16) * 2;                   // output groups of 16 x planes (ONE k-step: the chunk's 32 hidden units)
 constexpr int STAGE_FRAGS = W1_FRAGS + W2_FRAGS + 1;     // + one fragment of (1 / row scale, bias) of the chunk
 constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG;
 constexpr int BM = 128;
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 31, fh = lane >> 5;
+    const int fn = lane & 15, fg = lane >> 4;                // row inside a row group | k-group of an operand = feature quad of a result
     const long row0 = (long)blockIdx.x * BM + wave * 32;
 
     // Long launches (>= 4 rounds of workgroups): the first round starts STAGGERED, by up to 7 x stagger sleeps of ~0.4 us over
@@ -123,8 +133,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         for (int f = wave; f < STAGE_FRAGS; f += 4) dma_fragment(rs_img, src + f * FRAG, dst + f * FRAG);
     };
 
-    // ---- this wave's 32 rows of X as B-operand fragments: lane (r, h) holds X[row r][16 s + 8 h .. + 7], two planes -------
-    // (whole-line loads + a layout change in the ring's second slot, which the first stage does not use: common.h)
+    // ---- this wave's 32 rows of X as B-operand fragments: lane (n, kg) holds X[row 16 R + n][32 s + 8 kg .. + 7] in xf[.][8 R + s],
+    // two planes (whole-line loads + a layout change in the ring's second slot, which the first stage does not use: common.h)
     int range_bad = 0;                                       // an operand beyond fp16's range (gemm_f16x3.hip contract)
     half8 xf[2][D / 16];
     {
@@ -134,16 +144,16 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
             if (m > p.M - 1) m = p.M - 1;                     // tail rows recompute the last row (never stored)
             return p.X + (size_t)m * p.ldx;
         };
-        gom_rows_to_fragments<128, false>(xrow, xrow, reinterpret_cast<float*>(smem + STAGE_BYTES) + wave * (32 * 128), lane, xf, xmax,
-                                          [&]() { dma_stage(0, 0); });
+        gom_rows_to_fragments_t<128, false, true>(xrow, xrow, reinterpret_cast<float*>(smem + STAGE_BYTES) + wave * (32 * 128), lane, xf,
+                                                  xmax, [&]() { dma_stage(0, 0); });
         range_bad = !(xmax <= 65504.f);
     }
 
-    f32x16 acc2[D / 32];
+    f32x4 acc2[D / 16][2];                                   // [output group of 16][row group]
 #pragma unroll
-    for (int t = 0; t < D / 32; ++t)
+    for (int t = 0; t < D / 16; ++t)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) acc2[t][g] = 0.f;
+        for (int r = 0; r < 2; ++r) acc2[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -165,40 +175,49 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
 #define FFN_DMA(i) dma_fragment(rs_img, nsrc + (i) * 4 * FRAG, ndst + (i) * 4 * FRAG);
         const unsigned char* base = smem + st * STAGE_BYTES + lane * 16;
 
-        // The 64 weight fragments of the chunk are consumed in eight groups of eight (four k-steps); with ONE wave per SIMD
-        // nothing else hides the LDS latency, so group g + 1 is read into the other register set BEFORE the twelve MFMAs of
-        // group g are issued (explicit two-deep software pipeline; the sched_group_barrier pairs pin that order -- left alone
-        // the compiler issues every fragment read right in front of its MFMAs: 2 reads, wait, 3 MFMAs, ... = 28 % MFMA busy).
+        // The 64 weight fragments of the chunk are consumed in eight groups of eight; with ONE wave per SIMD nothing else hides
+        // the LDS latency, so group g + 1 is read into the other register set BEFORE the 24 MFMAs of group g are issued
+        // (explicit two-deep software pipeline; the sched_group_barrier pairs pin that order -- left alone the compiler issues
+        // every fragment read right in front of its MFMAs: reads, wait, MFMAs, ... = 28 % MFMA busy).
         half8 fa[8], fb[8];
 #define FFN_LOAD(dst, g)                                                                                      \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                          \
         dst[i_] = *reinterpret_cast<const half8*>(base + ((g) * 8 + i_) * FRAG);
 #define FFN_PIN3()                                        \
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
 #define FFN_PIN1()                                        \
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);   \
     __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
 #define FFN_PIN0()                                        \
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-        // ---- H^T chunk = W1c . X^T : one accumulator, 16 k-steps x 3 plane products (smallest terms first) ----
-        f32x16 acc1;
+    __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+        // ---- H^T chunk = W1c . X^T : 2 hidden groups x 2 row groups of 16 x 16, 8 k-steps x 3 plane products (smallest first);
+        //      fragment 4 i + 2 Hh + p of a group = plane p of hidden group Hh at the group's k-step i ----
+        f32x4 acc1[2][2];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) acc1[g] = 0.f;
+        for (int h_ = 0; h_ < 2; ++h_)
+#pragma unroll
+            for (int r_ = 0; r_ < 2; ++r_) acc1[h_][r_] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define FFN_GEMM1(src, g)                                                                                     \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
-        const int s_ = (g) * 4 + i_;                                                                          \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_ + 1], xf[0][s_], acc1, 0, 0, 0);             \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[1][s_], acc1, 0, 0, 0);                 \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[0][s_], acc1, 0, 0, 0);                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                        \
+        const int s_ = (g) * 2 + i_;                                                                          \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                      \
+            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                                  \
+                acc1[h_][r_] = mfma16(src[4 * i_ + 2 * h_ + 1], xf[0][8 * r_ + s_], acc1[h_][r_]);            \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                      \
+            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                                  \
+                acc1[h_][r_] = mfma16(src[4 * i_ + 2 * h_], xf[1][8 * r_ + s_], acc1[h_][r_]);                \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                      \
+            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                                  \
+                acc1[h_][r_] = mfma16(src[4 * i_ + 2 * h_], xf[0][8 * r_ + s_], acc1[h_][r_]);                \
     }
         FFN_LOAD(fa, 0)
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // group 0's reads come first, then (reads, MFMAs) pairs
@@ -207,33 +226,41 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         FFN_LOAD(fb, 3) FFN_GEMM1(fa, 2) FFN_DMA(6) FFN_DMA(7) FFN_DMA(8) FFN_PIN3()
         FFN_LOAD(fa, 4) FFN_GEMM1(fb, 3) FFN_DMA(9) FFN_DMA(10) FFN_DMA(11) FFN_PIN3()   // fa <- first group of W2 fragments
         __builtin_amdgcn_sched_barrier(0);
-        // ---- relu(acc / row scale + bias), split into two fp16 planes: registers 8u..8u+7 are the B fragment of k-step u ----
+        // ---- relu(acc / row scale + bias), split into two fp16 planes: the lane's 2 x 4 values of a row group are its eight
+        //      k-slots of the second product's B fragment ----
         const float* aux = reinterpret_cast<const float*>(smem + st * STAGE_BYTES + (W1_FRAGS + W2_FRAGS) * FRAG);
-        half8 hf[2][CH / 16];
+        half8 hf[2][2];                                          // [plane][row group]
+        {
+            f32x4 sc[2], bi[2];
 #pragma unroll
-        for (int u = 0; u < CH / 16; ++u) {
-            f32x4 v[2];
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int q = 2 * u + qq;
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(aux + 8 * q + 4 * fh);
-                const f32x4 bi = *reinterpret_cast<const f32x4*>(aux + CH + 8 * q + 4 * fh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[qq][e] = fmaxf(fmaf(acc1[4 * q + e], sc[e], bi[e]), 0.f);
-                    hmax = fmaxf(hmax, v[qq][e]);              // (never NaN after the max with 0) checked once, after the loop
-                }
+            for (int h_ = 0; h_ < 2; ++h_) {
+                sc[h_] = *reinterpret_cast<const f32x4*>(aux + 16 * h_ + 4 * fg);
+                bi[h_] = *reinterpret_cast<const f32x4*>(aux + CH + 16 * h_ + 4 * fg);
             }
-            split8(v[0], v[1], hf[0][u], hf[1][u]);
+#pragma unroll
+            for (int r_ = 0; r_ < 2; ++r_) {
+                f32x4 v[2];
+#pragma unroll
+                for (int h_ = 0; h_ < 2; ++h_)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[h_][e] = fmaxf(fmaf(acc1[h_][r_][e], sc[h_][e], bi[h_][e]), 0.f);
+                        hmax = fmaxf(hmax, v[h_][e]);          // (never NaN after the max with 0) checked once, after the loop
+                    }
+                split8(v[0], v[1], hf[0][r_], hf[1][r_]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- Y^T += W2[:, chunk] . H^T : eight independent accumulators; group g holds n-tiles 2g, 2g + 1 ----
+        // ---- Y^T += W2[:, chunk] . H^T : 16 output groups x 2 row groups, independent accumulators; fragment 2 i + p of group g =
+        //      plane p of output group 4 g + i ----
 #define FFN_GEMM2(src, g)                                                                                     \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
-        const int t_ = (g) * 2 + (i_ >> 1), u_ = i_ & 1;                                                      \
-        acc2[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_ + 1], hf[0][u_], acc2[t_], 0, 0, 0);     \
-        acc2[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], hf[1][u_], acc2[t_], 0, 0, 0);         \
-        acc2[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], hf[0][u_], acc2[t_], 0, 0, 0);         \
+        const int t_ = (g) * 4 + i_;                                                                          \
+        _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                                    \
+            acc2[t_][r_] = mfma16(src[2 * i_ + 1], hf[0][r_], acc2[t_][r_]);                                  \
+            acc2[t_][r_] = mfma16(src[2 * i_], hf[1][r_], acc2[t_][r_]);                                      \
+            acc2[t_][r_] = mfma16(src[2 * i_], hf[0][r_], acc2[t_][r_]);                                      \
+        }                                                                                                     \
     }
         FFN_LOAD(fb, 5) FFN_GEMM2(fa, 0) FFN_DMA(12) FFN_DMA(13) FFN_DMA(14) FFN_PIN3()
         FFN_LOAD(fa, 6) FFN_GEMM2(fb, 1) FFN_DMA(15) FFN_PIN1()
@@ -253,16 +280,15 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     range_bad |= !(hmax <= 65504.f);                         // beyond fp16: flagged, never a silent wrong result
     // ---- epilogue: Y^T (row of X on the lane, output feature in the registers) -> row-major through LDS ----
     float* stg = reinterpret_cast<float*>(smem);             // [128][256] fp32; 16-byte chunk c of row r at chunk c ^ (r & 7)
-    {
-        float* mine = stg + (wave * 32 + fr) * D;
 #pragma unroll
-        for (int t = 0; t < D / 32; ++t)
+    for (int r_ = 0; r_ < 2; ++r_) {
+        const int lr = wave * 32 + 16 * r_ + fn;
+        float* mine = stg + lr * D;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = {acc2[t][4 * q], acc2[t][4 * q + 1], acc2[t][4 * q + 2], acc2[t][4 * q + 3]};
-                const int chunk = 8 * t + 2 * q + fh;        // features 32 t + 8 q + 4 h .. + 3
-                *reinterpret_cast<f32x4*>(mine + ((chunk ^ (fr & 7)) << 2)) = v;
-            }
+        for (int t = 0; t < D / 16; ++t) {
+            const int chunk = 4 * t + fg;                    // features 16 t + 4 g .. + 3
+            *reinterpret_cast<f32x4*>(mine + ((chunk ^ (lr & 7)) << 2)) = acc2[t][r_];
+        }
     }
     // The residual rows of the row pass below (row 4 g + rsel of the wave's 32, chunks sub + 16 k) are all requested HERE, in
     // the accumulators' registers: one HBM / L2 latency, under the barrier and the first staged reads, instead of one in front
@@ -350,9 +376,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     if (bad && p.flag) atomicOr(p.flag, 1);                  // an activation left fp16's range (gemm_f16x3.hip contract)
 }
 
-// Fragment-linear weight image.  Per chunk c of 32 hidden units, 65 fragments of 1 KB; element j (0..7) of lane l = (r, h):
-//   f = 2 s + p      (s = 0..15)                 : plane p of W1s[32 c + r][16 s + 8 h + j]
-//   f = 32 + 4 t + 2 u + p  (t = 0..7, u = 0..1) : plane p of W2s[32 t + r][32 c + 16 u + 8 (j >> 2) + 4 h + (j & 3)]
+// Fragment-linear weight image.  Per chunk c of 32 hidden units, 65 fragments of 1 KB; element j (0..7) of lane l = (m, kg) =
+// (l & 15, l >> 4):
+//   f = 4 s + 2 Hh + p   (s = 0..7, Hh = 0..1)   : plane p of W1s[32 c + 16 Hh + m][32 s + 8 kg + j]
+//   f = 32 + 2 t + p     (t = 0..15)             : plane p of W2s[16 t + m][32 c + 16 (j >> 2) + 4 kg + (j & 3)]
 //   f = 64                                       : floats 0..31 = 1 / (row scale of W1s) of the chunk, 32..63 = b1 of the chunk
 // (W1s / W2s = the row-scaled planes of gom_split_f16x2).
 __global__ __launch_bounds__(256) void ffn_image_kernel(const unsigned short* __restrict__ p1, long ps1, int ld1,
@@ -363,13 +390,13 @@ __global__ __launch_bounds__(256) void ffn_image_kernel(const unsigned short* __
     const long total = (long)(F / CH) * STAGE_FRAGS * 512;
     if (i >= total) return;
     const int e = (int)(i % 512), f = (int)((i / 512) % STAGE_FRAGS), c = (int)(i / (512L * STAGE_FRAGS));
-    const int l = e >> 3, j = e & 7, r = l & 31, h = l >> 5;
+    const int l = e >> 3, j = e & 7, m = l & 15, kg = l >> 4;
     if (f < W1_FRAGS) {
-        const int s = f >> 1, pl = f & 1;
-        img[i] = p1[pl * ps1 + (size_t)(CH * c + r) * ld1 + 16 * s + 8 * h + j];
+        const int s = f >> 2, hh = (f >> 1) & 1, pl = f & 1;
+        img[i] = p1[pl * ps1 + (size_t)(CH * c + 16 * hh + m) * ld1 + 32 * s + 8 * kg + j];
     } else if (f < W1_FRAGS + W2_FRAGS) {
-        const int id = f - W1_FRAGS, t = id >> 2, u = (id >> 1) & 1, pl = id & 1;
-        img[i] = p2[pl * ps2 + (size_t)(32 * t + r) * ld2 + CH * c + 16 * u + 8 * (j >> 2) + 4 * h + (j & 3)];
+        const int id = f - W1_FRAGS, t = id >> 1, pl = id & 1;
+        img[i] = p2[pl * ps2 + (size_t)(16 * t + m) * ld2 + CH * c + 16 * (j >> 2) + 4 * kg + (j & 3)];
     } else {
         const int fi = e >> 1;                                // float index inside the fragment (two fp16 slots per float)
         float v = 0.f;

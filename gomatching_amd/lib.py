@@ -8,7 +8,7 @@ import os
 from ctypes import c_int, c_long, c_float, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgomatching_hip.so")
+LIB_PATH = os.environ.get("GOM_LIB_PATH") or os.path.join(HERE, "libgomatching_hip.so")   # (override: same-box A/B of two builds)
 
 GOM_OK = 0
 _ERR = {1: "GOM_ERR_INVALID_ARG (violated precondition)", 2: "GOM_ERR_UNSUPPORTED"}
