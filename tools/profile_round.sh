@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-alt-backends > $out/${tag}_bench_under_rocprof.json 2> $out/stats.err
 echo "stats rc $?"
 cp $out/stats/stats_kernel_stats.csv $out/${tag}_kernel_stats.csv 2>/dev/null
+python3 tools/trace_gap_sites.py $out/stats/stats_kernel_trace.csv passagg best > $out/${tag}_detector_pass_census.txt 2>> $out/stats.err
 rm -f $out/stats/stats_kernel_trace.csv
 GOM_BENCH_WRITE_GRIDS=$out/gemm_api_grids.json timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-backends > /dev/null 2> $out/pmc_fetch.err
 echo "fetch rc $?"

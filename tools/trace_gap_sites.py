@@ -35,6 +35,9 @@ def one_pass(path, which=-2, aggregate=False):
             byq[r.get("Queue_Id", "?")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows = sorted(max(byq.values(), key=len))
     marks = [i for i, r in enumerate(rows) if "stem_pool_kernel" in r[2]]
+    if which == "best":                                           # the pass with the least idle time = a graph replay
+        idle = lambda k: sum(max(rows[i][0] - rows[i - 1][1], 0) for i in range(marks[k] + 1, marks[k + 1]))
+        which = min(range(len(marks) - 1), key=idle)
     a, b = marks[which], marks[which + 1]
     short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "")[:60]
     t0 = rows[a][0]
@@ -59,6 +62,7 @@ def one_pass(path, which=-2, aggregate=False):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] in ("pass", "passagg"):
-        one_pass(sys.argv[1], int(sys.argv[3]) if len(sys.argv) > 3 else -2, sys.argv[2] == "passagg")
+        w = sys.argv[3] if len(sys.argv) > 3 else "-2"
+        one_pass(sys.argv[1], w if w == "best" else int(w), sys.argv[2] == "passagg")
     else:
         main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1)
