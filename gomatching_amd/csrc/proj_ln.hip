@@ -84,6 +84,9 @@ __device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)byte_offset, 0, 0, 0);
 }
 
+// FORM 0: + residual, rows stored (the attention blocks); 1: no residual, rows stored; 2: no residual, only <row, dot_w> + dot_b
+// stored.  Compile-time: as run-time branches the residual loads of form 0 were no longer batched (268 -> 405 us at 297k rows).
+template <int FORM>
 __global__ __launch_bounds__(256, 1) void proj_ln_kernel(const ProjArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void proj_ln_kernel(const ProjArgs p) {
     f32x4 dw[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        dw[k] = p.dot_out ? *reinterpret_cast<const f32x4*>(p.dot_w + (sub + 16 * k) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        dw[k] = FORM == 2 ? *reinterpret_cast<const f32x4*>(p.dot_w + (sub + 16 * k) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     int bad = range_bad;
 #pragma unroll 2
     for (int g = 0; g < 8; ++g) {
@@ -214,8 +217,12 @@ __global__ __launch_bounds__(256, 1) void proj_ln_kernel(const ProjArgs p) {
         for (int k = 0; k < 4; ++k) {
             const int ch = sub + 16 * k;
             const f32x4 y = *reinterpret_cast<const f32x4*>(stg + lr * D + ((ch ^ (lr & 7)) << 2));
-            const f32x4 r = p.R ? *reinterpret_cast<const f32x4*>(p.R + (size_t)mc * p.ldr + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            v[k] = p.R ? y * sc[k] + bi[k] + r : y * sc[k] + bi[k];   // the tile kernel's epilogue: fma(acc, scale, bias) [+ residual]
+            if constexpr (FORM == 0) {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(p.R + (size_t)mc * p.ldr + ch * 4);
+                v[k] = y * sc[k] + bi[k] + r;                   // the tile kernel's epilogue: fma(acc, scale, bias) + residual
+            } else {
+                v[k] = y * sc[k] + bi[k];
+            }
             sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
         }
         const float mean = row16_sum(sum) * (1.f / D);
@@ -231,10 +238,10 @@ __global__ __launch_bounds__(256, 1) void proj_ln_kernel(const ProjArgs p) {
         for (int k = 0; k < 4; ++k) {
             const f32x4 o = v[k] * rstd * ga[k] + be[k];
             bad |= !(fabsf(o[0]) <= 3.4e38f) | !(fabsf(o[1]) <= 3.4e38f) | !(fabsf(o[2]) <= 3.4e38f) | !(fabsf(o[3]) <= 3.4e38f);
-            if (p.dot_out) dot += (o[0] * dw[k][0] + o[1] * dw[k][1]) + (o[2] * dw[k][2] + o[3] * dw[k][3]);
+            if constexpr (FORM == 2) dot += (o[0] * dw[k][0] + o[1] * dw[k][1]) + (o[2] * dw[k][2] + o[3] * dw[k][3]);
             else if (m < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + (sub + 16 * k) * 4) = o;
         }
-        if (p.dot_out) {                                     // uniform
+        if constexpr (FORM == 2) {
             dot = row16_sum(dot) + p.dot_b;
             if (sub == 0 && m < p.M) p.dot_out[m] = dot;
         }
@@ -274,13 +281,19 @@ extern "C" int gom_proj_ln_image(const void* w_planes, long w_plane_stride, int 
     return gom_launch_status();
 }
 
+template <int FORM>
+static int proj_ln_launch_t(const ProjArgs& a, hipStream_t stream) {
+    // (the attribute is per DEVICE: set on every launch -- a process-wide flag would miss a second GPU; it costs ~1 us)
+    hipError_t e = hipFuncSetAttribute((const void*)proj_ln_kernel<FORM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+    hipLaunchKernelGGL(proj_ln_kernel<FORM>, dim3((unsigned)cdiv(a.M, BM)), dim3(256), LDS_BYTES, stream, a);
+    return gom_launch_status();
+}
+
 static int proj_ln_launch(ProjArgs a, hipStream_t stream) {
     a.stagger = cdiv(a.M, BM) >= 1024 ? 4 : 0;               // >= 4 rounds of workgroups
-    // (the attribute is per DEVICE: set on every launch -- a process-wide flag would miss a second GPU; it costs ~1 us)
-    hipError_t e = hipFuncSetAttribute((const void*)proj_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-    hipLaunchKernelGGL(proj_ln_kernel, dim3((unsigned)cdiv(a.M, BM)), dim3(256), LDS_BYTES, stream, a);
-    return gom_launch_status();
+    if (a.dot_out) return proj_ln_launch_t<2>(a, stream);
+    return a.R ? proj_ln_launch_t<0>(a, stream) : proj_ln_launch_t<1>(a, stream);
 }
 
 // R may be NULL: Y = LayerNorm(X W^T + b) (the encoder's enc_output + enc_output_norm pair, deformable_transformer.py:171-172)
