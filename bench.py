@@ -417,7 +417,7 @@ def main():
     # pointwise convolutions ("pw:", the same instantiation: csrc/gemm_f16x3.hip dispatch<0, 0>)
     bn_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("bneck:")]     # fused bottleneck tail + next head launches
     msda_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("msda:")]    # fused multi-scale deformable attention
-    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:", "decattn:", "bneck:", "msda:")))]
+    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:", "projdot:", "decattn:", "bneck:", "msda:")))]
     dur_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     flops = sum(p[2] for p in prof)
     alg_bytes = sum(p[3] for p in prof)
@@ -574,7 +574,7 @@ def main():
             pb = sum(p_[3] for p_ in pl_prof)
             line["roofline_proj_ln"] = {
                 "bound": "hbm", "kernel": "proj_ln_kernel", "achieved": pb / (pd * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
-                "frac": pb / (pd * 1e-3) / 1e12 / 8.0, "traffic": pmc_traffic("proj_ln_kernel"),
+                "frac": pb / (pd * 1e-3) / 1e12 / 8.0, "traffic": pmc_traffic("proj_ln_kernel<0>") or pmc_traffic("proj_ln_kernel"),
                 "launches_per_step": len(pl_prof) // PROFILE_STEPS, "avg_launch_us": pd * 1e3 / len(pl_prof),
                 "share_of_step_time": (pd / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
                 "note": "out_proj + residual + LayerNorm of every attention block in one launch (csrc/proj_ln.hip): 3 KB of "

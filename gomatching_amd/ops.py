@@ -529,7 +529,7 @@ def proj_ln_dot(x, blk, w, b):
                                    _stream()), "gom_proj_ln_dot_f32")
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * 256 * 257, 4.0 * M * 257 + blk.image.numel(), "projln:%dx256x256" % M, _profile_scope))
+        prof.append((e0, e1, 2.0 * M * 256 * 257, 4.0 * M * 257 + blk.image.numel(), "projdot:%dx256x257" % M, _profile_scope))
     return out
 
 
