@@ -43,6 +43,10 @@ SIGNATURES = {
     "gom_gemm_f32_f16x3": (I, [P, P, I, P, L, I, P, P, P, P, I, I, I, P, I, I, I, I, P, P]),
     "gom_gemm_f32_f16x3_rp": (I, [P, P, I, P, L, I, P, P, P, P, I, I, I, I, P, I, I, I, I, P, P]),
     "gom_conv2d_nhwc_f32_f16x3": (I, [P, P, L, I, P, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, L, I, P, P]),
+    "gom_conv3x3_patch_supported": (I, [I, I]),
+    "gom_conv3x3_patch_image_bytes": (L, [I, I]),
+    "gom_conv3x3_patch_image": (I, [P, L, I, I, I, P, L, P]),
+    "gom_conv3x3_patch_f32_f16x3": (I, [P, P, P, P, P, I, P, I, I, I, I, I, P, P]),
     "gom_bneck_image_bytes": (L, [I, I, I]),
     "gom_bneck_image": (I, [P, L, I, P, P, P, P, L, I, I, I, I, P, L, P]),
     "gom_bneck_f32": (I, [P, I, P, P, I, P, P, P, I, P, I, I, I, I, I, P, P]),

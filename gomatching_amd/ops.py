@@ -289,6 +289,9 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
     return out
 
 
+CONV3_PATCH = _switch("CONV3_PATCH")   # f16x3 back-end: 3x3 / stride 1 convolutions on the patch-resident kernel
+
+
 def conv2d_nhwc(x, w_ohwi, scale=None, shift=None, R=None, relu=False, stride=1, pad=0):
     """x [B,H,W,Cin] -> [B,OH,OW,Cout]; w [Cout,KH,KW,Cin] fp32, or a SplitWeight made by prep_conv_weight."""
     split = isinstance(w_ohwi, SplitWeight)
@@ -309,6 +312,20 @@ def conv2d_nhwc(x, w_ohwi, scale=None, shift=None, R=None, relu=False, stride=1,
         if splits > 1:
             nbytes = 4 * splits * M * Cout
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        if (w_ohwi.kind == "f16x3" and CONV3_PATCH and KH == 3 and KW == 3 and stride == 1 and pad == 1 and R is None and splits <= 1
+                and _L().gom_conv3x3_patch_supported(Cin, Cout)):
+            # the bottlenecks' 3x3 / 1 convolutions: input patch resident in LDS (csrc/conv3x3_patch.hip)
+            img = getattr(w_ohwi, "patch_image", None)
+            if img is None:                                  # fragment-linear image of the planes, built once per weight
+                nb = _L().gom_conv3x3_patch_image_bytes(Cin, Cout)
+                img = torch.empty((nb,), dtype=torch.uint8, device=pl.device)
+                check(_L().gom_conv3x3_patch_image(_p(pl), pl.stride(0), pl.stride(1), Cin, Cout, _p(img), nb, _stream()),
+                      "gom_conv3x3_patch_image")
+                w_ohwi.patch_image = img
+            check(_L().gom_conv3x3_patch_f32_f16x3(_p(x), _p(img), _p(w_ohwi.inv_scale), _p(scale), _p(shift), 1 if relu else 0,
+                                                   _p(y), B, H, Wd, Cin, Cout, _p(range_flag(x.device)), _stream()),
+                  "gom_conv3x3_patch_f32_f16x3")
+            return y
         if w_ohwi.kind == "f16x3":
             # a pointwise convolution IS a launch of the GEMM tile kernel (dispatch<0, 0> in csrc/gemm_f16x3.hip): bench.py's
             # roofline sample of that kernel covers these launches too (label "pw:")

@@ -153,6 +153,17 @@ int gom_conv2d_nhwc_f32_f16x3(const float* X, const void* Wplanes, long w_plane_
                               const float* scale, const float* shift, const float* R, int relu, float* Y, int B, int H,
                               int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
                               long workspace_bytes, int splits, int* flag, void* stream);
+/* 3x3 / stride 1 / pad 1 convolution with the input patch resident in LDS (csrc/conv3x3_patch.hip): the bottleneck blocks'
+ * conv2 (Detectron2 BottleneckBlock behind gom_lstmatcher.py:42-61).  Cin and Cout multiples of 64
+ * (gom_conv3x3_patch_supported).  gom_conv3x3_patch_image: one-time fragment-linear image of the gom_split_f16x2 planes of
+ * W [Cout, 3, 3, Cin] (gom_conv3x3_patch_image_bytes bytes; -1 = shape not served); wscale = the split's inverse row scales.
+ * fp32-class like the implicit-GEMM kernel (k order: 64-channel chunk, tap, channel; 32-wide k-steps): not its bits. */
+int gom_conv3x3_patch_supported(int Cin, int Cout);
+long gom_conv3x3_patch_image_bytes(int Cin, int Cout);
+int gom_conv3x3_patch_image(const void* w_planes, long w_plane_stride, int ldw, int Cin, int Cout, void* image, long image_bytes,
+                            void* stream);
+int gom_conv3x3_patch_f32_f16x3(const float* X, const void* image, const float* wscale, const float* scale, const float* shift,
+                                int relu, float* Y, int B, int H, int Wd, int Cin, int Cout, int* flag, void* stream);
 /* The ResNet stem as one launch (csrc/stem_pool.hip): conv 7x7 / stride 2 / pad 3 from the 4-channel NHWC input to 64 channels
  * (weights = the gom_split_f16x2 planes of the [64, 7*7*4] matrix, K padded to ldw) + per-channel scale / shift (folded
  * BatchNorm, may be NULL) + ReLU + max_pool2d(3, stride 2, pad 1): Y [B, PH, PW, 64], PH = ((H - 1) / 2) / 2 + 1 likewise PW
