@@ -135,8 +135,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const PArgs p) {
 
     // operand lane (n = lane & 15, kg = lane >> 4): pixel n of a 16-pixel row (A) / column n of a 16-column group (B), k 8 kg .. + 7
     const int pp_base = (wr * 4) * PW + fn;                  // the lane's patch pixel for tile row 4 wr, tap (0, 0)
-    half8 af[2][MT];
-    auto load_A = [&](int r) {                               // k-tile r of the chunk: tap r >> 1 = 3 dy + dx, channels 32 (r & 1) .. + 31
+    // A fragments of two consecutive k-tiles in two register sets: the reads of the next k-tile are issued BEFORE the barrier and
+    // the products that separate it from its own (the patch does not change inside a chunk, and 18 k-tiles per chunk is even)
+    half8 afx[2][MT], afy[2][MT];
+    auto load_A = [&](int r, half8 (&af)[2][MT]) {           // k-tile r of the chunk: tap r >> 1 = 3 dy + dx, channels 32 (r & 1) .. + 31
         const int tap = r >> 1, dy = tap / 3, dx = tap - 3 * dy;
         const int slot = (r & 1) * 4 + fg;
 #pragma unroll
@@ -147,8 +149,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const PArgs p) {
             af[1][i] = *reinterpret_cast<const half8*>(a + P_PLANE);
         }
     };
-    auto mma = [&](int st, int k) {                          // k-tile k of ring stage st against the fragments in af
-        const unsigned char* w_base = Ws + (st & 1) * ST_BYTES + k * KT_BYTES + (wc * NT * 2) * FRAG + lane * 16;
+    auto mma = [&](int kt, const half8 (&af)[2][MT]) {       // k-tile kt of the launch (ring slot (kt / KPS) & 1) against af
+        const unsigned char* w_base = Ws + ((kt / KPS) & 1) * ST_BYTES + (kt % KPS) * KT_BYTES + (wc * NT * 2) * FRAG + lane * 16;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const half8 b0 = *reinterpret_cast<const half8*>(w_base + (2 * j) * FRAG);
@@ -163,37 +165,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const PArgs p) {
             }
         }
     };
+    bool fresh = chunks > 1;                                 // the 12 youngest requests are a patch that may stay in flight
+    // This wave's share of a stage has landed (a patch requested BEHIND it keeps flying for one more stage), its LDS writes are
+    // done; then everybody's: nobody still reads the other slot / the old patch.  (Not __syncthreads(): its fence waits for
+    // vmcnt(0), i.e. for the patch in flight.)
+    auto stage_sync = [&](int st) {
+        if (fresh) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        fresh = false;
+        if ((st + 1) * KPS < total) dma_W(st + 1);
+    };
 
-    constexpr int ST_PER_CHUNK = KT_PER_CHUNK / KPS;
-    const int stages = total / KPS;
     load_patch(0);
     dma_W(0);
     store_patch();
-    bool fresh = chunks > 1;                                 // the 12 youngest requests are a patch that may stay in flight
     if (fresh) load_patch(1);
-    for (int st = 0; st < stages; ++st) {
-        const int cc = st / ST_PER_CHUNK, rs = st - cc * ST_PER_CHUNK;
-        // this wave's share of stage st has landed (a patch requested BEHIND it keeps flying for one more stage)
-        if (fresh) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        fresh = false;
-        __syncthreads();                                     // ... everybody's; nobody still reads the other slot / the old patch
-        if (st + 1 < stages) dma_W(st + 1);
-#pragma unroll
-        for (int k = 0; k < KPS; ++k) {
-            load_A(rs * KPS + k);
-            mma(st, k);
-        }
-        if (rs == ST_PER_CHUNK - 1 && st + 1 < stages) {     // the next stage opens a chunk: its patch replaces this one
-            __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the first patch is in place
+    load_A(0, afx);
+    for (int kt = 0; kt < total; kt += 2) {                  // pairs of k-tiles never straddle a chunk
+        const int cc = kt / KT_PER_CHUNK, r = kt - cc * KT_PER_CHUNK;
+        stage_sync(kt / KPS);
+        load_A(r + 1, afy);
+        mma(kt, afx);
+        if (KPS == 1) stage_sync(kt + 1);
+        if (r + 2 < KT_PER_CHUNK) load_A(r + 2, afx);
+        mma(kt + 1, afy);
+        if (r + 2 == KT_PER_CHUNK && kt + 2 < total) {       // the next k-tile opens a chunk: its patch replaces this one
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             store_patch();
             if (cc + 2 < chunks) {
                 load_patch(cc + 2);
                 fresh = true;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            load_A(0, afx);
         }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // ---- epilogue: 32-pixel slabs (two tile rows) through the now free patch area to whole 16-byte pieces of NHWC rows ----
     int bad = !(amax <= 65504.f);                            // an input beyond fp16's range (gemm_f16x3.hip contract)
