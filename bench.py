@@ -43,7 +43,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha1()
     for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "proj_ln.hip", "msda.hip",
-                 "dec_attn.hip", "bneck_fused.hip", "common.h"):
+                 "dec_attn.hip", "bneck_fused.hip", "conv3x3_patch.hip", "common.h"):
         with open(os.path.join(ROOT, "gomatching_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -417,7 +417,8 @@ def main():
     # pointwise convolutions ("pw:", the same instantiation: csrc/gemm_f16x3.hip dispatch<0, 0>)
     bn_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("bneck:")]     # fused bottleneck tail + next head launches
     msda_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("msda:")]    # fused multi-scale deformable attention
-    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:", "projdot:", "decattn:", "bneck:", "msda:")))]
+    c3_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("conv3:")]     # patch-resident 3x3 convolutions
+    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:", "projdot:", "decattn:", "bneck:", "msda:", "conv3:")))]
     dur_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     flops = sum(p[2] for p in prof)
     alg_bytes = sum(p[3] for p in prof)
@@ -611,6 +612,18 @@ def main():
             "note": "conv3 + BN + residual + ReLU of a ResNet bottleneck block and conv1 + BN + ReLU of the next in one launch "
                     "(res2 / res3: csrc/bneck_fused.hip): the block's output is written once and not read back by conv1; 26-50 "
                     "FLOP per byte, an HBM-stream kernel"}
+    if c3_prof:
+        cd_ = sum(p_[0].elapsed_time(p_[1]) for p_ in c3_prof)
+        cb_, cf_ = sum(p_[3] for p_ in c3_prof), sum(p_[2] for p_ in c3_prof)
+        line["roofline_conv3x3"] = {
+            "bound": "mfma", "kernel": "conv3x3_patch_kernel<BN>", "achieved": cf_ / (cd_ * 1e-3) / 1e12, "peak": PEAKS["f16x3"][1],
+            "unit": "TFLOP/s", "frac": cf_ / (cd_ * 1e-3) / 1e12 / PEAKS["f16x3"][1], "traffic": pmc_traffic("conv3x3_patch_kernel"),
+            "hbm_view": {"achieved": cb_ / (cd_ * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s", "frac": cb_ / (cd_ * 1e-3) / 1e12 / 8.0},
+            "launches_per_step": len(c3_prof) // PROFILE_STEPS, "avg_launch_us": cd_ * 1e3 / len(c3_prof),
+            "share_of_step_time": (cd_ / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
+            "note": "conv2 (3x3 / 1) of the ResNet bottlenecks with the input patch resident in LDS and the weights streamed by "
+                    "LDS-DMA (csrc/conv3x3_patch.hip): 76-81 % matrix-pipe busy in its loop at the 1.4-1.6 GHz the chip holds under "
+                    "it (tools/exp/conv3_clock.py); the implicit-GEMM kernel it replaces ran these launches at ~0.30"}
     if dec_prof:
         T_ = cfg.MODEL.TRANSFORMER
         rows = FRAMES_PER_GPU * T_.NUM_QUERIES * T_.NUM_POINTS
@@ -645,7 +658,7 @@ def main():
     line["roofline_tile_gemm"] = line.pop("roofline")
     shares = {k_: line[k_].get("share_of_step_time", 0.0)
               for k_ in ("roofline_tile_gemm", "roofline_fused_ffn", "roofline_msda", "roofline_k256_long", "roofline_proj_ln",
-                         "roofline_bneck") if k_ in line}
+                         "roofline_bneck", "roofline_conv3x3") if k_ in line}
     top = max(shares, key=shares.get)
     line["roofline"] = {"bound": line[top]["bound"], "achieved": line[top]["achieved"], "peak": line[top]["peak"],
                         "unit": line[top]["unit"], "frac": line[top]["frac"], "traffic": line[top].get("traffic"),

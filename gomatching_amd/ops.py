@@ -322,9 +322,17 @@ def conv2d_nhwc(x, w_ohwi, scale=None, shift=None, R=None, relu=False, stride=1,
                 check(_L().gom_conv3x3_patch_image(_p(pl), pl.stride(0), pl.stride(1), Cin, Cout, _p(img), nb, _stream()),
                       "gom_conv3x3_patch_image")
                 w_ohwi.patch_image = img
+            prof = _gemm_profile
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             check(_L().gom_conv3x3_patch_f32_f16x3(_p(x), _p(img), _p(w_ohwi.inv_scale), _p(scale), _p(shift), 1 if relu else 0,
                                                    _p(y), B, H, Wd, Cin, Cout, _p(range_flag(x.device)), _stream()),
                   "gom_conv3x3_patch_f32_f16x3")
+            if prof is not None:
+                e1.record()
+                prof.append((e0, e1, 2.0 * M * Cout * 9 * Cin, 4.0 * M * (Cin + Cout) + 4.0 * 9 * Cin * Cout,
+                             "conv3:%dx%dx%d" % (M, Cout, 9 * Cin), _profile_scope))
             return y
         if w_ohwi.kind == "f16x3":
             # a pointwise convolution IS a launch of the GEMM tile kernel (dispatch<0, 0> in csrc/gemm_f16x3.hip): bench.py's
