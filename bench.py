@@ -135,6 +135,80 @@ def cpu_baseline(cfg, sd, shift, re_shift, frames_chw, orig_hw, gpu_res, gpu_id_
             "full_size_parity_clip": parity}
 
 
+LEGS = {"dstext": ("pp_dstext", [(1080, 1920)] * 8,
+                   "configs[3]: GoMatching_PP_DSText, 8 frames 1920x1080 -> 1280x2276, 300 queries, SHA_FFN_CRSATTN, no rescoring, NMS 0.3"),
+        "bovtext": ("bovtext", [(720, 1280)] * 3 + [(1080, 1920)] * 3 + [(1280, 720)] * 2,
+                    "configs[4]: GoMatching_BOVText, voc 5462 (bilingual head), ONE clip mixing 3 x 1280x720 + 3 x 1920x1080 + 2 x 720x1280 "
+                    "sources (-> 1000x1778 / 1000x1778 / 1778x1000), 100 queries, LSTMatcher")}
+
+
+def config_leg(leg, device, gemm, detect_frac, steps=6, warmup=2):
+    """Secondary figure for BASELINE.json configs[3] / configs[4] on ONE GPU: the reference's timed window
+    (text_track_visualizer.py:325-334: `batch_inference` of the clip + short-track removal + rescaling, frames in pinned host
+    memory, H2D inside) over an 8-frame synthetic clip, `steps` times back to back after `warmup`.  Each clip is one
+    `batch_inference` call (mixed sizes are split into per-size detector steps inside it, as the reference loops frames), so
+    unlike the headline there is no overlap ACROSS clips.  Also returns the per-stage split of one eager, synchronised clip."""
+    from gomatching_amd import ops
+    from gomatching_amd.config import setup_cfg
+    from gomatching_amd.predictor import GoMBatchPredictor, new_time_cost
+    from gomatching_amd.synth import make_clip
+    builtin, sizes, what = LEGS[leg]
+    cfg = setup_cfg(builtin=builtin)
+    cfg.MODEL.DEVICE = "cuda"
+    ops.GEMM_MODE = gemm
+    frames, t_of = [], {}
+    for hw in sizes:                                             # one scene per source size, consecutive time indices
+        t = t_of.get(hw, 0)
+        t_of[hw] = t + 1
+        frames.append((hw, t))
+    clips = {hw: make_clip(n, hw[0], hw[1], clip_id=40 + len(leg), num_rects=12) for hw, n in t_of.items()}
+    pred = GoMBatchPredictor(cfg, None)
+    inputs, src = [], []
+    for hw, t in frames:
+        x, shw = pred.prepare([clips[hw][t][:, :, ::-1]])
+        inputs.append(dict(x[0], image=x[0]["image"].pin_memory()))
+        src.append(shw)
+    model, sd = build_model(cfg, device)
+    calibrate(model, [dict(inputs[0], image=inputs[0]["image"].to(device))], frac=detect_frac)
+
+    def clip(tc):
+        insts, id_count = model.batch_inference(inputs, 0, 0, [], tc)
+        if model.min_track_len > 0:
+            insts = model._remove_short_track(insts)
+        return model.batch_postprocess(insts, src), id_count
+
+    for _ in range(2 + warmup):                                  # eager pass + hipGraph capture per step shape, then warm-up
+        clip(new_time_cost())
+    torch.cuda.synchronize()
+    tc = new_time_cost()
+    t0 = time.time()
+    for _ in range(steps):
+        res, id_count = clip(tc)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    graphed = bool(model.use_graphs and any(isinstance(v, dict) for v in model._graphs.values()))
+    tcs = new_time_cost(sync=True)                               # per-stage split: one eager clip with a sync after every stage
+    t1 = time.time()
+    clip(tcs)
+    torch.cuda.synchronize()
+    eager_ms = (time.time() - t1) * 1e3
+    out = {"value": len(inputs) * steps / dt, "unit": "frames/sec", "ms_per_clip": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+           "workload": what, "net_input_hw": sorted({tuple(x["image"].shape[-2:]) for x in inputs}),
+           "detector_steps_per_clip": [b - a for a, b in model._steps(inputs)],
+           "detector_hipgraph": graphed, "fallback_steps": int(model.fallback_steps),
+           "fused_inter_attention": all(L["inter_block"] is not None for L in model.detection_transformer.dec),
+           "detections_per_frame": [len(r["instances"]) for r in res], "tracks": int(id_count),
+           "stage_ms_per_clip_eager_synced": dict({k: v * 1e3 for k, v in tcs.items() if isinstance(v, float) and v > 0},
+                                                  whole_clip=eager_ms),
+           "note": "secondary figure (headline = configs[1]); one batch_inference call per clip, clips back to back without "
+                   "cross-clip overlap; parity of this configuration: tests/test_clips_fullsize_gpu.py"}
+    assert model.fallback_steps == 0 or gemm != "f16x3"
+    model.close()
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` outside torchrun: start N fresh child processes of this script, one per GPU (RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment; the reference starts its own workers the same way,
@@ -205,6 +279,11 @@ def main():
     ap.add_argument("--gemm", default="f16x3", choices=["f16x3", "bf16x6", "fp32"],
                     help="contraction back-end: two-plane fp16 split on the fp16 matrix cores (default), three-plane bf16 "
                          "split, or exact-fp32 MFMA")
+    ap.add_argument("--config", default="ic15", choices=["ic15", "dstext", "bovtext", "all"],
+                    help="ic15 = BASELINE.json configs[1], the headline (always measured); dstext / bovtext ADD the secondary leg of "
+                         "configs[3] (GoMatching_PP_DSText: 1920x1080 -> 1280x2276, 300 queries) / configs[4] (GoMatching_BOVText: voc "
+                         "5462, mixed-resolution clip) as `value_dstext` / `value_bovtext`; all = both (the default run's N=1 line carries both)")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the secondary configs[3] / configs[4] legs of the default run")
     ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU,
                     help="diagnostic: frames of the clip each rank owns per step (BASELINE.json: 8; the self-launch test compares "
                          "N=2 x 8 with N=1 x 16, the same 16-frame clip)")
@@ -667,6 +746,15 @@ def main():
                         "shares_of_step_time": shares,
                         "measured_in": line["roofline_tile_gemm"].get("measured_in")}
     solo = rank == 0 and world == 1 and args.backbone == "r50" and args.emulate_world == 1
+    line["fallback_steps"] = int(model.fallback_steps)          # steps of this run re-done on the bf16x6 twin (range flag tripped)
+    assert model.fallback_steps == 0 or args.gemm != "f16x3", "an f16x3 step fell back to bf16x6 inside the measurement"
+    legs = [] if (args.no_config_legs or not solo) else (["dstext", "bovtext"] if args.config in ("all", "ic15") else [args.config])
+    if legs:
+        del pipe
+        model._graphs.clear()                                    # the captured graph pins the headline model's activation pool
+        torch.cuda.empty_cache()
+    for leg in legs:
+        line["value_" + leg] = config_leg(leg, device, args.gemm, args.detect_frac)
     if solo and not args.no_alt_backends:
         # the other two contraction back-ends on the same window, a few steps each (secondary figures, same process)
         alt = {}

@@ -152,13 +152,98 @@ class GoMatchingMI355X(nn.Module):
         return training.forward_losses(self, batched_inputs)
 
 
-def register(registry=None):
-    """Register the class under ARCH_NAME in Detectron2's META_ARCH_REGISTRY (or in `registry`, any object with the fvcore
-    Registry interface)."""
+class _RoiHeadsMI355X(nn.Module):
+    """The association head as the class `build_roi_heads(cfg, input_shape)` constructs for `MODEL.ROI_HEADS.NAME`
+    (/root/reference/gomatching/modeling/roi_heads/lstmatcher.py:59-92, shared_ffn_crsattn.py:62-63): every `roi_heads.*` weight of
+    the reference's state dict is a parameter under the reference's name (prefix stripped), so `load_state_dict`, `children()`
+    and `rescoring_head.parameters()` work; the eval-time arithmetic (`match_scores`, `short_term_scores`, `_forward_transformer`,
+    `_activate_asso`; `impl().asso_head` / `impl().rescoring_head`, whose names are sub-modules here) goes to the HIP head (`modeling/roi_heads.py`), rebuilt from the
+    CURRENT parameter values when they changed."""
+    HEAD_NAME = None
+    _HIP = ("match_scores", "short_term_scores", "_forward_transformer", "_activate_asso", "feature_dim",
+            "asso_thresh_test")
+
+    def __init__(self, cfg, input_shape=None):
+        super().__init__()
+        self.cfg = _cfg_of(cfg).clone()
+        self.cfg.MODEL.ROI_HEADS.NAME = self.HEAD_NAME
+        for key, shape in canonical_keys(self.cfg).items():
+            parts = key.split(".")
+            if parts[0] != "roi_heads":
+                continue
+            node = self
+            for p in parts[1:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            node.register_parameter(parts[-1], nn.Parameter(torch.zeros(tuple(shape), dtype=torch.float32)))
+        self._hip = None
+        self._hip_version = None
+
+    def impl(self):
+        v = tuple(p._version for p in self.parameters()) + (str(next(self.parameters()).device),)
+        if self._hip is None or self._hip_version != v:
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("%s runs on an MI355X only: move the module to the GPU first" % type(self).__name__)
+            from ..modeling.roi_heads import build_roi_heads
+            self._hip = build_roi_heads(self.cfg, {"roi_heads." + k: t.detach() for k, t in self.state_dict().items()}, dev)
+            self._hip_version = v
+        return self._hip
+
+    def __getattr__(self, name):
+        if name in type(self)._HIP:
+            return getattr(self.impl(), name)
+        return super().__getattr__(name)
+
+    def forward(self, *args, **kw):
+        raise RuntimeError("the head is driven by the META_ARCH (gom_lstmatcher.py:157,286-349): build MODEL.META_ARCHITECTURE "
+                           "'GoMatching' / '%s' from gomatching_amd.compat.d2_register" % ARCH_NAME)
+
+
+class LSTMatcher(_RoiHeadsMI355X):
+    HEAD_NAME = "LSTMatcher"
+
+
+class SHA_FFN_CRSATTN(_RoiHeadsMI355X):
+    HEAD_NAME = "SHA_FFN_CRSATTN"
+
+
+_NAMED = {}
+
+
+def register(registry=None, name=None, roi_heads_registry=None):
+    """Register the META_ARCH class in Detectron2's META_ARCH_REGISTRY (or in `registry`, any object with the fvcore Registry
+    interface) under `name` (default ARCH_NAME).  `name="GoMatching"` takes the REFERENCE's name, so its yaml files
+    (`MODEL.META_ARCHITECTURE: "GoMatching"`, configs/*.yaml:2) build the MI355X model unchanged -- for checkouts that do not
+    import `gomatching.modeling` (whose own registration of that name would collide).  `roi_heads_registry` (or True for
+    Detectron2's ROI_HEADS_REGISTRY) additionally offers `LSTMatcher` / `SHA_FFN_CRSATTN` under the reference's names
+    (lstmatcher.py:59-60, shared_ffn_crsattn.py:62-63) to `build_roi_heads`.  Returns the registered META_ARCH class."""
     if registry is None:
         from detectron2.modeling.meta_arch.build import META_ARCH_REGISTRY as registry
+    cls = GoMatchingMI355X
+    if name is not None and name != ARCH_NAME:
+        cls = _NAMED.get(str(name))
+        if cls is None:
+            cls = _NAMED[str(name)] = type(str(name), (GoMatchingMI355X,), {"__doc__": GoMatchingMI355X.__doc__,
+                                                                            "__module__": __name__})
     try:
-        registry.register(GoMatchingMI355X)
-    except (AssertionError, KeyError):                           # already registered
-        pass
-    return GoMatchingMI355X
+        present = registry.get(cls.__name__)
+    except (KeyError, AssertionError):
+        present = None
+    if present is None:
+        registry.register(cls)
+    elif present is not cls and not (isinstance(present, type) and issubclass(present, GoMatchingMI355X)):
+        raise RuntimeError("META_ARCH name %r is already taken by %r (importing gomatching.modeling registers the reference's "
+                           "class under it): register the MI355X model under %r instead" % (cls.__name__, present, ARCH_NAME))
+    else:
+        cls = present
+    if roi_heads_registry is not None and roi_heads_registry is not False:
+        if roi_heads_registry is True:
+            from detectron2.modeling.roi_heads.roi_heads import ROI_HEADS_REGISTRY as roi_heads_registry
+        for head in (LSTMatcher, SHA_FFN_CRSATTN):
+            try:
+                roi_heads_registry.register(head)
+            except (AssertionError, KeyError):
+                pass
+    return cls

@@ -418,7 +418,9 @@ class DeepSolo:
         text = ops.gemm(hs, self.ctrl_text[0], bias=self.ctrl_text[1])                        # [Q,voc+1]
         # pred_ctrl_points IS the last layer's refined reference: the same (shared, detection_transformer_wobackbone.py:141-155)
         # MLP on the same hs plus the same inverse_sigmoid(reference), through the same sigmoid (deformable_transformer.py:484-488)
-        ctrl = inter_refs[self.n_dec - 1]
+        # -- for DEC_LAYERS >= 2.  With a single layer the reference's base is inter_references[-1], the already refined points
+        # (index last_lvl - 1 = -1), so the head output is one more application of the MLP on top of them.
+        ctrl = inter_refs[self.n_dec - 1] if self.n_dec >= 2 else ops.ref_sigmoid(self._mlp3(hs, self.ctrl_coord), ref, 2)
         bd = ops.ref_sigmoid(self._mlp3(hs, self.boundary), ref, 4)
         return {"pred_logits": cls, "pred_text_logits": text, "pred_ctrl_points": ctrl, "pred_bd_points": bd,
                 "query_features": hs}

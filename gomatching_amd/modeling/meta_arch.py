@@ -89,9 +89,10 @@ class GoMatching:
         """(backbone, DeepSolo) under the current contraction back-end (ops.GEMM_MODE)."""
         cfg = self.cfg
         if cfg.MODEL.BACKBONE.NAME == "build_swin_backbone":
-            if cfg.MODEL.SWIN.TYPE != "tiny":
-                raise NotImplementedError("only Swin-T is built (detection_transformer_wobackbone.py:61-64)")
-            backbone = SwinTiny(sd, self.device)
+            if cfg.MODEL.SWIN.TYPE not in ("tiny", "small"):
+                raise NotImplementedError("Swin-T and Swin-S are built (the types detection_transformer_wobackbone.py:61-64 "
+                                          "admits)")
+            backbone = SwinTiny(sd, self.device, swin_type=cfg.MODEL.SWIN.TYPE)
         elif cfg.MODEL.BACKBONE.NAME == "build_vitaev2_backbone":
             if cfg.MODEL.ViTAEv2.TYPE != "vitaev2_s":
                 raise NotImplementedError("only vitaev2_s exists (detection_transformer_wobackbone.py:64-68)")
@@ -460,6 +461,18 @@ class GoMatching:
             g["ids"] = inst.track_ids.detach().cpu().numpy().astype(np.int64)
         return g
 
+    def _nboxes(self, inst):
+        """Host boxes of a frame divided by ITS OWN image size (lstmatcher.py:478-494 `_get_boxes_time`: every frame of a window is
+        normalised by its own (w, h), which matters when a clip mixes resolutions -- BASELINE config #5).  The tracker kernels then
+        run with an image size of 1 x 1 (x / 1.0f is exact), so the fp32 quotient is formed once, here, as the reference forms it."""
+        g = self._host(inst)
+        nb = g.get("nboxes")
+        if nb is None or len(nb) != len(g["boxes"]):
+            h, w = inst.image_size
+            nb = g["boxes"].reshape(-1, 4).astype(np.float32) / np.array([w, h, w, h], np.float32)
+            g["nboxes"] = nb
+        return nb
+
     def _set_ids(self, inst, ids):
         """Inside `track_frames` ids live on the host while the recurrence runs and `_flush_ids` uploads them once."""
         g = self._host(inst)
@@ -615,7 +628,8 @@ class GoMatching:
         if n_k == 0 or M == 0:
             return np.zeros((n_k, M), np.float32), uniq, ids
         rows = np.concatenate([self._rows_full(w) for w in window])[sel_idx].astype(np.int32)
-        boxes = np.concatenate([h["boxes"] for h in hosts])[sel_idx].astype(np.float32)
+        boxes = np.concatenate([self._nboxes(w) for w in window])[sel_idx].astype(np.float32)
+        hw = (1.0, 1.0)                                          # boxes are normalised per frame already (_nboxes)
         nonk = np.nonzero(not_k)[0]
         k_inds = np.nonzero(~not_k)[0]
         col_of = np.searchsorted(uniq, ids)
@@ -672,7 +686,7 @@ class GoMatching:
                 continue
             for fr in (frames[t - 1], frames[t]):
                 rows.append(self._reid_rows(fr, np.ones((len(fr),), bool)))
-                boxes.append(self._host(fr)["boxes"])
+                boxes.append(self._nboxes(fr))
             pairs.append((off, n_prev, n_cur))
             which.append(t)
             off += n_prev + n_cur
@@ -688,7 +702,7 @@ class GoMatching:
             src_first, rows_first, boxes_first = src_all.clone(), rows_d.clone(), boxes_d.clone()
             if tap:
                 _rh.TAP = tap1 = [("src", src_all), ("rows", rows_d), ("boxes", boxes_d)]   # references: no extra kernels
-        scores = self.roi_heads.short_term_scores(src_all, pairs, boxes_d, frames[1].image_size, h2d=self._h2d)
+        scores = self.roi_heads.short_term_scores(src_all, pairs, boxes_d, (1.0, 1.0), h2d=self._h2d)
         flat = self._d2h(torch.cat([s.reshape(-1) for s in scores]))         # the one sync of the short-term path
         if check:                                                # diagnostic: were the inputs final when they were first read?
             _rh.TAP = None
@@ -701,7 +715,7 @@ class GoMatching:
             if tap:
                 _rh.TAP = tap2 = [("src", again), ("rows", rows_d), ("boxes", boxes_d)]
             flat2 = self._d2h(torch.cat([s.reshape(-1) for s in self.roi_heads.short_term_scores(
-                again, pairs, boxes_d, frames[1].image_size, h2d=self._h2d)]))
+                again, pairs, boxes_d, (1.0, 1.0), h2d=self._h2d)]))
             _rh.TAP = None
             if not np.isfinite(flat).all():
                 print("S of the FIRST evaluation is not finite: %d of %d elements" % (int((~np.isfinite(flat)).sum()), flat.size), flush=True)
@@ -945,7 +959,7 @@ class GoMatching:
         hosts = [self._host(w) for w in window]
         n = np.asarray([len(w) for w in window], np.int32)
         tot = int(n.sum())
-        boxes = np.ascontiguousarray(np.concatenate([h["boxes"].reshape(-1, 4) for h in hosts]) if tot
+        boxes = np.ascontiguousarray(np.concatenate([self._nboxes(w) for w in window]) if tot
                                      else np.zeros((0, 4)), dtype=np.float32)
         rows = np.ascontiguousarray(np.concatenate([self._rows_full(w) for w in window]) if tot else np.zeros((0,)),
                                     dtype=np.int32)
@@ -967,7 +981,7 @@ class GoMatching:
         self._hoist_projections(trk)
         idc = ctypes.c_long(int(id_count) if id_count else 0)
         secs = (ctypes.c_double * 2)(0.0, 0.0)
-        hw = dets[0].image_size
+        hw = (1.0, 1.0)                                          # per-frame normalisation happened in _nboxes
         ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         time_cost["short_match"] += time.time() - t0
         run_stream = ops._stream()

@@ -1,4 +1,4 @@
-"""Swin-T backbone driver (third_party/adet/modeling/swin/swin_transformer.py:491-724, built by the
+"""Swin-T / Swin-S backbone driver (third_party/adet/modeling/swin/swin_transformer.py:491-724, built by the
 reference through `build_swin_backbone` with out_features stage3..5).
 
 Tokens stay channels-last [B*H*W, C]; every Linear is one GEMM launch (bias / residual / in the epilogue), the window
@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..weights import SWIN_TINY
+from ..weights import SWIN_TYPES
 
 _f32 = torch.float32
 
@@ -45,9 +45,9 @@ class SwinTiny:
     channels = {"stage3": 192, "stage4": 384, "stage5": 768}
     size_divisibility = 32          # what the reference's module reports (:651); GoMatching never pads to it
 
-    def __init__(self, sd, device, prefix="backbone.0.backbone."):
+    def __init__(self, sd, device, prefix="backbone.0.backbone.", swin_type="tiny"):
         self.device = device
-        S = SWIN_TINY
+        S = SWIN_TYPES[swin_type]                                # tiny | small: the same blocks, stage-3 depth 6 | 18
         self.ws = S["window"]
         g = lambda k: sd[prefix + k].detach().float().contiguous().to(device)
         lin = lambda k: (ops.prep_weight(g(k + ".weight")), g(k + ".bias") if (prefix + k + ".bias") in sd else None)

@@ -402,8 +402,10 @@ def allreduce_gradients(parameters, group=None):
     12-33 M parameters (47-131 MB): one bucket is latency-optimal on the point-to-point xGMI ring.
     The bucket is RANK-INVARIANT: every parameter with `requires_grad`, in the order given, zeros where this rank has no
     gradient (a clip without ground-truth ids returns the zero loss, a clip whose short-term matcher had no rows leaves that
-    matcher's parameters without one -- on that rank only); the averaged gradient is written back to every one of them, as
-    DistributedDataParallel does.  No rank ever skips the collective."""
+    matcher's parameters without one -- on that rank only); the averaged gradient is written back to every parameter that had a
+    gradient on AT LEAST ONE rank, as DistributedDataParallel does.  A parameter no rank used keeps `grad = None` (one
+    "has a gradient" word per parameter travels at the end of the bucket), so weight decay / momentum treat it exactly as a
+    single-process run does.  No rank ever skips the collective."""
     torch = _torch()
     import torch.distributed as dist
     params = [p for p in parameters if p.requires_grad]
@@ -411,13 +413,18 @@ def allreduce_gradients(parameters, group=None):
         return 0
     if not params:
         return 0                                                 # rank-invariant: `requires_grad` is a property of the model
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=params[0].dtype, device=params[0].device)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params] + [has])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    used = flat[-len(params):].cpu() > 0
+    flat = flat[:-len(params)]
     flat /= dist.get_world_size(group)
     o = 0
-    for p in params:
+    for p, u in zip(params, used.tolist()):
         n = p.numel()
-        if p.grad is None:
+        if not u:
+            pass                                                 # unused on every rank: stays None
+        elif p.grad is None:
             p.grad = flat[o:o + n].view_as(p).clone()
         else:
             p.grad.copy_(flat[o:o + n].view_as(p.grad))
@@ -458,6 +465,10 @@ def forward_losses(model, batched_inputs):
         det = ops.detect_post(out["pred_logits"], re, out["pred_ctrl_points"], out["pred_bd_points"], recs, B, nq, P,
                               kind[1][0], kind[1][1], impl.test_score_threshold, 2.0, -1.0)
         torch.cuda.current_stream().synchronize()
+        if ops.GEMM_MODE == "f16x3":
+            # the range flag of the f16x3 kernels (`detect_launch` reads and clears it per inference step): an activation beyond
+            # fp16's range during a TRAINING forward must not feed the losses silently, nor stay set for the next inference step
+            ops.check_range_flag(qf.device)
     counts = det["count"].cpu().numpy()
     keep = det["keep_idx"].cpu().numpy()
     frames, targets, res_targets = [], [], []

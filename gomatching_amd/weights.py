@@ -41,11 +41,13 @@ def _resnet_keys(prefix="backbone.0.backbone."):
 
 
 SWIN_TINY = {"embed": 96, "depths": (2, 2, 6, 2), "heads": (3, 6, 12, 24), "window": 7}
+# the two types whose channels DeepSolo's input_proj admits (detection_transformer_wobackbone.py:59-62); swin_transformer.py:696-721
+SWIN_TYPES = {"tiny": SWIN_TINY, "small": dict(SWIN_TINY, depths=(2, 2, 18, 2))}
 
 
-def _swin_keys(prefix="backbone.0.backbone."):
-    """Swin-T, out_features stage3..5, patch_norm (swin_transformer.py:692-724)."""
-    S = SWIN_TINY
+def _swin_keys(prefix="backbone.0.backbone.", swin_type="tiny"):
+    """Swin-T / Swin-S, out_features stage3..5, patch_norm (swin_transformer.py:692-724)."""
+    S = SWIN_TYPES[swin_type]
     keys = {prefix + "patch_embed.proj.weight": (S["embed"], 3, 4, 4), prefix + "patch_embed.proj.bias": (S["embed"],)}
     _ln(keys, prefix + "patch_embed.norm", S["embed"])
     for i, (depth, heads) in enumerate(zip(S["depths"], S["heads"])):
@@ -259,7 +261,7 @@ def _roi_head_keys(cfg, prefix="roi_heads."):
 def canonical_keys(cfg):
     keys = {}
     name = cfg.MODEL.BACKBONE.NAME
-    keys.update(_swin_keys() if name == "build_swin_backbone" else _vitae_keys() if name == "build_vitaev2_backbone"
+    keys.update(_swin_keys(swin_type=cfg.MODEL.SWIN.TYPE) if name == "build_swin_backbone" else _vitae_keys() if name == "build_vitaev2_backbone"
                 else _resnet_keys())
     keys.update(_deepsolo_keys(cfg))
     keys.update(_roi_head_keys(cfg))

@@ -89,8 +89,30 @@ def main():
         for k in ("stage3", "stage4", "stage5"):
             out["%s_%s" % (k, tag)] = ref[k].numpy()
             print(tag, k, tuple(ref[k].shape), "oracle vs reference max|d| = %.2e" % float((ref[k] - mine[k]).abs().max()))
-    np.savez_compressed(os.path.join(GOLD, "swin_tiny.npz"), **out)
-    print("wrote", os.path.join(GOLD, "swin_tiny.npz"), os.path.getsize(os.path.join(GOLD, "swin_tiny.npz")))
+    if "--small-only" not in sys.argv:
+        np.savez_compressed(os.path.join(GOLD, "swin_tiny.npz"), **out)
+        print("wrote", os.path.join(GOLD, "swin_tiny.npz"), os.path.getsize(os.path.join(GOLD, "swin_tiny.npz")))
+    # Swin-S (swin_transformer.py:709-721: depths (2, 2, 18, 2), everything else as tiny), one odd-sized input
+    cfg.MODEL.SWIN.TYPE = "small"
+    sd = synth_state_dict(cfg, seed=4)
+    net = swin_mod.SwinTransformer(embed_dim=96, depths=(2, 2, 18, 2), num_heads=(3, 6, 12, 24), window_size=7,
+                                   mlp_ratio=4, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                                   drop_path_rate=0.3, ape=False, patch_norm=True, frozen_stages=-1,
+                                   out_features=["stage3", "stage4", "stage5"])
+    own = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    missing, unexpected = net.load_state_dict(own, strict=False)
+    assert not unexpected and all("relative_position_index" in k for k in missing), (missing, unexpected)
+    net.eval()
+    x = torch.randn(1, 3, 90, 130, generator=g)
+    with torch.no_grad():
+        ref = net(x)
+        mine = swin_oracle.swin_tiny(x, sd)
+    out = {"x_s": x.numpy()}
+    for k in ("stage3", "stage4", "stage5"):
+        out["%s_s" % k] = ref[k].numpy()
+        print("small", k, tuple(ref[k].shape), "oracle vs reference max|d| = %.2e" % float((ref[k] - mine[k]).abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "swin_small.npz"), **out)
+    print("wrote", os.path.join(GOLD, "swin_small.npz"), os.path.getsize(os.path.join(GOLD, "swin_small.npz")))
 
 
 if __name__ == "__main__":

@@ -745,7 +745,12 @@ def run_clip(sd, cfg, images, orig_hw=None):
         instances, id_count = track_clip(sd, cfg, per_frame)
         if cfg.VIDEO_TEST.MIN_TRACK_LEN > 0:
             instances = remove_short_track(cfg, instances)
-        hw = orig_hw if orig_hw is not None else (images[0].shape[-2], images[0].shape[-1])
+        if orig_hw is None:
+            sizes = [(im.shape[-2], im.shape[-1]) for im in images]
+        elif isinstance(orig_hw[0], (tuple, list)):             # one source size per frame (mixed-resolution clip)
+            sizes = [tuple(s) for s in orig_hw]
+        else:
+            sizes = [tuple(orig_hw)] * len(instances)
         vitae = cfg.MODEL.BACKBONE.NAME == "build_vitaev2_backbone"
-        return batch_postprocess(instances, [hw] * len(instances), cfg.INPUT.MIN_SIZE_TEST if vitae else None,
+        return batch_postprocess(instances, sizes, cfg.INPUT.MIN_SIZE_TEST if vitae else None,
                                  cfg.INPUT.MAX_SIZE_TEST if vitae else None), id_count

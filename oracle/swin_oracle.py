@@ -87,7 +87,7 @@ def _merge(x, H, W, sd, p):
     return F.linear(x, sd[p + "reduction.weight"])
 
 
-def swin_tiny(x, sd, prefix=PREFIX):
+def swin_tiny(x, sd, prefix=PREFIX, depths=None):
     """x: [B,3,H,W] normalised.  Returns {'stage3','stage4','stage5'} NCHW (strides 8, 16, 32), SwinTransformer.forward
     (:682-...) with out_features stage3..5 and patch_norm."""
     g = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
@@ -101,7 +101,10 @@ def swin_tiny(x, sd, prefix=PREFIX):
     x = x.flatten(2).transpose(1, 2)
     x = F.layer_norm(x, (EMBED,), g["patch_embed.norm.weight"], g["patch_embed.norm.bias"])
     outs = {}
-    for i, (depth, heads) in enumerate(zip(DEPTHS, HEADS)):
+    if depths is None:                                           # Swin-S = the same network with 18 stage-3 blocks (:709-721)
+        n3 = sum(1 for k in g if k.startswith("layers.2.blocks.") and k.endswith(".norm1.weight"))
+        depths = DEPTHS[:2] + (n3,) + DEPTHS[3:]
+    for i, (depth, heads) in enumerate(zip(depths, HEADS)):
         C = EMBED * 2 ** i
         mask = shift_mask(Wh, Ww)
         for b in range(depth):

@@ -1,0 +1,220 @@
+"""GPU, slow: TRACKED clips of BASELINE configs #3, #4 and #5 at full size against the CPU oracle.
+
+  #4  GoMatching++ / DSText: 8 frames 1920x1080 -> 1280x2276, 300 queries, SHA_FFN_CRSATTN, no rescoring, NMS 0.3, thr 0.5.
+  #5  BOVText: voc 5462, ONE batch_inference call over frames of 1280x720, 1920x1080 and 720x1280 sources
+      (-> 1000x1778, 1000x1778, 1778x1000 network inputs; the matcher normalises every frame's boxes by ITS size).
+  #3  64 frames of 1280x720 as eight sequential 8-frame shards on ONE GPU -> pack_records -> concatenation ->
+      unpack_records -> track_frames: ids equal to the single-process run and to the oracle's tracker.
+
+How the oracle is used (kept under ~5 min per test): the CPU detector (oracle.detect_frames, ~10-25 s per frame on 32 threads)
+runs on a SUBSET of the frames and must agree with the HIP detector there (same detections and characters, scores 1e-5,
+points 1e-3 px, embeddings 1e-4); the oracle's TRACKER (track_clip + remove_short_track + batch_postprocess) then runs over
+the HIP path's detections of ALL frames and must give identical ids.  GOM_FULL_ORACLE_CLIP=1 runs `oracle.run_clip` over
+every frame instead (the log of such a run is committed under profiles/).  Tolerances: north_star (ids / characters identical,
+points 1e-3 px; 6 ulp of the coordinate at 2276 px, see test_fullsize_gpu.py:53-55).
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from gomatching_amd.config import setup_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FULL = os.environ.get("GOM_FULL_ORACLE_CLIP") == "1"
+
+
+def _tc():
+    from gomatching_amd.predictor import new_time_cost
+    return new_time_cost()
+
+
+def _prepare(cfg, frames_rgb):
+    """Harness preparation per frame (each frame keeps its own source size)."""
+    from gomatching_amd.predictor import GoMBatchPredictor
+    inputs, sizes = [], []
+    for f in frames_rgb:
+        x, hw = GoMBatchPredictor(cfg, None).prepare([f[:, :, ::-1]])
+        inputs.append(x[0])
+        sizes.append(hw)
+    return inputs, sizes
+
+
+def _calibrate(cfg, image, frac, seed=2):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_fullsize_gpu import _calibrated_sd
+    return _calibrated_sd(cfg, seed=seed, image=image, frac=frac)
+
+
+def _px_tol(images):
+    return max(1e-3, 6.0 * float(np.spacing(np.float32(max(max(im.shape[-2:]) for im in images)))))
+
+
+def _oracle_insts(res):
+    """The HIP path's per-frame detections as oracle `Inst`s (embeddings + boxes + payload), for the oracle's tracker."""
+    from oracle import gom_oracle as O
+    out = []
+    for r in res:
+        out.append(O.Inst(tuple(r.image_size), reid_features=r.reid_features.detach().cpu().clone(),
+                          pred_boxes=r.pred_boxes.tensor.detach().cpu().clone(), scores=r.scores.detach().cpu().clone(),
+                          ctrl_points=r.ctrl_points.detach().cpu().clone().flatten(1), recs=r.recs.detach().cpu().clone(),
+                          bd=r.bd.detach().cpu().clone(), pred_classes=r.pred_classes.detach().cpu().clone()))
+    return out
+
+
+def _same_detections(got, ref, px_tol):
+    assert len(got) == len(ref), (len(got), len(ref))
+    if len(ref) == 0:
+        return
+    assert torch.equal(got["recs"], ref["recs"])
+    assert float((got["scores"] - ref["scores"]).abs().max()) <= 1e-5
+    for k in ("bd", "ctrl_points", "pred_boxes"):
+        assert float((got[k] - ref[k]).abs().max()) <= px_tol, k
+    assert float((got["reid_features"] - ref["reid_features"]).abs().max()) <= 1e-4
+
+
+def _clip_vs_oracle(builtin, frames_rgb, frac, check_frames, log):
+    """Runs the clip through `GoMatching.batch_inference` + short-track removal + rescaling and through the oracle."""
+    from oracle import gom_oracle as O
+    from gomatching_amd.modeling import GoMatching
+    cfg = setup_cfg(builtin=builtin)
+    cfg.MODEL.DEVICE = DEV
+    ocfg = setup_cfg(builtin=builtin)
+    ocfg.MODEL.DEVICE = "cpu"
+    inputs, sizes = _prepare(cfg, frames_rgb)
+    images = [x["image"] for x in inputs]
+    px_tol = _px_tol(images)
+    sd = _calibrate(cfg, images[0], frac)
+    model = GoMatching(cfg, sd, device=DEV, frames_per_step=8)
+    # the detections alone first (tracking drops the embeddings of frames that left the window, gom_lstmatcher.py:402-403):
+    # they feed the oracle's tracker; `batch_inference` then detects the same frames again (same bits: test_determinism_gpu.py)
+    model.begin_batch([], len(inputs))
+    raw = _oracle_insts(model.detect_steps(inputs, _tc()))
+    t0 = time.time()
+    insts, id_count = model.batch_inference(inputs, 0, 0, [], _tc())
+    torch.cuda.synchronize()
+    log["gpu_s"] = time.time() - t0
+    assert model.fallback_steps == 0
+    for a, b in zip(raw, insts):
+        assert torch.equal(a["scores"], b.scores.cpu()) and torch.equal(a["pred_boxes"], b.pred_boxes.tensor.cpu())
+    raw_ids = [x.track_ids.cpu().clone() for x in insts]
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    t0 = time.time()
+    if not FULL:
+        with torch.no_grad():
+            for f in check_frames:                                     # the CPU detector on a subset of the frames
+                _same_detections(raw[f], O.detect_frames(sd, ocfg, [images[f]])[0], px_tol)
+    kept = model._remove_short_track(list(insts)) if model.min_track_len > 0 else insts
+    res = model.batch_postprocess(kept, sizes)
+    log["detections"] = [len(x) for x in raw]
+    log["kept"] = [len(r["instances"]) for r in res]
+    log["tracks"] = int(id_count)
+    with torch.no_grad():
+        if FULL:
+            o_res, o_count = O.run_clip(sd, ocfg, images, orig_hw=sizes)
+        else:
+            o_inst, o_count = O.track_clip(sd, ocfg, raw)
+            for f, x in enumerate(o_inst):
+                assert x["track_ids"].tolist() == raw_ids[f].tolist(), ("ids before removal", f)
+            if ocfg.VIDEO_TEST.MIN_TRACK_LEN > 0:
+                o_inst = O.remove_short_track(ocfg, o_inst)
+            o_res = O.batch_postprocess(o_inst, sizes)
+    log["oracle_s"] = time.time() - t0
+    assert int(id_count) == int(o_count)
+    mx = 0.0
+    for f, (r, g) in enumerate(zip(o_res, res)):
+        r, g = r["instances"], g["instances"]
+        assert len(r) == len(g), ("frame", f, len(r), len(g))
+        if len(r) == 0:
+            continue
+        assert g.track_ids.cpu().tolist() == r["track_ids"].tolist(), ("ids", f)
+        assert torch.equal(g.recs.cpu(), r["recs"]), ("characters", f)
+        d = max(float((g.bd.cpu() - r["bd"]).abs().max()), float((g.ctrl_points.cpu().flatten(1) - r["ctrl_points"]).abs().max()))
+        mx = max(mx, d)
+        assert d <= px_tol, ("points", f, d)
+    log["max_abs_px"] = mx
+    log["px_tol"] = px_tol
+    log["mode"] = "oracle.run_clip over every frame" if FULL else \
+        "oracle detector on frames %s, oracle tracker over the HIP detections of all frames" % (list(check_frames),)
+    model.close()
+    return log
+
+
+def test_dstext_clip_300_queries_vs_oracle():
+    """Config #4 as a tracked clip: the matcher at n up to 300, SHA_FFN_CRSATTN, NMS 0.3, long-term windows of 6 frames."""
+    from gomatching_amd.synth import make_clip
+    frames = make_clip(8, 1080, 1920, clip_id=4, num_rects=14)
+    log = _clip_vs_oracle("pp_dstext", frames, 0.3, check_frames=(0, 5), log={"config": "pp_dstext 8 x 1920x1080 -> 1280x2276, nq 300"})
+    print("CLIP", log)
+    assert max(log["detections"]) >= 20 and log["tracks"] > max(log["detections"])
+
+
+def test_dstext_tracker_stress_every_query_a_detection():
+    """The tracker-stress variant of SURVEY.md 8-d at config #4: the class bias lets EVERY query through the threshold, so
+    frames carry up to 300 detections before NMS and the long-term windows approach 6 x 300 rows."""
+    from gomatching_amd.synth import make_clip
+    frames = make_clip(8, 1080, 1920, clip_id=5, num_rects=14)
+    log = _clip_vs_oracle("pp_dstext", frames, 1.0, check_frames=(), log={"config": "pp_dstext stress (every query passes)"})
+    print("CLIP", log)
+    assert max(log["detections"]) >= 100
+
+
+def test_bovtext_mixed_resolution_clip_vs_oracle():
+    """Config #5: bilingual head (voc 5462), one `batch_inference` call over 1280x720, 1920x1080 and 720x1280 sources."""
+    from gomatching_amd.synth import make_clip
+    a = make_clip(3, 720, 1280, clip_id=6, num_rects=10)
+    b = make_clip(3, 1080, 1920, clip_id=6, num_rects=10)               # same scene generator key: rectangles persist in
+    c = make_clip(2, 1280, 720, clip_id=6, num_rects=10)                # relative position across the size changes
+    frames = a + b + c
+    log = _clip_vs_oracle("bovtext", frames, 0.3, check_frames=(1, 4, 7), log={"config": "bovtext voc 5462, sources 3 x 1280x720 + 3 x 1920x1080 + 2 x 720x1280"})
+    print("CLIP", log)
+    assert min(log["detections"]) >= 3
+
+
+def test_64_frame_clip_as_eight_shards_on_one_gpu():
+    """Config #3's logic without the 8-GPU node: the eight ranks' work done one after the other on ONE GPU -- eight 8-frame
+    shards detected separately, each packed into the all-gather record (`pack_records`), the eight buffers concatenated in
+    rank order (what `all_gather_into_tensor` returns), unpacked and tracked once (`exchange_and_track`'s second half).  Track
+    ids must equal those of the single-process `batch_inference` over the 64 frames AND the oracle's tracker."""
+    from oracle import gom_oracle as O
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.synth import make_clip
+    from gomatching_amd.dist import pack_records, unpack_records
+    cfg = setup_cfg(builtin="icdar15")
+    cfg.MODEL.DEVICE = DEV
+    ocfg = setup_cfg(builtin="icdar15")
+    ocfg.MODEL.DEVICE = "cpu"
+    frames = make_clip(64, 720, 1280, clip_id=3, num_rects=12)
+    inputs, sizes = _prepare(cfg, frames)
+    sd = _calibrate(cfg, inputs[0]["image"], 0.3)
+    T = cfg.MODEL.TRANSFORMER
+    model = GoMatching(cfg, sd, device=DEV, frames_per_step=8)
+    single, count_single = model.batch_inference(inputs, 0, 0, [], _tc())
+    ids_single = [x.track_ids.cpu().tolist() for x in single]
+    model.begin_batch([], 64)
+    raw = _oracle_insts(model.detect_steps(inputs, _tc()))
+    recs = []
+    for r in range(8):                                                 # "rank" r: its block of 8 frames
+        model.begin_batch([], 8)
+        dets = model.detect_steps(inputs[8 * r:8 * r + 8], _tc())
+        recs.append(pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, model.device).clone())
+    allrec = torch.cat(recs)                                           # rank order = frame order
+    model.begin_batch([], 64)
+    all_dets = unpack_records(allrec, single[0].image_size, model.roi_heads.feature_dim, T.NUM_POINTS)
+    sharded, count_sharded = model.track_frames(all_dets, 0, 0, [], _tc())
+    ids_sharded = [x.track_ids.cpu().tolist() for x in sharded]
+    assert ids_sharded == ids_single and int(count_sharded) == int(count_single)
+    with torch.no_grad():
+        o_inst, o_count = O.track_clip(sd, ocfg, raw)
+    assert [x["track_ids"].tolist() for x in o_inst] == ids_single and int(o_count) == int(count_single)
+    kept = model._remove_short_track(sharded)
+    o_kept = O.remove_short_track(ocfg, o_inst)
+    assert [x.track_ids.cpu().tolist() for x in kept] == [x["track_ids"].tolist() for x in o_kept]
+    n = [len(x) for x in ids_single]
+    print("CLIP64 detections/frame %s tracks %d kept/frame %s" % (n, int(count_single), [len(x) for x in kept]))
+    assert min(n) >= 5 and int(count_single) > max(n)
+    model.close()

@@ -63,3 +63,37 @@ def test_meta_arch_wrapper_in_the_shim_registry():
     assert model.min_track_len == cfg.VIDEO_TEST.MIN_TRACK_LEN
     with pytest.raises(RuntimeError, match="MI355X"):            # no CPU path: inference before .to('cuda') fails loudly
         model.batch_inference([], 0, 0, [], {})
+
+
+def test_registration_under_the_reference_names():
+    """north_star: the reference's yaml files name `MODEL.META_ARCHITECTURE: "GoMatching"` (configs/*.yaml:2) and
+    `MODEL.ROI_HEADS.NAME: LSTMatcher | SHA_FFN_CRSATTN`; `register(name="GoMatching", roi_heads_registry=...)` offers the MI355X
+    classes under exactly those names (for checkouts that do not import `gomatching.modeling`, whose registration would collide)."""
+    from oracle import ref_shim
+    from gomatching_amd.compat import d2_register
+    from gomatching_amd.weights import canonical_keys
+    ref_shim.install()
+    meta, heads = type(ref_shim._Registry())(), type(ref_shim._Registry())()
+    cls = d2_register.register(meta, name="GoMatching", roi_heads_registry=heads)
+    assert meta.get("GoMatching") is cls and cls.__name__ == "GoMatching" and issubclass(cls, d2_register.GoMatchingMI355X)
+    assert d2_register.register(meta, name="GoMatching") is cls                 # idempotent
+    d2_register.register(meta)                                                  # and the MI355X name beside it
+    assert meta.get(d2_register.ARCH_NAME) is d2_register.GoMatchingMI355X
+    for builtin, name, n_params in (("icdar15", "LSTMatcher", 32794881), ("pp_dstext", "SHA_FFN_CRSATTN", 11802881)):
+        cfg = mini_cfg(builtin)
+        assert cfg.MODEL.ROI_HEADS.NAME == name
+        head = heads.get(name)(cfg, None)                                        # build_roi_heads(cfg, input_shape)
+        assert isinstance(head, torch.nn.Module) and type(head).__name__ == name
+        want = {k[len("roi_heads."):]: tuple(s) for k, s in canonical_keys(cfg).items() if k.startswith("roi_heads.")}
+        got = {k: tuple(p.shape) for k, p in head.named_parameters()}
+        assert got == want
+        n = sum(p.numel() for p in head.parameters())
+        assert n == n_params - (0 if cfg.MODEL.ROI_HEADS.WITH_RESR else 0) or n == n_params - 257, (name, n)
+        sd = synth_state_dict(cfg, seed=3)
+        res = head.load_state_dict({k[len("roi_heads."):]: torch.as_tensor(v).float() for k, v in sd.items()
+                                    if k.startswith("roi_heads.")})
+        assert not res.missing_keys and not res.unexpected_keys
+        with pytest.raises(RuntimeError, match="MI355X"):
+            head.match_scores                                                    # the arithmetic lives on the GPU only
+        model = cls(cfg)                                                         # the yaml's META_ARCHITECTURE builds the wrapper
+        assert [n_ for n_, _ in model.roi_heads.named_children()][0] == "asso_head"

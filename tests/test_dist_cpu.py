@@ -97,7 +97,7 @@ def _grad_worker(rank, world, port, q):
         for i, p in enumerate(params):
             ok &= bool(torch.allclose(p.grad, torch.full_like(p, (1 + 2) / 2 * (i + 1))))
         ok &= only0.grad is not None and bool(torch.allclose(only0.grad, torch.full_like(only0, 4.0)))
-        ok &= nowhere.grad is not None and float(nowhere.grad.abs().max()) == 0.0
+        ok &= nowhere.grad is None                                  # unused on every rank: untouched, as under DDP
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -33,3 +33,17 @@ def test_shift_mask_and_relative_index_shapes():
     assert m.shape == (2 * 3, 49, 49) and set(np.unique(m.numpy()).tolist()) <= {0.0, -100.0}
     idx = swin_oracle.relative_position_index()
     assert idx.shape == (49, 49) and int(idx.min()) == 0 and int(idx.max()) == 168
+
+
+def test_oracle_matches_reference_module_swin_small():
+    """Swin-S (depths 2, 2, 18, 2; swin_transformer.py:709-721) against the reference module's outputs."""
+    cfg = setup_cfg(builtin="icdar15")
+    cfg.MODEL.BACKBONE.NAME = "build_swin_backbone"
+    cfg.MODEL.SWIN.TYPE = "small"
+    sd = synth_state_dict(cfg, seed=4)
+    assert "backbone.0.backbone.layers.2.blocks.17.norm1.weight" in sd
+    g = golden("swin_small.npz")
+    with torch.no_grad():
+        out = swin_oracle.swin_tiny(torch.from_numpy(g["x_s"]), sd)
+    for k in ("stage3", "stage4", "stage5"):
+        assert float(np.abs(out[k].numpy() - g[k + "_s"]).max()) <= 2e-5

@@ -46,6 +46,23 @@ def test_swin_tiny_matches_reference_module(tag, gemm_mode):
         assert err <= 2e-4, (k, tag, err)
 
 
+def test_swin_small_matches_reference_module(gemm_mode):
+    """Swin-S: the same kernels over 18 stage-3 blocks (the other type detection_transformer_wobackbone.py:59-62 admits)."""
+    from gomatching_amd.modeling.swin import SwinTiny
+    cfg = setup_cfg(builtin="icdar15")
+    cfg.MODEL.BACKBONE.NAME = "build_swin_backbone"
+    cfg.MODEL.SWIN.TYPE = "small"
+    g = golden("swin_small.npz")
+    net = SwinTiny(synth_state_dict(cfg, seed=4), torch.device(DEV), swin_type="small")
+    assert len(net.stages[2]["blocks"]) == 18
+    x = torch.from_numpy(g["x_s"])
+    x4 = torch.cat([x.permute(0, 2, 3, 1), x.new_zeros(x.shape[0], x.shape[2], x.shape[3], 1)], -1).contiguous().to(DEV)
+    out = net.forward(x4)
+    for k in ("stage3", "stage4", "stage5"):
+        err = float((out[k].permute(0, 3, 1, 2).cpu() - torch.from_numpy(g[k + "_s"])).abs().max())
+        assert err <= 3e-4, (k, err)
+
+
 def test_swin_glue_kernels_vs_torch():
     from gomatching_amd import ops
     g = torch.Generator().manual_seed(0)
