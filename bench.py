@@ -666,6 +666,16 @@ def main():
             "achieved": both_fl / (both_ms * 1e-3) / 1e12, "frac": both_fl / (both_ms * 1e-3) / 1e12 / PEAKS[args.gemm][1],
             "share_of_step_time": (both_ms / PROFILE_STEPS) / (elapsed / args.steps * 1e3)}
     if msda_prof:
+        def msda_pop(ps):
+            d_ = sum(p_[0].elapsed_time(p_[1]) for p_ in ps)
+            b_ = sum(p_[3] for p_ in ps)
+            return {"launches_per_step": len(ps) // PROFILE_STEPS, "avg_launch_us": d_ * 1e3 / len(ps),
+                    "algorithmic_bytes_per_launch_avg": b_ / len(ps), "achieved": b_ / (d_ * 1e-3) / 1e12, "peak": 8.0,
+                    "unit": "TB/s", "frac": b_ / (d_ * 1e-3) / 1e12 / 8.0,
+                    "share_of_step_time": (d_ / PROFILE_STEPS) / (elapsed / args.steps * 1e3)}
+        nqp = cfg.MODEL.TRANSFORMER.NUM_QUERIES * cfg.MODEL.TRANSFORMER.NUM_POINTS
+        enc_p = [p_ for p_ in msda_prof if int(p_[4].split("x")[1]) != nqp]
+        dec_p = [p_ for p_ in msda_prof if int(p_[4].split("x")[1]) == nqp]
         md = sum(p_[0].elapsed_time(p_[1]) for p_ in msda_prof)
         mb = sum(p_[3] for p_ in msda_prof)
         line["roofline_msda"] = {
@@ -674,6 +684,13 @@ def main():
             "launches_per_step": len(msda_prof) // PROFILE_STEPS, "avg_launch_us": md * 1e3 / len(msda_prof),
             "algorithmic_bytes_per_launch_avg": mb / len(msda_prof),
             "share_of_step_time": (md / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
+            # the two populations apart: the blended figure flatters the encoder launches
+            "encoder_launches": msda_pop(enc_p) if enc_p else None,
+            "decoder_launches": dict(msda_pop(dec_p), note="algorithmic bytes here = the value map once + raw + output; for "
+                                     "%d sparse queries per frame (512 corner lines each: %.0f MB of line reads per launch against a "
+                                     "%.0f MB map) 'the map once' is an upper bound of the distinct lines touched, not a minimum -- "
+                                     "read this launch's fraction as <= the printed one"
+                                     % (nqp, FRAMES_PER_GPU * nqp * 512 * 128 / 1e6, FRAMES_PER_GPU * 37171 * 1024 / 1e6)) if dec_p else None,
             "note": "softmax + sampling locations + bilinear gather in one pass (csrc/msda.hip), 6 encoder + 6 decoder launches; "
                     "algorithmic bytes = value once + raw offsets | logits + output (SURVEY.md 8-d).  Against HBM the fraction is "
                     "low because the binding unit is the texture-address path: 512 distinct 128-byte corner lines per query, "

@@ -41,7 +41,25 @@ struct RowArgs {
     float* C;
     int* flag;
     int lda, ldr, ldc, M, chunks, cpg, r_chunks, relu, r_period;
+    int tiles, frames, tpf;                                  // frame-interleaved tile order (periodic residual): see tile_of()
 };
+
+// Which 128-row tile a workgroup takes.  Plain launches: its index.  With a PERIODIC residual (the encoder's position table
+// [S, 384]: row m reads table row m % S) the same 196 KB of table are needed by the tiles at the same position of every frame,
+// and in index order those are a whole frame (S rows, 57 MB of table) apart: every frame re-reads the table through the
+// fabric (profiles/r03: 1.30 x the algorithmic bytes).  Workgroups go round-robin to the 8 XCDs by their linear index, each XCD
+// with its own 4 MB L2 -- so XCD x = i % 8 takes, in the order j = i / 8 it starts them, the `frames` tiles of position
+// q = (j / frames) * 8 + x one after the other: the table rows of a position are fetched once per XCD pass and hit in L2 for the
+// other frames.  Tiles straddle frame boundaries (S % 128 != 0), which only shifts a position's rows by < 128: still the same
+// lines.  Ids beyond the last position / tile exit at once (the id space is padded to whole groups of 8 x frames).
+__device__ __forceinline__ long tile_of(const RowArgs& p, unsigned i) {
+    if (p.frames <= 1) return i;
+    const unsigned x = i & 7u, j = i >> 3;
+    const unsigned b = j % (unsigned)p.frames, q = (j / (unsigned)p.frames) * 8u + x;
+    if (q >= (unsigned)p.tpf) return -1;
+    const long t = (long)b * p.tpf + q;
+    return t < p.tiles ? t : -1;
+}
 
 __device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) { gom_split2_f16(x, y, q0, q1); }
 
@@ -81,7 +99,9 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
     const int fr = lane & 31, fh = lane >> 5;
     const int c0 = (int)blockIdx.y * p.cpg;
     const int c1 = min(p.chunks, c0 + p.cpg);
-    long row = (long)blockIdx.x * BM + wave * 32 + fr;
+    const long tile = tile_of(p, blockIdx.x);
+    if (tile < 0) return;                                    // padding of the interleaved id space (whole workgroup)
+    long row = tile * BM + wave * 32 + fr;
     if (row > p.M - 1) row = p.M - 1;                        // tail rows recompute AND re-store the last row (same bits)
 
     const __amdgpu_buffer_rsrc_t rs_img =
@@ -100,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
     half8 xf[2][KD / 16];
     {
         float xmax = 0.f;
-        const long wrow0 = (long)blockIdx.x * BM + wave * 32;
+        const long wrow0 = tile * BM + wave * 32;
         auto arow = [&](int r) {
             long m = wrow0 + r;
             if (m > p.M - 1) m = p.M - 1;                     // tail rows recompute (and re-store) the last row: same bits
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
         // stores to rows >= M are dropped by the bounds check and still ISSUED, so that the counted wait below stays exact.
         // Lane (column fr, half h) addresses row 4 h of its wave's 32; register r adds (r & 3) + 8 (r >> 2) rows (in the
         // VECTOR offset: the bounds check does not see the scalar one).
-        const long tile0 = (long)blockIdx.x * BM;
+        const long tile0 = tile * BM;
         const unsigned rows_here = (unsigned)min((long)BM, (long)p.M - tile0);
         const unsigned c_row = (unsigned)p.ldc * 4u, r_row = (unsigned)p.ldr * 4u;
         const __amdgpu_buffer_rsrc_t rs_c =
@@ -300,7 +320,10 @@ extern "C" int gom_gemm_k256_image(const void* w_planes, long w_plane_stride, in
 
 static int g_k256_lines = -1;                            // -1: by M (long problems), 0 / 1: forced (tests, tools)
 
+static int g_k256_interleave = 1;                        // frame-interleaved tile order for periodic residuals (0: index order)
+
 extern "C" void gom_gemm_k256_set_lines(int mode) { g_k256_lines = mode; }
+extern "C" void gom_gemm_k256_set_interleave(int on) { g_k256_interleave = on; }
 
 extern "C" int gom_gemm_k256_rp_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr,
                                     int r_cols, int r_period, int relu, float* C, int ldc, int M, int N, int K, int col_groups,
@@ -325,7 +348,14 @@ extern "C" int gom_gemm_k256_rp_f32(const float* A, const float* A2, int lda, co
     a.A = A; a.A2 = A2; a.img = (const unsigned char*)image; a.R = R; a.C = C; a.flag = flag;
     a.lda = lda; a.ldr = ldr; a.ldc = ldc; a.M = M; a.chunks = chunks; a.cpg = cdiv(chunks, groups);
     a.r_chunks = R ? r_cols / CW : 0; a.relu = relu ? 1 : 0; a.r_period = r_period;
-    const dim3 grid((unsigned)tiles, (unsigned)cdiv(chunks, a.cpg));
+    a.tiles = tiles; a.frames = 1; a.tpf = tiles;
+    unsigned ids = (unsigned)tiles;
+    if (g_k256_interleave && R && r_period > 0 && M % r_period == 0 && M / r_period > 1 && tiles >= 512 && cdiv(chunks, a.cpg) == 1) {
+        a.frames = M / r_period;
+        a.tpf = cdiv(tiles, a.frames);
+        ids = (unsigned)(cdiv(a.tpf, 8) * 8 * a.frames);
+    }
+    const dim3 grid(ids, (unsigned)cdiv(chunks, a.cpg));
     // (the attribute is per DEVICE: set on every launch -- a process-wide flag would miss a second GPU; it costs ~1 us)
     hipError_t e = hipFuncSetAttribute((const void*)gemm_k256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e == hipSuccess)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "gom_dec_attn_image_bytes": (L, [I, I]),
     "gom_dec_attn_image": (I, [P, L, I, P, P, P, L, I, P, P, P, P, I, P, L, P]),
     "gom_dec_attn_f32": (I, [P, I, P, I, P, F, P, I, I, I, I, I, P, P]),
+    "gom_dec_inter_heads_f32": (I, [P, I, P, P, I, I, I, I, P, P]),
     "gom_proj_ln_image_bytes": (L, [I, I]),
     "gom_proj_ln_image": (I, [P, L, I, I, I, P, L, P]),
     "gom_proj_ln_f32": (I, [P, I, P, P, P, P, I, P, P, F, P, I, I, P, P]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "gom_gemm_k256_f32": (I, [P, P, I, P, P, I, I, I, P, I, I, I, I, I, P, P]),
     "gom_gemm_k256_rp_f32": (I, [P, P, I, P, P, I, I, I, I, P, I, I, I, I, I, P, P]),
     "gom_gemm_k256_set_lines": (None, [I]),
+    "gom_gemm_k256_set_interleave": (None, [I]),
     "gom_stem_conv_pool_f32": (I, [P, P, L, I, P, P, P, P, I, I, I, P, P]),
     "gom_ffn_fused_image_bytes": (L, [I, I]),
     "gom_ffn_fused_image": (I, [P, L, I, P, P, P, L, I, I, I, P, L, P]),

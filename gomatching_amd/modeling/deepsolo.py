@@ -117,7 +117,10 @@ class DeepSolo:
             self.dec.append({
                 # the whole block (in_proj, attention, out_proj, residual, norm) as ONE launch under the f16x3 back-end, else None
                 "intra_block": ops.dec_attn_block(wi, bi, intra_out, n_intra, inter=False),
-                "inter_block": ops.dec_attn_block(wx, bx, inter_out, n_inter, inter=True) if self.nq <= 128 else None,
+                # up to 128 queries per frame one launch (csrc/dec_attn.hip); up to 352 (GoMatching++: 300) the block's image feeds
+                # csrc/dec_inter.hip (in_proj + attention per (group, head)) followed by the out_proj + LayerNorm launch
+                "inter_block": ops.dec_attn_block(wx, bx, inter_out, n_inter, inter=True)
+                if self.nq <= ops.DEC_INTER_MAX_HEADS else None,
                 "intra_qk": qlin((wi[:2 * E], bi[:2 * E])), "intra_v": qlin((wi[2 * E:], bi[2 * E:])),
                 "intra_out": qlin(intra_out), "norm_intra": n_intra, "intra_out_ln": ops.proj_ln_block(intra_out, n_intra),
                 "inter_in": qlin((wx, bx)),
@@ -357,8 +360,10 @@ class DeepSolo:
                              [P * 2 * E, 0, 2 * E, P * 2 * E, 0, 2 * E, P * E, 0, E, P * E, 0, E])
                 tgt = self._out_norm(attn, L, "intra", tgt)
             # inter-instance attention over the nq queries, batched over (frame, point) (:396-404)
-            if L["inter_block"] is not None:
+            if L["inter_block"] is not None and nq <= ops.DEC_INTER_MAX_FUSED:
                 tgt = ops.dec_attn(tgt, L["inter_block"], B * P, nq, inner=P)
+            elif L["inter_block"] is not None and L["inter_out_ln"] is not None:
+                tgt = ops.proj_ln(ops.dec_inter_heads(tgt, L["inter_block"], B * P, nq, inner=P), L["inter_out_ln"], tgt)
             else:
                 qkv = ops.linear(tgt, L["inter_in"])                                           # [Q, 768]
                 if attn is None:

@@ -677,6 +677,30 @@ def dec_attn(x, blk, groups, group_tokens, inner=1, pos=None, out=None):
     return out
 
 
+def dec_inter_heads(x, blk, groups, group_tokens, inner, out=None):
+    """in_proj + attention core of the inter-instance block for 128 < group_tokens <= 352 (csrc/dec_inter.hip): returns the
+    concatenated head outputs [rows, 256] (out_proj + residual + LayerNorm: `proj_ln`).  Row mapping as `dec_attn` (inter)."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == 256 and x.dtype == _f32 and blk.inter
+    rows = groups * group_tokens
+    assert x.shape[0] >= rows
+    if out is None:
+        out = torch.empty((x.shape[0], 256), dtype=_f32, device=x.device)
+    prof = _gemm_profile if (_gemm_profile is not None and rows > 0) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().gom_dec_inter_heads_f32(_p(x), x.stride(0) if x.shape[0] > 1 else 256, _p(blk.image), _p(out),
+                                       out.stride(0) if out.shape[0] > 1 else 256, groups, group_tokens, inner,
+                                       _p(range_flag(x.device)), _stream()), "gom_dec_inter_heads_f32")
+    if prof is not None:
+        e1.record()
+        flops = 2.0 * rows * 256 * 768 + 4.0 * rows * group_tokens * 256      # in_proj + QK^T and PV of every head
+        prof.append((e0, e1, flops, 4.0 * rows * 256 * 2 + 24 * 36864, "decattn:inter-heads:%dx%d" % (groups, group_tokens), _profile_scope))
+    return out
+
+
+DEC_INTER_MAX_FUSED = 128            # tokens per group the one-launch block (csrc/dec_attn.hip) serves; up to 352: csrc/dec_inter.hip
+DEC_INTER_MAX_HEADS = 352
 FUSED_FFN = _switch("FUSED_FFN")     # f16x3 back-end: FFN blocks as one fused launch (False: GEMM, GEMM, LayerNorm)
 
 

@@ -227,6 +227,16 @@ int gom_dec_attn_image(const void* in_planes, long in_plane_stride, int ld_in, c
 int gom_dec_attn_f32(const float* X, int ldx, const float* P, int ldp, const void* image, float eps, float* Y, int ldy, int groups,
                      int group_tokens, int inner, int inter, int* flag, void* stream);
 
+/* The inter-instance attention (deformable_transformer.py:396-404) for MORE than 128 queries per frame (GoMatching_PP_DSText.yaml:
+ * 300), csrc/dec_inter.hip: in_proj + the 8 x 32 attention core, one workgroup per (group, head) with the head's K / V^T of all
+ * `group_tokens` <= 352 tokens in LDS and an online softmax over the key blocks:
+ *     O[token, 32 h .. 32 h + 31] = softmax(q_h k_h^T / sqrt(32)) v_h,    q | k | v = X . in_proj_weight^T + in_proj_bias
+ * X, O [rows, 256] fp32 (token t of group g is row ((g / inner) * group_tokens + t) * inner + g % inner); `image` = the
+ * gom_dec_attn_image of the block with inter = 1 (its in_proj stages are read).  out_proj + residual + LayerNorm follow as one
+ * gom_proj_ln_f32 launch.  Same f16x3 scheme, range contract and *flag as gom_dec_attn_f32. */
+int gom_dec_inter_heads_f32(const float* X, int ldx, const void* image, float* O, int ldo, int groups, int group_tokens,
+                            int inner, int* flag, void* stream);
+
 /* Row-resident K = 256 form of gom_gemm_f32_f16x3 for SHORT problems (the decoder's Q-side nn.Linear layers at
  * M = frames x queries x points rows: deformable_transformer.py:386-422,470-488), csrc/gemm_k256.hip:
  *     C[M, N] = act( (A [+ A2])[M, 256] . W[N, 256]^T + bias [+ R on columns < r_cols] ),   N, r_cols multiples of 32.
@@ -247,6 +257,9 @@ int gom_gemm_k256_rp_f32(const float* A, const float* A2, int lda, const void* i
                          int r_period, int relu, float* C, int ldc, int M, int N, int K, int col_groups, int* flag,
                          void* stream);
 void gom_gemm_k256_set_lines(int mode);
+/* Periodic residual, several periods (frames), long problem: workgroups take the row tiles frame-interleaved per XCD, so that the
+ * table rows of a position are fetched into an XCD's L2 once for all frames (1 = default, 0 = index order; same bits). */
+void gom_gemm_k256_set_interleave(int on);
 
 /* Fused FFN block of a DeepSolo transformer layer (deformable_transformer.py:250-251,266-273 encoder linear1/ReLU/linear2 +
  * residual + norm2; :352-354,368-369 decoder + norm3):

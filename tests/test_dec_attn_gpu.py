@@ -82,6 +82,42 @@ def test_inter_block(B, nq, P):
     ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
 
 
+@pytest.mark.parametrize("B,nq,P", [(8, 300, 25), (1, 300, 25), (2, 129, 3), (1, 352, 1), (1, 161, 2), (1, 320, 2)])
+def test_inter_block_more_than_128_queries(B, nq, P):
+    """GoMatching++ (300 queries): in_proj + attention per (group, head) (csrc/dec_inter.hip) + the out_proj / LayerNorm launch
+    against the float64 statement of the whole block, and the head outputs alone against float64 too."""
+    from gomatching_amd import ops
+    g = torch.Generator().manual_seed(B * 131 + nq * 7 + P)
+    w = _weights(2)
+    rows = B * nq * P
+    x = torch.randn(rows, 256, generator=g)
+    blk = _block(ops, w, True)
+    xd = x.to(DEV)
+    heads = torch.full((rows, 256), 7.0, device=DEV)
+    ops.dec_inter_heads(xd, blk, B * P, nq, inner=P, out=heads)
+    idx = torch.arange(rows).view(B, nq, P).permute(0, 2, 1).reshape(B * P, nq)
+    in_w, in_b = w[0].double(), w[1].double()
+    q, k, v = [(x.double() @ in_w[i * 256:(i + 1) * 256].t() + in_b[i * 256:(i + 1) * 256])[idx].view(B * P, nq, 8, 32).transpose(1, 2)
+               for i in range(3)]
+    o = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32.0), -1) @ v).transpose(1, 2).reshape(B * P * nq, 256)
+    ref_heads = torch.zeros(rows, 256, dtype=torch.float64)
+    ref_heads[idx.reshape(-1)] = o
+    err = float((heads.cpu().double() - ref_heads).abs().max())
+    assert err < 1e-5, err
+    d = [t.to(DEV) for t in w]
+    pl = ops.ProjLN(ops.split_weight(d[2], kind="f16x3"), d[3], d[4], d[5])
+    out = ops.proj_ln(heads, pl, xd)
+    err = float((out.cpu().double() - _ref(x, None, w, idx)).abs().max())
+    assert err < 2e-5, err
+    ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
+    if nq == 300 and B == 1:                                         # the range contract of this kernel
+        xb = xd.clone()
+        xb[37, 5] = 7e4
+        ops.dec_inter_heads(xb, blk, B * P, nq, inner=P)
+        with pytest.raises(Exception, match="fp16's range"):
+            ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
+
+
 def test_blocks_raise_the_range_flag():
     from gomatching_amd import ops
     dev = torch.device(DEV, torch.cuda.current_device())

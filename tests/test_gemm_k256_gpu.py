@@ -43,7 +43,8 @@ def test_k256_equals_tile_kernel(M, N, groups):
 
 
 @pytest.mark.parametrize("lines", [0, 1])
-@pytest.mark.parametrize("M,N,period", [(20000, 640, 2500), (4097, 96, 33), (129, 64, 32), (70000, 256, 0), (300, 512, 301)])
+@pytest.mark.parametrize("M,N,period", [(20000, 640, 2500), (4097, 96, 33), (129, 64, 32), (70000, 256, 0), (300, 512, 301),
+                                        (8 * 9001, 640, 9001), (3 * 23333, 128, 23333)])   # long + periodic: frame-interleaved tiles
 def test_k256_store_forms_and_periodic_residual(lines, M, N, period):
     """The kernel's two store forms (16-byte pieces with the row on the lane / whole 128-byte lines with the column on the
     lane, gom_gemm_k256_set_lines) return the tile kernel's bits -- with a residual on the leading columns, a PERIODIC one

@@ -80,6 +80,10 @@ for N, rc in ((640, 384), (640, 0), (256, 0), (1536, 0)):
     for mode in (0, 1):
         k256(mode)()
         same.append(bool(torch.equal(out, ref)))
-    t = ab([lambda: ops.gemm(A, sw, bias=b, out=out, **kw), k256(0), k256(1)])
-    print("M %6d N %4d periodic R-cols %3d  tile %7.1f us | k256 16-byte stores %7.1f us | k256 whole-line stores %7.1f us | bits equal to the tile kernel: %s" % (
-        M, N, rc, t[0], t[1], t[2], same), flush=True)
+    def plain_order():
+        lib.load().gom_gemm_k256_set_interleave(0)
+        ops.linear(A, lin, out=out, groups=1, **kw)
+        lib.load().gom_gemm_k256_set_interleave(1)
+    t = ab([lambda: ops.gemm(A, sw, bias=b, out=out, **kw), k256(0), k256(1), plain_order])
+    print("M %6d N %4d periodic R-cols %3d  tile %7.1f us | k256 16-byte stores %7.1f us | k256 whole-line stores %7.1f us | same, tiles in index "
+          "order (no frame interleave) %7.1f us | bits equal to the tile kernel: %s" % (M, N, rc, t[0], t[1], t[2], t[3], same), flush=True)
