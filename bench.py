@@ -497,7 +497,8 @@ def main():
     bn_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("bneck:")]     # fused bottleneck tail + next head launches
     msda_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("msda:")]    # fused multi-scale deformable attention
     c3_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("conv3:")]     # patch-resident 3x3 convolutions
-    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:", "projdot:", "decattn:", "bneck:", "msda:", "conv3:")))]
+    pwk_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("pwk256:")]  # 256-channel pointwise convolutions on the K = 256 kernel
+    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:", "projdot:", "decattn:", "bneck:", "msda:", "conv3:", "pwk256:")))]
     dur_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     flops = sum(p[2] for p in prof)
     alg_bytes = sum(p[3] for p in prof)
@@ -708,6 +709,16 @@ def main():
             "note": "conv3 + BN + residual + ReLU of a ResNet bottleneck block and conv1 + BN + ReLU of the next in one launch "
                     "(res2 / res3: csrc/bneck_fused.hip): the block's output is written once and not read back by conv1; 26-50 "
                     "FLOP per byte, an HBM-stream kernel"}
+    if pwk_prof:
+        wd_ = sum(p_[0].elapsed_time(p_[1]) for p_ in pwk_prof)
+        wb_, wf_ = sum(p_[3] for p_ in pwk_prof), sum(p_[2] for p_ in pwk_prof)
+        line["roofline_pw_k256"] = {
+            "bound": "hbm", "kernel": "gemm_k256_kernel<false> (res4 conv3: 256 -> 1024 + BN + shortcut + ReLU)",
+            "achieved": wb_ / (wd_ * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s", "frac": wb_ / (wd_ * 1e-3) / 1e12 / 8.0,
+            "mfma_view": {"achieved": wf_ / (wd_ * 1e-3) / 1e12, "peak": PEAKS["f16x3"][1], "unit": "TFLOP/s",
+                          "frac": wf_ / (wd_ * 1e-3) / 1e12 / PEAKS["f16x3"][1]},
+            "launches_per_step": len(pwk_prof) // PROFILE_STEPS, "avg_launch_us": wd_ * 1e3 / len(pwk_prof),
+            "share_of_step_time": (wd_ / PROFILE_STEPS) / (elapsed / args.steps * 1e3)}
     if c3_prof:
         cd_ = sum(p_[0].elapsed_time(p_[1]) for p_ in c3_prof)
         cb_, cf_ = sum(p_[3] for p_ in c3_prof), sum(p_[2] for p_ in c3_prof)

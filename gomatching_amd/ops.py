@@ -289,6 +289,8 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
     return out
 
 
+PW_K256 = _switch("PW_K256")         # f16x3 back-end: pointwise convolutions with 256 input channels on the row-resident K = 256 kernel
+PW_K256_MIN_ROWS = 16384
 CONV3_PATCH = _switch("CONV3_PATCH")   # f16x3 back-end: 3x3 / stride 1 convolutions on the patch-resident kernel
 
 
@@ -333,6 +335,33 @@ def conv2d_nhwc(x, w_ohwi, scale=None, shift=None, R=None, relu=False, stride=1,
                 e1.record()
                 prof.append((e0, e1, 2.0 * M * Cout * 9 * Cin, 4.0 * M * (Cin + Cout) + 4.0 * 9 * Cin * Cout,
                              "conv3:%dx%dx%d" % (M, Cout, 9 * Cin), _profile_scope))
+            return y
+        if (w_ohwi.kind == "f16x3" and PW_K256 and KH == 1 and KW == 1 and stride == 1 and pad == 0 and Cin == 256 and Cout % 32 == 0
+                and Cout >= 512 and M >= PW_K256_MIN_ROWS and splits <= 1 and x.is_contiguous()):
+            # conv3 of the res4 bottlenecks (256 -> 1024, + BN + shortcut + ReLU): K = 256 is the row-resident kernel's shape
+            # (csrc/gemm_k256.hip: rows as fragments once, weights by LDS-DMA, no A staging) -- FrozenBN's scale folds into the
+            # image's inverse row scale, its shift is the bias
+            key = (id(scale), id(shift))
+            cache = w_ohwi.__dict__.setdefault("k256_images", {})
+            img = cache.get(key)
+            if img is None:
+                inv = w_ohwi.inv_scale if scale is None else (w_ohwi.inv_scale * scale).contiguous()
+                nb = _L().gom_gemm_k256_image_bytes(Cout, Cin)
+                img = torch.empty((nb,), dtype=torch.uint8, device=pl.device)
+                check(_L().gom_gemm_k256_image(_p(pl), pl.stride(0), pl.stride(1), _p(inv), _p(shift), Cout, Cin, _p(img), nb,
+                                               _stream()), "gom_gemm_k256_image")
+                cache[key] = img = (img, inv, scale, shift)         # (the vectors stay referenced: ids are the cache key)
+            prof = _gemm_profile
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(_L().gom_gemm_k256_rp_f32(_p(x), None, Cin, _p(img[0]), _p(R), Cout if R is not None else 0,
+                                            Cout if R is not None else 0, 0, 1 if relu else 0, _p(y), Cout, M, Cout, Cin, 1,
+                                            _p(range_flag(x.device)), _stream()), "gom_gemm_k256_rp_f32")
+            if prof is not None:
+                e1.record()
+                prof.append((e0, e1, 2.0 * M * Cout * Cin, 4.0 * M * Cin + 4.0 * M * Cout * (2 if R is not None else 1) + 4.0 * Cout * Cin,
+                             "pwk256:%dx%dx%d" % (M, Cout, Cin), _profile_scope))
             return y
         if w_ohwi.kind == "f16x3":
             # a pointwise convolution IS a launch of the GEMM tile kernel (dispatch<0, 0> in csrc/gemm_f16x3.hip): bench.py's

@@ -316,7 +316,7 @@ def deepsolo_forward(sd, cfg, feats, masks, pos, taps=None, prefix="detection_tr
     enc_coord = mlp(om, sd, prefix + "bezier_proposal_coord", 3) + props
     topk = torch.topk(enc_class[..., 0], nq, dim=1)[1]
     coords = torch.gather(enc_coord, 1, topk.unsqueeze(-1).repeat(1, 1, 8)).sigmoid()
-    refp = torch.matmul(bernstein_matrix(P), coords.view(B, nq, 4, 2))      # B,nq,P,2
+    refp = torch.matmul(bernstein_matrix(P).to(coords.dtype), coords.view(B, nq, 4, 2))      # B,nq,P,2
     if taps is not None:
         taps.update(enc_class=enc_class[..., 0], topk=topk, init_ref=refp)
 
