@@ -52,6 +52,9 @@ struct RowArgs {
 // q = (j / frames) * 8 + x one after the other: the table rows of a position are fetched once per XCD pass and hit in L2 for the
 // other frames.  Tiles straddle frame boundaries (S % 128 != 0), which only shifts a position's rows by < 128: still the same
 // lines.  Ids beyond the last position / tile exit at once (the id space is padded to whole groups of 8 x frames).
+// MEASURED (tools/gemm_k256_bench.py, M = 297 368, N = 640): 374 us against 364 us in index order -- the re-reads are served by
+// the 256 MB Infinity Cache at no visible cost, and the interleave breaks the write stream's order.  Kept as an option
+// (gom_gemm_k256_set_interleave), OFF by default.
 __device__ __forceinline__ long tile_of(const RowArgs& p, unsigned i) {
     if (p.frames <= 1) return i;
     const unsigned x = i & 7u, j = i >> 3;
@@ -320,7 +323,7 @@ extern "C" int gom_gemm_k256_image(const void* w_planes, long w_plane_stride, in
 
 static int g_k256_lines = -1;                            // -1: by M (long problems), 0 / 1: forced (tests, tools)
 
-static int g_k256_interleave = 1;                        // frame-interleaved tile order for periodic residuals (0: index order)
+static int g_k256_interleave = 0;                        // frame-interleaved tile order for periodic residuals: measured 3 % SLOWER (374 vs 364 us), off
 
 extern "C" void gom_gemm_k256_set_lines(int mode) { g_k256_lines = mode; }
 extern "C" void gom_gemm_k256_set_interleave(int on) { g_k256_interleave = on; }

@@ -137,8 +137,8 @@ extern "C" void gom_tracker_destroy(void* h) {
  *   secs[0] / secs[1] accumulate the short- / long-term seconds. */
 static int tracker_run_impl(void* handle, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
                             long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool,
-                            float img_w, float img_h, const float* decay_table, long* id_count_io, double* secs,
-                            void* stream) {
+                            float img_w, float img_h, const float* frame_wh, const float* decay_table, long* id_count_io,
+                            double* secs, void* stream) {
     Tracker* t = (Tracker*)handle;
     if (!t || F <= 0 || !n || !ids || first_new < 0 || first_new >= F || !id_count_io || !s_off) return GOM_ERR_INVALID_ARG;
     std::vector<long> off(F + 1, 0);
@@ -245,10 +245,19 @@ static int tracker_run_impl(void* handle, int F, const int* n, const float* boxe
             int* p_kinds = p;                  p += n_k;
             float* p_boxes = (float*)p;        p += 4 * N;
             float* p_decay = (float*)p;
+            // `frame_wh` (w, h per window frame): the long-term match normalises EVERY frame's boxes by the image size of the
+            // window's FIRST frame (gom_lstmatcher.py:471 `Instances(full_instances[0].image_size)` -> lstmatcher.py:478-494) -- the
+            // fp32 quotient is formed here as torch forms it, and the kernels run with an image size of 1 x 1
+            float mw = img_w, mh = img_h;
             for (int a = 0; a < N; ++a) {
                 p_rows[a] = rows[sel_idx[a]];
                 std::memcpy(p_boxes + 4 * a, boxes + 4L * sel_idx[a], 4 * sizeof(float));
+                if (frame_wh) {
+                    const float fw = frame_wh[2 * w0], fh = frame_wh[2 * w0 + 1];
+                    p_boxes[4 * a] /= fw; p_boxes[4 * a + 1] /= fh; p_boxes[4 * a + 2] /= fw; p_boxes[4 * a + 3] /= fh;
+                }
             }
+            if (frame_wh) mw = mh = 1.f;
             p_offs[0] = 0;
             for (int w = 0; w < T; ++w) p_offs[w + 1] = p_offs[w] + n_arr[w];
             for (int m = 0; m < M; ++m) p_last[m] = 0;
@@ -277,7 +286,7 @@ static int tracker_run_impl(void* handle, int F, const int* n, const float* boxe
             // the chain's last kernel writes the n_k x M trajectory scores STRAIGHT into pinned host memory (device-visible,
             // posted PCIe writes, complete at the stream sync below): one launch fewer per match than a copy kernel
             rc = chain(pool_dev, ld_pool, t->proj, t->ld_proj, d_rows, d_offs, d_meta, d_boxes, d_decay, N, T, lo, lo + n_k, M, t->enc, t->n_enc, t->dec,
-                       t->n_dec, t->d, t->heads, t->ffn, img_w, img_h, t->with_iou, t->max_center_dist, t->ws_dev, nws,
+                       t->n_dec, t->d, t->heads, t->ffn, mw, mh, t->with_iou, t->max_center_dist, t->ws_dev, nws,
                        t->traj_pin, stream);
             if (rc != GOM_OK) return rc;
             hipError_t e = hipStreamSynchronize(st);
@@ -285,7 +294,7 @@ static int tracker_run_impl(void* handle, int F, const int* n, const float* boxe
             if (g_double_check) {                                // diagnostic: the same chain again must give the same bits
                 std::vector<float> first(t->traj_pin, t->traj_pin + (size_t)n_k * M);
                 rc = chain(pool_dev, ld_pool, t->proj, t->ld_proj, d_rows, d_offs, d_meta, d_boxes, d_decay, N, T, lo, lo + n_k, M, t->enc, t->n_enc,
-                           t->dec, t->n_dec, t->d, t->heads, t->ffn, img_w, img_h, t->with_iou, t->max_center_dist, t->ws_dev,
+                           t->dec, t->n_dec, t->d, t->heads, t->ffn, mw, mh, t->with_iou, t->max_center_dist, t->ws_dev,
                            nws, t->traj_pin, stream);
                 if (rc != GOM_OK) return rc;
                 if (hipStreamSynchronize(st) != hipSuccess) return GOM_ERR_HIP_BASE;
@@ -310,7 +319,18 @@ extern "C" int gom_tracker_run(void* handle, int F, const int* n, const float* b
                                float img_w, float img_h, const float* decay_table, long* id_count_io, double* secs,
                                void* stream) {
     const int rc = tracker_run_impl(handle, F, n, boxes, rows, ids, first_new, first_real, S, s_off, pool_dev, ld_pool, img_w,
-                                    img_h, decay_table, id_count_io, secs, stream);
+                                    img_h, nullptr, decay_table, id_count_io, secs, stream);
     if (handle) ((Tracker*)handle)->proj = nullptr;         // projections are valid for one call only
+    return rc;
+}
+
+extern "C" int gom_tracker_run_wh(void* handle, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
+                                  long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool,
+                                  const float* frame_wh, const float* decay_table, long* id_count_io, double* secs,
+                                  void* stream) {
+    if (!frame_wh) return GOM_ERR_INVALID_ARG;
+    const int rc = tracker_run_impl(handle, F, n, boxes, rows, ids, first_new, first_real, S, s_off, pool_dev, ld_pool, 1.f, 1.f,
+                                    frame_wh, decay_table, id_count_io, secs, stream);
+    if (handle) ((Tracker*)handle)->proj = nullptr;
     return rc;
 }

@@ -138,6 +138,7 @@ SIGNATURES = {
     "gom_stream_create_cu_mask": (I, [P, I, P]),
     "gom_stream_destroy": (I, [P]),
     "gom_tracker_run": (I, [P, I, P, P, P, P, I, L, P, P, P, I, F, F, P, P, P, P]),
+    "gom_tracker_run_wh": (I, [P, I, P, P, P, P, I, L, P, P, P, I, P, P, P, P, P]),
     "gom_linear_sum_assignment": (I, [ctypes.POINTER(ctypes.c_double), L, L, ctypes.POINTER(c_long),
                                       ctypes.POINTER(c_long)]),
 }

@@ -461,11 +461,16 @@ class GoMatching:
             g["ids"] = inst.track_ids.detach().cpu().numpy().astype(np.int64)
         return g
 
-    def _nboxes(self, inst):
-        """Host boxes of a frame divided by ITS OWN image size (lstmatcher.py:478-494 `_get_boxes_time`: every frame of a window is
-        normalised by its own (w, h), which matters when a clip mixes resolutions -- BASELINE config #5).  The tracker kernels then
-        run with an image size of 1 x 1 (x / 1.0f is exact), so the fp32 quotient is formed once, here, as the reference forms it."""
+    def _nboxes(self, inst, hw=None):
+        """Host boxes of a frame divided by an image size, as lstmatcher.py:478-494 `_get_boxes_time` divides them: by the frame's
+        OWN size in a short-term match (hw None), by the size of the window's FIRST frame in a long-term match (the reference
+        builds every window Instances with `full_instances[0].image_size`, gom_lstmatcher.py:471) -- which only differ when a clip
+        mixes resolutions (BASELINE config #5).  The tracker kernels then run with an image size of 1 x 1 (x / 1.0f is exact), so
+        the fp32 quotient is formed once, here, as the reference forms it."""
         g = self._host(inst)
+        if hw is not None and tuple(hw) != tuple(inst.image_size):
+            h, w = hw
+            return g["boxes"].reshape(-1, 4).astype(np.float32) / np.array([w, h, w, h], np.float32)
         nb = g.get("nboxes")
         if nb is None or len(nb) != len(g["boxes"]):
             h, w = inst.image_size
@@ -628,8 +633,9 @@ class GoMatching:
         if n_k == 0 or M == 0:
             return np.zeros((n_k, M), np.float32), uniq, ids
         rows = np.concatenate([self._rows_full(w) for w in window])[sel_idx].astype(np.int32)
-        boxes = np.concatenate([self._nboxes(w) for w in window])[sel_idx].astype(np.float32)
-        hw = (1.0, 1.0)                                          # boxes are normalised per frame already (_nboxes)
+        norm_hw = None if short_term else window[0].image_size   # long-term: the window's first frame's size for every frame
+        boxes = np.concatenate([self._nboxes(w, norm_hw) for w in window])[sel_idx].astype(np.float32)
+        hw = (1.0, 1.0)                                          # boxes are normalised already (_nboxes)
         nonk = np.nonzero(not_k)[0]
         k_inds = np.nonzero(~not_k)[0]
         col_of = np.searchsorted(uniq, ids)
@@ -959,7 +965,7 @@ class GoMatching:
         hosts = [self._host(w) for w in window]
         n = np.asarray([len(w) for w in window], np.int32)
         tot = int(n.sum())
-        boxes = np.ascontiguousarray(np.concatenate([self._nboxes(w) for w in window]) if tot
+        boxes = np.ascontiguousarray(np.concatenate([h["boxes"].reshape(-1, 4) for h in hosts]) if tot
                                      else np.zeros((0, 4)), dtype=np.float32)
         rows = np.ascontiguousarray(np.concatenate([self._rows_full(w) for w in window]) if tot else np.zeros((0,)),
                                     dtype=np.int32)
@@ -981,7 +987,7 @@ class GoMatching:
         self._hoist_projections(trk)
         idc = ctypes.c_long(int(id_count) if id_count else 0)
         secs = (ctypes.c_double * 2)(0.0, 0.0)
-        hw = (1.0, 1.0)                                          # per-frame normalisation happened in _nboxes
+        frame_wh = np.ascontiguousarray([[w.image_size[1], w.image_size[0]] for w in window], dtype=np.float32)
         ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         time_cost["short_match"] += time.time() - t0
         run_stream = ops._stream()
@@ -989,10 +995,10 @@ class GoMatching:
         if lane is not None:                                     # CU-partitioned step: the recurrence runs on its own CUs
             lane.wait_stream(torch.cuda.current_stream())        # ... after the embeddings it gathers from the pool
             run_stream = lane.cuda_stream
-        ops.check(L.gom_tracker_run(trk, len(window), ptr(n), ptr(boxes), ptr(rows), ptr(ids), first_new, start,
-                                    ptr(S_all), ptr(s_off), ctypes.c_void_p(self._pool.data_ptr()), self._pool.stride(0),
-                                    float(hw[1]), float(hw[0]), ptr(self._decay_table), ctypes.byref(idc), secs,
-                                    run_stream), "gom_tracker_run")
+        ops.check(L.gom_tracker_run_wh(trk, len(window), ptr(n), ptr(boxes), ptr(rows), ptr(ids), first_new, start,
+                                       ptr(S_all), ptr(s_off), ctypes.c_void_p(self._pool.data_ptr()), self._pool.stride(0),
+                                       ptr(frame_wh), ptr(self._decay_table), ctypes.byref(idc), secs, run_stream),
+                  "gom_tracker_run_wh")
         if lane is not None:
             torch.cuda.current_stream().wait_stream(lane)        # the pool may be rewritten by later work on this stream
         time_cost["short_match"] += secs[0]

@@ -258,7 +258,8 @@ int gom_gemm_k256_rp_f32(const float* A, const float* A2, int lda, const void* i
                          void* stream);
 void gom_gemm_k256_set_lines(int mode);
 /* Periodic residual, several periods (frames), long problem: workgroups take the row tiles frame-interleaved per XCD, so that the
- * table rows of a position are fetched into an XCD's L2 once for all frames (1 = default, 0 = index order; same bits). */
+ * table rows of a position are fetched into an XCD's L2 once for all frames (1 = on, 0 = index order = default: the interleave
+ * measured 3 % slower, the re-reads hit the Infinity Cache; same bits). */
 void gom_gemm_k256_set_interleave(int on);
 
 /* Fused FFN block of a DeepSolo transformer layer (deformable_transformer.py:250-251,266-273 encoder linear1/ReLU/linear2 +
@@ -532,6 +533,12 @@ int gom_tracker_set_projections(void* tracker, const float* proj_dev, int ld_pro
 int gom_tracker_run(void* tracker, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
                     long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool, float img_w,
                     float img_h, const float* decay_table, long* id_count_io, double* secs, void* stream);
+/* The same with one image size PER window frame (frame_wh [F, 2] = width, height): a long-term match then normalises every box
+ * of its window by the size of the window's FIRST frame, as the reference does (gom_lstmatcher.py:471 builds every window
+ * Instances with full_instances[0].image_size; lstmatcher.py:478-494 divides by it) -- clips that mix resolutions (BOVText). */
+int gom_tracker_run_wh(void* tracker, int F, const int* n, const float* boxes, const int* rows, long* ids, int first_new,
+                       long first_real, const float* S, const long* s_off, const float* pool_dev, int ld_pool,
+                       const float* frame_wh, const float* decay_table, long* id_count_io, double* secs, void* stream);
 /* ---- CU-partitioned streams (csrc/stream.hip): the tracker's lane of a multi-GPU step ------------------------------------
  * [host] A HIP stream whose kernels run only on the compute units of cu_mask (`words` x 32 bits, bit i = CU i of the driver's
  * enumeration).  GoMatching.reserve_tracker_cus() gives the tracker stream a few CUs of every XCD and the detector stream the

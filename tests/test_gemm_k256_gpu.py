@@ -62,6 +62,7 @@ def test_k256_store_forms_and_periodic_residual(lines, M, N, period):
     wide = torch.full((M, N + 64), 7.0, device=DEV)
     try:
         lib.load().gom_gemm_k256_set_lines(lines)
+        lib.load().gom_gemm_k256_set_interleave(1)                    # the optional frame-interleaved tile order: same bits
         for groups in (1, 2):
             for kw in ({}, {"R": R, "r_cols": rc, "r_period": period}, {"R": R, "r_cols": rc, "r_period": period, "relu": True}):
                 ref = ops.gemm(A, sw, bias=b, **kw)
@@ -72,6 +73,7 @@ def test_k256_store_forms_and_periodic_residual(lines, M, N, period):
         assert float((wide[:, :32] - 7.0).abs().max()) == 0.0 and float((wide[:, 32 + N:] - 7.0).abs().max()) == 0.0
     finally:
         lib.load().gom_gemm_k256_set_lines(-1)
+        lib.load().gom_gemm_k256_set_interleave(0)
     ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
 
 

@@ -233,6 +233,59 @@ def test_tracker_across_100_frame_batches_vs_oracle(builtin, matcher_runtime):
 
 
 @pytest.mark.parametrize("builtin", ["icdar15", "pp_dstext"])
+def test_tracker_mixed_resolution_vs_oracle(builtin, matcher_runtime):
+    """A clip whose frames change size (BASELINE config #5): a short-term match divides each frame's boxes by its OWN image size
+    (lstmatcher.py:478-494), a long-term match divides every frame of its window by the size of the window's FIRST frame
+    (gom_lstmatcher.py:471) -- ids equal the oracle's on a 40-frame trace that switches between three sizes, for all runtimes."""
+    from oracle import gom_oracle as O
+    from gomatching_amd.modeling import GoMatching
+    from gomatching_amd.structures import Instances, Boxes
+    from gomatching_amd.weights import synth_state_dict
+    cfg = mini_cfg(builtin, device=DEV)
+    sd = synth_state_dict(cfg, seed=7)
+    model = GoMatching(cfg, sd, device=DEV)
+    # objects that move slowly and carry NO appearance cue (fresh random embeddings every frame): the association falls to the
+    # IoU term, i.e. to how the boxes are normalised
+    g = np.random.default_rng(11)
+    objs = [{"xy": g.uniform(10, 90, 2), "v": g.uniform(-0.4, 0.4, 2)} for _ in range(6)]
+    trace = []
+    for _ in range(40):
+        feats, boxes = [], []
+        for o in objs:
+            o["xy"] = np.clip(o["xy"] + o["v"], 2, 100)
+            if g.random() < 0.9:
+                feats.append(g.standard_normal(model.roi_heads.feature_dim).astype(np.float32))
+                boxes.append([o["xy"][0], o["xy"][1] * 0.7, o["xy"][0] + 14, o["xy"][1] * 0.7 + 8])
+        trace.append((np.asarray(feats, np.float32).reshape(-1, model.roi_heads.feature_dim), np.asarray(boxes, np.float32).reshape(-1, 4)))
+    sizes = [((96, 128), (128, 96), (192, 256))[(f // 4) % 3] for f in range(40)]
+    scaled = [(f_, b * np.array([sz[1] / 128.0, sz[0] / 96.0, sz[1] / 128.0, sz[0] / 96.0], np.float32))
+              for (f_, b), sz in zip(trace, sizes)]
+    ocfg = mini_cfg(builtin)
+    o_insts = [O.Inst(sz, reid_features=torch.from_numpy(f_).clone(), pred_boxes=torch.from_numpy(b).clone())
+               for (f_, b), sz in zip(scaled, sizes)]
+    with torch.no_grad():
+        o_res, o_count = O.track_clip(sd, ocfg, o_insts)
+    dets = []
+    for (f_, b), sz in zip(scaled, sizes):
+        inst = Instances(sz)
+        inst.reid_features = torch.from_numpy(f_).to(DEV)
+        inst.pred_boxes = Boxes(torch.from_numpy(b).to(DEV))
+        dets.append(inst)
+    it = iter(dets)
+    model.detect_launch = lambda batched_inputs, time_cost: list(batched_inputs)
+    model.detect_finish = lambda h, time_cost: [next(it) for _ in h]
+    insts, id_count = model.batch_inference([{} for _ in range(40)], 0, 0, [], _time_cost())
+    assert int(id_count) == int(o_count)
+    for f in range(40):
+        assert insts[f].track_ids.cpu().tolist() == o_res[f]["track_ids"].tolist(), f
+    # the sizes matter: normalising everything by one size gives other ids on this trace (the test would not notice otherwise)
+    same = [O.Inst(sizes[0], reid_features=x["reid_features"].clone(), pred_boxes=x["pred_boxes"].clone()) for x in o_insts]
+    with torch.no_grad():
+        s_res, _ = O.track_clip(sd, ocfg, same)
+    assert any(a["track_ids"].tolist() != b["track_ids"].tolist() for a, b in zip(s_res, o_res))
+
+
+@pytest.mark.parametrize("builtin", ["icdar15", "pp_dstext"])
 @pytest.mark.parametrize("n_t,k", [([7, 0, 12, 5], 3), ([60, 70, 90], 2), ([1, 1], 1), ([3, 140], 1)])
 def test_native_match_runtime_equals_python_composition(builtin, n_t, k):
     """gom_match_scores_f32 (matcher_rt.cpp) returns the same bits as the per-kernel Python composition, for the
