@@ -289,7 +289,10 @@ def gemm(A, W, bias=None, scale=None, A2=None, rows=None, R=None, relu=False, ou
     return out
 
 
-PW_K256 = _switch("PW_K256")         # f16x3 back-end: pointwise convolutions with 256 input channels on the row-resident K = 256 kernel
+# f16x3 back-end: pointwise convolutions with 256 input channels (res4 conv3) on the row-resident K = 256 kernel.  MEASURED in the
+# step (bench.py, one box): 157 us per launch against the tile kernel's 150 -- the shortcut's residual reads and 16-byte stores
+# cost what the missing A staging saves at 441 one-per-CU tiles.  OFF; GOM_PW_K256=1 for A/B runs.
+PW_K256 = _switch("PW_K256", default=False)
 PW_K256_MIN_ROWS = 16384
 CONV3_PATCH = _switch("CONV3_PATCH")   # f16x3 back-end: 3x3 / stride 1 convolutions on the patch-resident kernel
 

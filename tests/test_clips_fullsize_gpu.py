@@ -61,14 +61,17 @@ def _px_tol(images):
     return max(1e-3, 8.0 * float(np.spacing(np.float32(max(max(im.shape[-2:]) for im in images)))))
 
 
-def _rank_swaps(model, image, taps_o, nq):
-    """Ranks at which the HIP path's proposal winners differ from the oracle's (same frame, B = 1), after checking that they are
-    the same SET and that every moved rank sits on an oracle logit gap below 1e-4."""
+def _rank_swaps(model, step_inputs, b, taps_o, nq):
+    """Ranks at which the HIP path's proposal winners of frame `b` of a detector step differ from the oracle's, after checking
+    that they are the same SET and that every moved rank sits on an oracle logit gap below 1e-4.  The WHOLE step is run again
+    (eagerly, with taps): a near-tie can fall either way between two correct evaluations, e.g. a batch of 8 and a batch of 1
+    (the stride-2 input_proj convolution slices K by the number of tiles), so the winners are read from the same batch shape
+    the detections came from."""
     taps = {}
-    x, _ = model.preprocess_image([{"image": image}])
+    x, _ = model.preprocess_image(step_inputs)
     feats = model.backbone.forward(x)
     model.detection_transformer.forward([feats[k] for k in model.feature_names], taps=taps)
-    got = taps["topk"].reshape(-1).cpu().numpy()
+    got = taps["topk"].reshape(len(step_inputs), nq)[b].cpu().numpy()
     ref = taps_o["topk"].reshape(-1).numpy()
     assert sorted(got.tolist()) == sorted(ref.tolist()), "proposal winners differ as a SET"
     moved = np.nonzero(got != ref)[0]
@@ -140,7 +143,8 @@ def _clip_vs_oracle(builtin, frames_rgb, frac, check_frames, log):
             for f in check_frames:                                     # the CPU detector on a subset of the frames
                 taps_o = {}
                 ref = O.detect_frames(sd, ocfg, [images[f]], taps=taps_o)[0]
-                moved = _rank_swaps(model, images[f], taps_o, cfg.MODEL.TRANSFORMER.NUM_QUERIES)
+                s0, s1 = [st for st in model._steps(inputs) if st[0] <= f < st[1]][0]
+                moved = _rank_swaps(model, inputs[s0:s1], f - s0, taps_o, cfg.MODEL.TRANSFORMER.NUM_QUERIES)
                 worst = _same_detections(raw[f], ref, px_tol, swapped=len(moved) > 0)
                 log["checked_frames"].append({"frame": f, "detections": len(ref), "ranks_moved": moved.tolist(), "max_abs_px": worst})
     kept = model._remove_short_track(list(insts)) if model.min_track_len > 0 else insts
