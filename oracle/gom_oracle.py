@@ -252,7 +252,7 @@ def decoder_layer(tgt, query_pos, ref_in, src, shapes, lsi, mask, sd, p, T):
     return layer_norm(tgt + t2, sd, p + "norm3")
 
 
-def deepsolo_forward(sd, cfg, feats, masks, pos, taps=None, prefix="detection_transformer."):
+def deepsolo_forward(sd, cfg, feats, masks, pos, taps=None, prefix="detection_transformer.", topk_override=None):
     """detection_transformer_wobackbone.py:159-270 + deformable_transformer.py:150-215.
     feats: 3 NCHW tensors (res3/4/5); masks: 3 bool [B,H,W]; pos: 3 NCHW pos encodings."""
     T = cfg.MODEL.TRANSFORMER
@@ -315,6 +315,10 @@ def deepsolo_forward(sd, cfg, feats, masks, pos, taps=None, prefix="detection_tr
     enc_class = linear(om, sd, prefix + "bezier_proposal_class")
     enc_coord = mlp(om, sd, prefix + "bezier_proposal_coord", 3) + props
     topk = torch.topk(enc_class[..., 0], nq, dim=1)[1]
+    if topk_override is not None:
+        # test aid: the winners in a GIVEN rank order (a parity test hands over the HIP path's order where two winners' logits
+        # are closer than any fp32 evaluation can resolve: a query slot = learned embedding + the token of that rank)
+        topk = torch.as_tensor(topk_override, dtype=torch.long).view(B, nq)
     coords = torch.gather(enc_coord, 1, topk.unsqueeze(-1).repeat(1, 1, 8)).sigmoid()
     refp = torch.matmul(bernstein_matrix(P).to(coords.dtype), coords.view(B, nq, 4, 2))      # B,nq,P,2
     if taps is not None:
@@ -702,7 +706,7 @@ def batch_postprocess(instances, image_sizes, min_size=None, max_size=None):
 # --------------------------------------------------------------------------
 # A1 + whole-frame driver
 # --------------------------------------------------------------------------
-def detect_frames(sd, cfg, images, taps=None):
+def detect_frames(sd, cfg, images, taps=None, topk_override=None):
     """gom_lstmatcher.py:268-351 for a list of [3,H,W] float images (0..255, cfg.INPUT.FORMAT order),
     all of one size: returns the per-frame Inst list *before* tracking."""
     mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
@@ -725,7 +729,7 @@ def detect_frames(sd, cfg, images, taps=None):
     pos = [pos_encoding_2d(m, T.HIDDEN_DIM // 2, T.TEMPERATURE) for m in masks]
     if taps is not None:
         taps.update(res3=feats[0], res4=feats[1], res5=feats[2])
-    out = deepsolo_forward(sd, cfg, feats, masks, pos, taps=taps)
+    out = deepsolo_forward(sd, cfg, feats, masks, pos, taps=taps, topk_override=topk_override)
     re = linear(out["query_features"], sd, "roi_heads.rescoring_head") if cfg.MODEL.ROI_HEADS.WITH_RESR else None
     if taps is not None:
         taps.update({("out_" + k): v for k, v in out.items() if v is not None})

@@ -17,8 +17,10 @@ points 1e-3 px).  Two facts bound what an fp32-vs-fp32 comparison can hold at th
   * the proposal stage picks the top-300 of 60 640 class logits; ~25 of the 299 gaps between consecutive winners are below 1e-4
     and some below 1e-5 (tools/diag/topk_ties.py), i.e. inside the rounding noise of ANY fp32 evaluation (the reference's own
     included).  Where two near-tied winners swap RANK (a query slot = learned embedding + the token of that rank) every other
-    query moves by ~2e-5 through the inter-query attention.  A checked frame whose winners are not rank-identical must show
-    that every moved rank sits on an oracle gap < 1e-4; its points are then held to 0.15 px and its scores to 2e-4 instead.
+    query moves by 2e-5 .. 1e-4 through the inter-query attention.  A checked frame whose winners are not rank-identical must
+    show the same winner SET with every moved rank on an oracle gap < 1e-4; the oracle then evaluates the frame once more
+    with the winners in the HIP path's order (oracle.detect_frames(topk_override=...)) and everything is held to the strict
+    tolerances again.
 """
 import os
 import time
@@ -79,7 +81,7 @@ def _rank_swaps(model, step_inputs, b, taps_o, nq):
     for i in moved:
         j = int(np.nonzero(ref == got[i])[0][0])
         assert abs(float(val[i]) - float(val[j])) < 1e-4, ("rank %d <-> %d swapped across a gap of %.2e" % (i, j, abs(float(val[i] - val[j]))))
-    return moved
+    return moved, got
 
 
 def _oracle_insts(res):
@@ -94,19 +96,19 @@ def _oracle_insts(res):
     return out
 
 
-def _same_detections(got, ref, px_tol, swapped=False):
+def _same_detections(got, ref, px_tol):
     assert len(got) == len(ref), (len(got), len(ref))
     if len(ref) == 0:
         return 0.0
     assert torch.equal(got["recs"], ref["recs"])
     # scores: sigmoid of the mean point logit after 12 transformer layers (north_star's bound is 1e-3)
-    assert float((got["scores"] - ref["scores"]).abs().max()) <= (2e-4 if swapped else 2e-5)
+    assert float((got["scores"] - ref["scores"]).abs().max()) <= 2e-5
     worst = 0.0
     for k in ("bd", "ctrl_points", "pred_boxes"):
         d = float((got[k] - ref[k]).abs().max())
         worst = max(worst, d)
-        assert d <= (0.15 if swapped else px_tol), (k, d, swapped)
-    assert float((got["reid_features"] - ref["reid_features"]).abs().max()) <= (2e-3 if swapped else 1e-4)
+        assert d <= px_tol, (k, d)
+    assert float((got["reid_features"] - ref["reid_features"]).abs().max()) <= 1e-4
     return worst
 
 
@@ -144,8 +146,10 @@ def _clip_vs_oracle(builtin, frames_rgb, frac, check_frames, log):
                 taps_o = {}
                 ref = O.detect_frames(sd, ocfg, [images[f]], taps=taps_o)[0]
                 s0, s1 = [st for st in model._steps(inputs) if st[0] <= f < st[1]][0]
-                moved = _rank_swaps(model, inputs[s0:s1], f - s0, taps_o, cfg.MODEL.TRANSFORMER.NUM_QUERIES)
-                worst = _same_detections(raw[f], ref, px_tol, swapped=len(moved) > 0)
+                moved, order = _rank_swaps(model, inputs[s0:s1], f - s0, taps_o, cfg.MODEL.TRANSFORMER.NUM_QUERIES)
+                if len(moved):                                         # near-tied winners fell the other way: same order, again
+                    ref = O.detect_frames(sd, ocfg, [images[f]], topk_override=order)[0]
+                worst = _same_detections(raw[f], ref, px_tol)
                 log["checked_frames"].append({"frame": f, "detections": len(ref), "ranks_moved": moved.tolist(), "max_abs_px": worst})
     kept = model._remove_short_track(list(insts)) if model.min_track_len > 0 else insts
     res = model.batch_postprocess(kept, sizes)

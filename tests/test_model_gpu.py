@@ -279,7 +279,7 @@ def test_tracker_mixed_resolution_vs_oracle(builtin, matcher_runtime):
     for f in range(40):
         assert insts[f].track_ids.cpu().tolist() == o_res[f]["track_ids"].tolist(), f
     # the sizes matter: normalising everything by one size gives other ids on this trace (the test would not notice otherwise)
-    same = [O.Inst(sizes[0], reid_features=x["reid_features"].clone(), pred_boxes=x["pred_boxes"].clone()) for x in o_insts]
+    same = [O.Inst(sizes[0], reid_features=torch.from_numpy(f_).clone(), pred_boxes=torch.from_numpy(b).clone()) for f_, b in scaled]
     with torch.no_grad():
         s_res, _ = O.track_clip(sd, ocfg, same)
     assert any(a["track_ids"].tolist() != b["track_ids"].tolist() for a, b in zip(s_res, o_res))
