@@ -237,13 +237,15 @@ __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __re
                                                                const float* __restrict__ raw, int ld_raw,
                                                                const float* __restrict__ ref, float* __restrict__ out,
                                                                int B, int Lq, long v_bs, int v_rs,
-                                                               const float* __restrict__ vr) {
+                                                               const float* __restrict__ vr, int q_begin, int q_count) {
     constexpr int POINTS = 4, LP = LEVELS * POINTS;
-    const long q_global = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
-    if (q_global >= (long)B * Lq) return;
+    // queries [q_begin, q_begin + q_count) of every frame (the whole frame by default; the tail behind the windowed kernel's part)
+    const long q_local = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+    if (q_local >= (long)B * q_count) return;
     const int lane = threadIdx.x & 63;
     const int m = lane >> 3, k = lane & 7;
-    const int b = (int)(q_global / Lq);
+    const int b = (int)(q_local / q_count);
+    const long q_global = (long)b * Lq + q_begin + (q_local - (long)b * q_count);
     const int l = k >> 1;                                    // level of this lane's two samples (2k, 2k + 1)
 
     // ---- owner part: two samples per lane ----
@@ -328,6 +330,225 @@ __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __re
     *reinterpret_cast<f32x4*>(out + (size_t)q_global * (HEADS * CH) + m * CH + k * 4) = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The fused op for the ENCODER's level-0 queries with the value map served from LDS (round 4).
+//
+// The kernels above are bound by the texture-address path: 512 scattered 128-byte corner lines per query at ~3.6 cycles each
+// (profiles/r03_msda_ta_counters.txt; no gather shape or value layout is cheaper: profiles/r04_msda_ta_counters.txt).  But an
+// encoder query IS a pixel, and its 128 samples fall within a few pixels of that pixel's position on every level: the raw
+// offsets are in pixels of the sampled level (loc = ref + off / (W_l, H_l)), |off| <= 5.4 over six layers of the bench
+// workload, p99.9 = 4 (tools/diag/msda_offsets.py; the reference initialises the offsets' bias to k = 1..4 pixels along eight
+// directions).  So a workgroup that owns a TILE of TY x TX level-0 queries and ONE head needs, per level, only the tile's
+// projection plus a halo of R pixels: it loads those lines ONCE (whole 128-byte lines, ~12 per (query, head) instead of 64
+// gathered ones) into LDS and serves every corner from there with ds_read_b128.
+//   * one workgroup = (frame, tile, head), 4 waves; a wave handles 8 (query, head) pairs at a time (8 lanes each, 4 channels per
+//     lane -- the lane-distributed kernel's layout with the eight heads of a wave replaced by eight queries), 4 such octet
+//     groups per wave = 128 queries per tile;
+//   * the per-sample arithmetic is the lane-distributed kernel's, instruction for instruction (softmax, location, the four
+//     corner weights, `(w1 v1 + w2 v2 + w3 v3 + w4 v4) * w` accumulated in sample order), so results are BIT-IDENTICAL;
+//   * levels are processed one after the other through one LDS buffer (fill level l, barrier, its four samples of every query);
+//     the accumulation order l = 0..3, p = 0..3 is the kernels' above;
+//   * a sample whose clamped corners are not all inside the window makes its wave's octet group (8 queries) take the global-
+//     memory path for that group -- the lane-distributed kernel's arithmetic again, same bits; never taken on the bench workload;
+//   * workgroup id = tile * 8 + head: workgroups go round-robin to the 8 XCDs, so XCD m sees exactly head m's lines (1/8 of the
+//     value map per L2) and consecutive tiles, which share their halos, meet in the same L2.
+// Queries of the coarser levels (25 % of the tokens) keep the lane-distributed kernel (q_begin / q_count above).
+template <int TY, int TX, int R, int CAP>
+__global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __restrict__ value,
+                                                             const int64_t* __restrict__ shapes,
+                                                             const int64_t* __restrict__ lsi,
+                                                             const float* __restrict__ raw, int ld_raw,
+                                                             const float* __restrict__ ref, float* __restrict__ out,
+                                                             int Lq, long v_bs, int v_rs, int tiles_y, int tiles_x) {
+    constexpr int POINTS = 4, LP = LEVELS * POINTS, ITERS = (TY * TX) / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char win[];          // CAP lines of 128 bytes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 3, k = lane & 7;
+    const int m = (int)(blockIdx.x & 7u);                    // head
+    unsigned tile = blockIdx.x >> 3;
+    const int tx = (int)(tile % (unsigned)tiles_x);
+    tile /= (unsigned)tiles_x;
+    const int ty = (int)(tile % (unsigned)tiles_y);
+    const int b = (int)(tile / (unsigned)tiles_y);
+    const int l = k >> 1;                                    // level of this lane's two samples (2k, 2k + 1)
+
+    int Hs[LEVELS], Ws[LEVELS];
+    unsigned lv[LEVELS];
+#pragma unroll
+    for (int i = 0; i < LEVELS; ++i) {
+        Hs[i] = (int)shapes[2 * i];
+        Ws[i] = (int)shapes[2 * i + 1];
+        lv[i] = (unsigned)lsi[i];
+    }
+    const int y0t = ty * TY, x0t = tx * TX;
+    const int y1t = min(y0t + TY, Hs[0]) - 1, x1t = min(x0t + TX, Ws[0]) - 1;
+    // windows: the projection of the tile's first and last query on every level, R pixels of halo + the second bilinear corner
+    const long qa = (long)b * Lq + (long)y0t * Ws[0] + x0t, qz = (long)b * Lq + (long)y1t * Ws[0] + x1t;
+    const float rxa = ref[qa * 2], rya = ref[qa * 2 + 1], rxz = ref[qz * 2], ryz = ref[qz * 2 + 1];
+    int wx0[LEVELS], wy0[LEVELS], wx1[LEVELS], wy1[LEVELS], wwd[LEVELS];
+#pragma unroll
+    for (int i = 0; i < LEVELS; ++i) {
+        int ax = (int)floorf(fminf(rxa, rxz) * Ws[i] - 0.5f) - R, zx = (int)floorf(fmaxf(rxa, rxz) * Ws[i] - 0.5f) + R + 1;
+        int ay = (int)floorf(fminf(rya, ryz) * Hs[i] - 0.5f) - R, zy = (int)floorf(fmaxf(rya, ryz) * Hs[i] - 0.5f) + R + 1;
+        ax = max(ax, 0); ay = max(ay, 0); zx = min(zx, Ws[i] - 1); zy = min(zy, Hs[i] - 1);
+        if (zx < ax) zx = ax;
+        if (zy < ay) zy = ay;
+        int w_ = zx - ax + 1, h_ = zy - ay + 1;
+        if (w_ > CAP) { w_ = CAP; zx = ax + w_ - 1; }
+        if (w_ * h_ > CAP) { h_ = CAP / w_; zy = ay + h_ - 1; }   // whatever does not fit is served by the global path
+        wx0[i] = ax; wy0[i] = ay; wx1[i] = zx; wy1[i] = zy; wwd[i] = w_;
+    }
+    // this lane's level (runtime index l): select with compares, not an indexed array (registers)
+    const int H = l == 0 ? Hs[0] : l == 1 ? Hs[1] : l == 2 ? Hs[2] : Hs[3];
+    const int W = l == 0 ? Ws[0] : l == 1 ? Ws[1] : l == 2 ? Ws[2] : Ws[3];
+    const int mx0 = l == 0 ? wx0[0] : l == 1 ? wx0[1] : l == 2 ? wx0[2] : wx0[3];
+    const int my0 = l == 0 ? wy0[0] : l == 1 ? wy0[1] : l == 2 ? wy0[2] : wy0[3];
+    const int mx1 = l == 0 ? wx1[0] : l == 1 ? wx1[1] : l == 2 ? wx1[2] : wx1[3];
+    const int my1 = l == 0 ? wy1[0] : l == 1 ? wy1[1] : l == 2 ? wy1[2] : wy1[3];
+    const int mww = l == 0 ? wwd[0] : l == 1 ? wwd[1] : l == 2 ? wwd[2] : wwd[3];
+    const unsigned lvl = l == 0 ? lv[0] : l == 1 ? lv[1] : l == 2 ? lv[2] : lv[3];
+    const float Hf = (float)H, Wf = (float)W;
+    const float rW = 1.f / Wf, rH = 1.f / Hf;
+
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(value + (size_t)b * v_bs), 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned mine = (unsigned)k * 16u;                 // this lane's 4 channels inside a 128-byte line
+    const unsigned head = (unsigned)(m * CH) * 4u;
+
+    // ---- owner part of every octet group: the lane-distributed kernel's, plus the window test and the LDS address ----
+    float sw1[ITERS][2], sw2[ITERS][2], sw3[ITERS][2], sw4[ITERS][2], sww[ITERS][2];
+    unsigned pk[ITERS][2];                                   // LDS byte address of corner (yc0, xc0) | dx << 20 | dy << 21
+    f32x4 acc[ITERS];
+    long qrow[ITERS];
+    bool fast[ITERS], live[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int j = (wave * ITERS + it) * 8 + g;           // query of the tile
+        const int jy = j / TX, jx = j - jy * TX;
+        const int qy = y0t + jy, qx = x0t + jx;
+        live[it] = qy <= y1t && qx <= x1t;
+        const long q_global = (long)b * Lq + (long)(live[it] ? qy : y0t) * Ws[0] + (live[it] ? qx : x0t);
+        qrow[it] = q_global;
+        const float* op = raw + (size_t)q_global * ld_raw + m * (LP * 2) + 4 * k;
+        const float* lp = raw + (size_t)q_global * ld_raw + HEADS * LP * 2 + m * LP + 2 * k;
+        const f32x4 off = *reinterpret_cast<const f32x4*>(op);
+        const float lg0 = lp[0], lg1 = lp[1];
+        const float rx = ref[q_global * 2], ry = ref[q_global * 2 + 1];
+        float mx = fmaxf(lg0, lg1);
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x1F | (1 << 10))));
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x1F | (2 << 10))));
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x1F | (4 << 10))));
+        const float e0 = expf(lg0 - mx), e1 = expf(lg1 - mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            sum += group8_read(e0, o);
+            sum += group8_read(e1, o);
+        }
+        const float inv_sum = 1.f / sum;
+        bool inw = true;
+        unsigned so1[2], so2[2], so3[2], so4[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float ox = off[2 * t], oy = off[2 * t + 1];
+            float qx_ = ox * rW, qy_ = oy * rH;
+            qx_ = fmaf(fmaf(-qx_, Wf, ox), rW, qx_);
+            qy_ = fmaf(fmaf(-qy_, Hf, oy), rH, qy_);
+            const float lx = rx + qx_, ly = ry + qy_;
+            const float w = (t ? e1 : e0) * inv_sum;
+            const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+            const bool inside = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
+            const bool y0 = h_low >= 0, y1 = h_low + 1 <= H - 1;
+            const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
+            const int yc0 = y0 ? h_low : 0, yc1 = y1 ? h_low + 1 : H - 1;
+            const int xc0 = x0 ? w_low : 0, xc1 = x1 ? w_low + 1 : W - 1;
+            const unsigned r0 = lvl + (unsigned)(yc0 * W), r1 = lvl + (unsigned)(yc1 * W);
+            so1[t] = (r0 + xc0) * (unsigned)v_rs * 4u + head;
+            so2[t] = (r0 + xc1) * (unsigned)v_rs * 4u + head;
+            so3[t] = (r1 + xc0) * (unsigned)v_rs * 4u + head;
+            so4[t] = (r1 + xc1) * (unsigned)v_rs * 4u + head;
+            sww[it][t] = inside ? w : 0.f;
+            sw1[it][t] = (y0 && x0) ? hh * hw : 0.f;
+            sw2[it][t] = (y0 && x1) ? hh * lw : 0.f;
+            sw3[it][t] = (y1 && x0) ? lh * hw : 0.f;
+            sw4[it][t] = (y1 && x1) ? lh * lw : 0.f;
+            // a sample outside the map carries weight 0: any finite line serves (the kernels above read the map's corner there)
+            const bool ok = !inside || (yc0 >= my0 && yc1 <= my1 && xc0 >= mx0 && xc1 <= mx1);
+            inw = inw && ok;
+            const int ly0 = inside ? yc0 - my0 : 0, lx0 = inside ? xc0 - mx0 : 0;
+            pk[it][t] = (unsigned)((ly0 * mww + lx0) * 128) | ((inside && xc1 != xc0) ? (1u << 20) : 0u) |
+                        ((inside && yc1 != yc0) ? (1u << 21) : 0u);
+        }
+        fast[it] = __builtin_amdgcn_ballot_w64(!inw) == 0;   // wave-uniform: all 8 queries' samples are inside their windows
+        acc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!fast[it]) {
+            // the lane-distributed kernel's gather for this octet group, from global memory
+#pragma unroll
+            for (int i = 0; i < LP; ++i) {
+                const int o = i >> 1, t = i & 1;
+                const unsigned a1 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so1[t]), o)) + mine;
+                const unsigned a2 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so2[t]), o)) + mine;
+                const unsigned a3 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so3[t]), o)) + mine;
+                const unsigned a4 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so4[t]), o)) + mine;
+                const f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a1, 0, 0));
+                const f32x4 v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a2, 0, 0));
+                const f32x4 v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a3, 0, 0));
+                const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a4, 0, 0));
+                const float w1 = group8_read(sw1[it][t], o), w2 = group8_read(sw2[it][t], o), w3 = group8_read(sw3[it][t], o),
+                            w4 = group8_read(sw4[it][t], o), ww = group8_read(sww[it][t], o);
+                const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                acc[it] += val * ww;
+            }
+        }
+    }
+
+    // ---- level by level: fill the window, then the level's four samples of every octet group ----
+#pragma unroll
+    for (int lev = 0; lev < LEVELS; ++lev) {
+        const int ww_ = wwd[lev], n_lines = ww_ * (wy1[lev] - wy0[lev] + 1);
+        __syncthreads();                                     // the previous level's reads are done
+        for (int base = wave * 8; base < n_lines; base += 32) {
+            const int line = base + g;
+            if (line < n_lines) {
+                const int yy = line / ww_, xx = line - yy * ww_;
+                const unsigned src = (lv[lev] + (unsigned)((wy0[lev] + yy) * Ws[lev] + wx0[lev] + xx)) * (unsigned)v_rs * 4u + head + mine;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)src, 0, 0));
+                *reinterpret_cast<f32x4*>(win + (size_t)line * 128 + mine) = v;
+            }
+        }
+        __syncthreads();
+        const unsigned row_bytes = (unsigned)ww_ * 128u;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (!fast[it]) continue;
+#pragma unroll
+            for (int pnt = 0; pnt < POINTS; ++pnt) {
+                const int i = lev * POINTS + pnt, o = i >> 1, t = i & 1;
+                const unsigned word = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, pk[it][t]), o));
+                const unsigned a1 = (word & 0xFFFFFu) + mine;
+                const unsigned dx = (word >> 20) & 1u, dy = (word >> 21) & 1u;
+                const unsigned a2 = a1 + dx * 128u, a3 = a1 + dy * row_bytes, a4 = a3 + dx * 128u;
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(win + a1);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(win + a2);
+                const f32x4 v3 = *reinterpret_cast<const f32x4*>(win + a3);
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(win + a4);
+                const float w1 = group8_read(sw1[it][t], o), w2 = group8_read(sw2[it][t], o), w3 = group8_read(sw3[it][t], o),
+                            w4 = group8_read(sw4[it][t], o), ww = group8_read(sww[it][t], o);
+                const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                acc[it] += val * ww;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+        if (live[it]) *reinterpret_cast<f32x4*>(out + (size_t)qrow[it] * (HEADS * CH) + m * CH + k * 4) = acc[it];
+}
+
 }  // namespace
 
 static int g_msda_lanes = 1;
@@ -349,11 +570,52 @@ extern "C" int gom_msda_fused_forward(const float* raw, int ld_raw, const float*
     if (g_msda_lanes && value_batch_stride > 0 && value_batch_stride < (1L << 29))     // 32-bit byte offsets inside a batch image
         hipLaunchKernelGGL((msda_fused_lanes_kernel<false>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream,
                            value, spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
-                           value_batch_stride, value_row_stride, (const float*)nullptr);
+                           value_batch_stride, value_row_stride, (const float*)nullptr, 0, num_query);
     else
         hipLaunchKernelGGL((msda_fused_kernel<4, false>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
                            spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
                            value_batch_stride, value_row_stride, (const float*)nullptr);
+    return gom_launch_status();
+}
+
+static int g_msda_window = 1;
+/* [host] 1 (default): the encoder entry below serves the level-0 queries from LDS windows; 0: everything on the lane-distributed
+ * kernel (A/B runs, tests).  Same bits either way. */
+extern "C" int gom_msda_set_window(int on) {
+    g_msda_window = on ? 1 : 0;
+    return GOM_OK;
+}
+
+/* The fused op for an ENCODER call: num_query = the tokens of the pyramid (query q of a frame IS token q: level-0 pixels first,
+ * `h0` x `w0` of them in raster order), reference points = the pixels' own positions.  Level-0 queries run on the LDS-window
+ * kernel, the coarser levels' on the lane-distributed one; results are bit-identical to gom_msda_fused_forward. */
+extern "C" int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, const float* ref, const float* value,
+                                              long value_batch_stride, int value_row_stride, const int64_t* spatial_shapes,
+                                              const int64_t* level_start_index, float* output, int batch, int num_query,
+                                              int h0, int w0, void* stream) {
+    GOM_CHECK_ARG(raw && ref && value && spatial_shapes && level_start_index && output);
+    GOM_CHECK_ARG(batch > 0 && num_query > 0 && ld_raw >= HEADS * LEVELS * 4 * 3 && (ld_raw % 4) == 0);
+    GOM_CHECK_ARG(value_row_stride >= HEADS * CH && (value_row_stride % 4) == 0 && (value_batch_stride % 4) == 0);
+    GOM_CHECK_ARG(((uintptr_t)raw % 16) == 0 && ((uintptr_t)value % 16) == 0);
+    GOM_CHECK_ARG(h0 > 0 && w0 > 0 && (long)h0 * w0 <= num_query);
+    constexpr int TY = 8, TX = 16, R = 5, CAP = 576;         // 72 KB of LDS: two workgroups per CU
+    const long n0 = (long)h0 * w0;
+    const int tiles_y = cdiv(h0, TY), tiles_x = cdiv(w0, TX);
+    const long wgs = (long)batch * tiles_y * tiles_x * 8;
+    if (!(g_msda_window && g_msda_lanes && value_batch_stride > 0 && value_batch_stride < (1L << 29) && wgs < (1L << 31)))
+        return gom_msda_fused_forward(raw, ld_raw, ref, value, value_batch_stride, value_row_stride, spatial_shapes,
+                                      level_start_index, output, batch, num_query, stream);
+    auto kern = msda_window_kernel<TY, TX, R, CAP>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CAP * 128);
+    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), CAP * 128, (hipStream_t)stream, value, spatial_shapes,
+                       level_start_index, raw, ld_raw, ref, output, num_query, value_batch_stride, value_row_stride, tiles_y,
+                       tiles_x);
+    const long rest = num_query - n0;
+    if (rest > 0)
+        hipLaunchKernelGGL((msda_fused_lanes_kernel<false>), dim3((unsigned)cdiv((long)batch * rest, 4)), dim3(256), 0,
+                           (hipStream_t)stream, value, spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch,
+                           num_query, value_batch_stride, value_row_stride, (const float*)nullptr, (int)n0, (int)rest);
     return gom_launch_status();
 }
 
@@ -368,7 +630,7 @@ extern "C" int gom_msda_fused_forward_vr(const float* raw, int ld_raw, const flo
     if (g_msda_lanes && value_batch_stride > 0 && value_batch_stride < (1L << 29))
         hipLaunchKernelGGL((msda_fused_lanes_kernel<true>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream,
                            value, spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
-                           value_batch_stride, value_row_stride, valid_ratios);
+                           value_batch_stride, value_row_stride, valid_ratios, 0, num_query);
     else
         hipLaunchKernelGGL((msda_fused_kernel<4, true>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, value,
                            spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,

@@ -229,6 +229,7 @@ class DeepSolo:
             pos_w = [ops.broadcast_rows(t_, B).view(B * S, 384) for t_ in pos_w]
         geo = {
             "S": S, "shapes": ss_d, "lsi": lsi_d, "lsi_host": [int(v) for v in lsi], "pos_w": pos_w,
+            "hw0": (int(shapes[0][0]), int(shapes[0][1])),
             "pos_periodic": self._pos_periodic,
             "lvl_pos": ops.broadcast_rows(lvl_pos, B).view(B * S, 256),
             "enc_ref": ops.broadcast_rows(ops.encoder_reference_points(ss_d, lsi_d, S, vs_d), B).view(B * S, 1, 2),
@@ -279,7 +280,8 @@ class DeepSolo:
                             r_period=S if geo["pos_periodic"] else 0)                     # [B*S, 384 | 256]
             if geo["vr"] is not None:                      # padded batch: value.masked_fill(padding_mask, 0)
                 ops.zero_padded_tokens_(rv, 384, 256, geo["shapes"], geo["lsi"], geo["vshapes"], B, S)
-            samp = ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, geo["vr"])
+            samp = ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, geo["vr"],
+                                  encoder_hw0=geo["hw0"] if geo["vr"] is None else None)
             if L["out_ln"] is not None:
                 src = ops.proj_ln(samp, L["out_ln"], src)
             else:

@@ -900,9 +900,13 @@ MSDA_LANES = _switch("MSDA_LANES")   # fused MSDA: per-sample arithmetic distrib
 _msda_lanes_set = [None]
 
 
-def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq, valid_ratios=None):
+MSDA_WINDOW = _switch("MSDA_WINDOW")   # encoder calls: level-0 queries served from LDS windows of the value map (same bits)
+
+
+def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq, valid_ratios=None, encoder_hw0=None):
     """raw [B*Lq, >=384] (offsets | logits, stride(1)==1), ref [B*Lq, 2], value2d [B*S, 256] column slice;
-    valid_ratios [4,2] fp32 (Wv/W, Hv/H) for padded batches."""
+    valid_ratios [4,2] fp32 (Wv/W, Hv/H) for padded batches.  encoder_hw0 = (H0, W0): an ENCODER call (query q = token q,
+    reference points = the tokens' own positions) -- the level-0 queries then run on the LDS-window kernel (csrc/msda.hip)."""
     assert raw.stride(1) == 1 and value2d.stride(1) == 1
     _chk_f32(ref, valid_ratios)
     if _msda_lanes_set[0] != MSDA_LANES:                     # library-side switch follows ops.MSDA_LANES
@@ -926,8 +930,13 @@ def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq, valid_ratios
                                              _stream()), "gom_msda_fused_forward_vr")
         _after()
         return out
-    check(_L().gom_msda_fused_forward(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride, value2d.stride(0),
-                                      _p(shapes), _p(lsi), _p(out), B, Lq, _stream()), "gom_msda_fused_forward")
+    if encoder_hw0 is not None and MSDA_WINDOW and MSDA_LANES:
+        check(_L().gom_msda_fused_forward_encoder(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride, value2d.stride(0),
+                                                  _p(shapes), _p(lsi), _p(out), B, Lq, int(encoder_hw0[0]), int(encoder_hw0[1]),
+                                                  _stream()), "gom_msda_fused_forward_encoder")
+    else:
+        check(_L().gom_msda_fused_forward(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride, value2d.stride(0),
+                                          _p(shapes), _p(lsi), _p(out), B, Lq, _stream()), "gom_msda_fused_forward")
     _after()
     return out
 

@@ -379,6 +379,37 @@ def test_msda_larger_vs_oracle_and_prepare():
     _close(fused, exp.view(B * Lq, 256), 3e-5, 0, "fused msda vs oracle")
 
 
+@pytest.mark.parametrize("shapes,B,scale", [([(23, 31), (12, 16), (6, 8), (3, 4)], 2, 2.0), ([(40, 72), (20, 36), (10, 18), (5, 9)], 3, 4.0),
+                                            ([(17, 50), (9, 25), (5, 13), (3, 7)], 1, 9.0), ([(8, 16), (4, 8), (2, 4), (1, 2)], 2, 1.0),
+                                            ([(125, 223), (63, 112), (32, 56), (16, 28)], 1, 2.5)])
+def test_msda_encoder_window_kernel_is_bit_identical(shapes, B, scale):
+    """The encoder form of the fused op (level-0 queries served from LDS windows of the value map, csrc/msda.hip) against the
+    lane-distributed kernel on the same inputs: the SAME BITS -- with offsets of a few pixels (everything inside the windows),
+    with offsets far beyond the halo (the octet groups' global-memory path), on maps that are not multiples of the 8 x 16 tile
+    and on the bench's pyramid."""
+    ops = _ops()
+    from gomatching_amd import lib
+    g = torch.Generator().manual_seed(int(scale * 10) + B)
+    ss = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    S = int(ss.prod(1).sum())
+    wide = torch.randn(B * S, 640, generator=g).to(DEV)
+    raw = torch.randn(B * S, 384, generator=g)
+    raw[:, :256] *= scale                                             # offsets in pixels of the sampled level
+    raw = raw.to(DEV)
+    ref = ops.encoder_reference_points(ss.to(DEV), lsi.to(DEV), S).repeat(B, 1).contiguous()
+    L = lib.load()
+    try:
+        L.gom_msda_set_window(0)
+        plain = ops.msda_fused(raw, ref, wide[:, 384:], S * 640, ss.to(DEV), lsi.to(DEV), B, S, encoder_hw0=shapes[0])
+        L.gom_msda_set_window(1)
+        win = ops.msda_fused(raw, ref, wide[:, 384:], S * 640, ss.to(DEV), lsi.to(DEV), B, S, encoder_hw0=shapes[0])
+    finally:
+        L.gom_msda_set_window(1)
+    assert torch.equal(win, plain), float((win - plain).abs().max())
+    assert torch.equal(win, ops.msda_fused(raw, ref, wide[:, 384:], S * 640, ss.to(DEV), lsi.to(DEV), B, S))
+
+
 # ------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("hd,Lq,Lk,outer,inner", [(32, 25, 25, 6, 1), (32, 12, 12, 2, 25), (32, 100, 100, 1, 3),
                                                   (128, 37, 90, 1, 1), (128, 5, 700, 1, 1), (32, 300, 300, 1, 2)])
