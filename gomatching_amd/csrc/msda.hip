@@ -11,6 +11,8 @@
 // lanes per head, each lane 4 channels, so every corner fetch is a 16-byte load, a head's corner
 // is one 128-byte line, and the query's 256 outputs leave as one contiguous 1 KiB store.  The op
 // is gather-bound (HBM/L2), not MFMA work.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -230,6 +232,34 @@ __device__ __forceinline__ float group8_read(float v, int owner) {      // value
     }
 }
 
+// The same broadcast on the VALU: two DPP moves -- quad_perm spreads lane (owner & 3) of every quad, a row shift by 4 with a bank
+// mask then copies the owner's quad over the other quad of each group of eight.  ds_swizzle goes through the LDS pipe (~12 of its
+// cycles per wave-instruction, measured in the window kernel below, where 8 waves per CU issue 6 per corner-quartet); the VALU
+// has four pipes per CU and nothing else to do there.  Pure data movement: the same bits.
+template <int OWNER>
+__device__ __forceinline__ float group8_bcast(float v) {
+    constexpr int q = OWNER & 3;
+    constexpr int perm = q | (q << 2) | (q << 4) | (q << 6);
+    const int x = __builtin_bit_cast(int, v);
+    const int t = __builtin_amdgcn_update_dpp(x, x, perm, 0xF, 0xF, false);
+    // OWNER < 4: lanes 4..7 / 12..15 take lanes 0..3 / 8..11 (row_shr:4, banks 1 and 3); else the other way (row_shl:4, banks 0, 2)
+    const int r = OWNER < 4 ? __builtin_amdgcn_update_dpp(t, t, 0x114, 0xF, 0xA, false)
+                            : __builtin_amdgcn_update_dpp(t, t, 0x104, 0xF, 0x5, false);
+    return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float group8_bcast_rt(float v, int owner) {     // owner: a literal after unrolling
+    switch (owner) {
+        case 0: return group8_bcast<0>(v);
+        case 1: return group8_bcast<1>(v);
+        case 2: return group8_bcast<2>(v);
+        case 3: return group8_bcast<3>(v);
+        case 4: return group8_bcast<4>(v);
+        case 5: return group8_bcast<5>(v);
+        case 6: return group8_bcast<6>(v);
+        default: return group8_bcast<7>(v);
+    }
+}
+
 template <bool HAS_VR>
 __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __restrict__ value,
                                                                const int64_t* __restrict__ shapes,
@@ -353,8 +383,8 @@ __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __re
 //   * workgroup id = tile * 8 + head: workgroups go round-robin to the 8 XCDs, so XCD m sees exactly head m's lines (1/8 of the
 //     value map per L2) and consecutive tiles, which share their halos, meet in the same L2.
 // Queries of the coarser levels (25 % of the tokens) keep the lane-distributed kernel (q_begin / q_count above).
-template <int TY, int TX, int R, int CAP>
-__global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __restrict__ value,
+template <int TY, int TX, int R, int CAP, int CAPB, int NB, bool DPP = false>
+__global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const float* __restrict__ value,
                                                              const int64_t* __restrict__ shapes,
                                                              const int64_t* __restrict__ lsi,
                                                              const float* __restrict__ raw, int ld_raw,
@@ -395,8 +425,9 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
         if (zx < ax) zx = ax;
         if (zy < ay) zy = ay;
         int w_ = zx - ax + 1, h_ = zy - ay + 1;
-        if (w_ > CAP) { w_ = CAP; zx = ax + w_ - 1; }
-        if (w_ * h_ > CAP) { h_ = CAP / w_; zy = ay + h_ - 1; }   // whatever does not fit is served by the global path
+        const int cap = (CAPB && (i & 1)) ? CAPB : CAP;      // levels 1, 3 live in the second buffer when there is one
+        if (w_ > cap) { w_ = cap; zx = ax + w_ - 1; }
+        if (w_ * h_ > cap) { h_ = cap / w_; zy = ay + h_ - 1; }   // whatever does not fit is served by the global path
         wx0[i] = ax; wy0[i] = ay; wx1[i] = zx; wy1[i] = zy; wwd[i] = w_;
     }
     // this lane's level (runtime index l): select with compares, not an indexed array (registers)
@@ -416,12 +447,32 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
     const unsigned mine = (unsigned)k * 16u;                 // this lane's 4 channels inside a 128-byte line
     const unsigned head = (unsigned)(m * CH) * 4u;
 
+    // (the fill lambdas are defined below; level 0 of the double-buffered form is requested here, in front of the owner part)
+    if constexpr (CAPB != 0) {
+        const int ww_ = wwd[0], n_lines = ww_ * (wy1[0] - wy0[0] + 1);
+        const float inv_w = 1.f / (float)ww_;
+        for (int base = wave * 8; base < n_lines; base += 32) {
+            int line = base + g;
+            if (line > n_lines - 1) line = n_lines - 1;
+            int yy = (int)(((float)line + 0.5f) * inv_w);
+            int xx = line - yy * ww_;
+            if (xx < 0) { --yy; xx += ww_; }
+            if (xx >= ww_) { ++yy; xx -= ww_; }
+            const unsigned src = (lv[0] + (unsigned)((wy0[0] + yy) * Ws[0] + wx0[0] + xx)) * (unsigned)v_rs * 4u + head + mine;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(win + (size_t)base * 128), 16,
+                                                     (int)src, 0, 0, 0);
+        }
+    }
     // ---- owner part of every octet group: the lane-distributed kernel's, plus the window test and the LDS address ----
+    // (straight-line code over the ITERS groups: no branch in here or in the level loops, so that the scheduler can overlap the
+    // groups' loads, swizzles and LDS reads -- a wave has at most one partner on its SIMD to hide latency behind)
     float sw1[ITERS][2], sw2[ITERS][2], sw3[ITERS][2], sw4[ITERS][2], sww[ITERS][2];
     unsigned pk[ITERS][2];                                   // LDS byte address of corner (yc0, xc0) | dx << 20 | dy << 21
     f32x4 acc[ITERS];
     long qrow[ITERS];
     bool fast[ITERS], live[ITERS];
+    f32x4 offs[ITERS];
+    float lga[ITERS], lgb[ITERS], rxs[ITERS], rys[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int j = (wave * ITERS + it) * 8 + g;           // query of the tile
@@ -432,9 +483,52 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
         qrow[it] = q_global;
         const float* op = raw + (size_t)q_global * ld_raw + m * (LP * 2) + 4 * k;
         const float* lp = raw + (size_t)q_global * ld_raw + HEADS * LP * 2 + m * LP + 2 * k;
-        const f32x4 off = *reinterpret_cast<const f32x4*>(op);
-        const float lg0 = lp[0], lg1 = lp[1];
-        const float rx = ref[q_global * 2], ry = ref[q_global * 2 + 1];
+        offs[it] = *reinterpret_cast<const f32x4*>(op);
+        lga[it] = lp[0];
+        lgb[it] = lp[1];
+        rxs[it] = ref[q_global * 2];
+        rys[it] = ref[q_global * 2 + 1];
+    }
+    // geometry of sample (IT, T) of this lane (a macro, not a lambda: the arrays must be indexed by literals to stay in registers)
+#define MSDA_GEOMETRY(IT, T, OFF4, RX, RY, E, INV_SUM, OK, SO)                                                    \
+    {                                                                                                             \
+        const float ox = (OFF4)[2 * (T)], oy = (OFF4)[2 * (T) + 1];                                               \
+        float qx_ = ox * rW, qy_ = oy * rH;                                                                       \
+        qx_ = fmaf(fmaf(-qx_, Wf, ox), rW, qx_);                                                                  \
+        qy_ = fmaf(fmaf(-qy_, Hf, oy), rH, qy_);                                                                  \
+        const float lx = (RX) + qx_, ly = (RY) + qy_;                                                             \
+        const float w = (E) * (INV_SUM);                                                                          \
+        const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;                                                   \
+        const bool inside = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;                                 \
+        const float hf = floorf(h_im), wf = floorf(w_im);                                                         \
+        const float lh = h_im - hf, lw = w_im - wf;                                                               \
+        const float hh = 1.f - lh, hw = 1.f - lw;                                                                 \
+        const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;                                     \
+        const bool y0 = h_low >= 0, y1 = h_low + 1 <= H - 1;                                                      \
+        const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;                                                      \
+        const int yc0 = y0 ? h_low : 0, yc1 = y1 ? h_low + 1 : H - 1;                                             \
+        const int xc0 = x0 ? w_low : 0, xc1 = x1 ? w_low + 1 : W - 1;                                             \
+        const unsigned r0 = lvl + (unsigned)(yc0 * W), r1 = lvl + (unsigned)(yc1 * W);                            \
+        SO##1 = (r0 + xc0) * (unsigned)v_rs * 4u + head;                                                          \
+        SO##2 = (r0 + xc1) * (unsigned)v_rs * 4u + head;                                                          \
+        SO##3 = (r1 + xc0) * (unsigned)v_rs * 4u + head;                                                          \
+        SO##4 = (r1 + xc1) * (unsigned)v_rs * 4u + head;                                                          \
+        sww[IT][T] = inside ? w : 0.f;                                                                            \
+        sw1[IT][T] = (y0 && x0) ? hh * hw : 0.f;                                                                  \
+        sw2[IT][T] = (y0 && x1) ? hh * lw : 0.f;                                                                  \
+        sw3[IT][T] = (y1 && x0) ? lh * hw : 0.f;                                                                  \
+        sw4[IT][T] = (y1 && x1) ? lh * lw : 0.f;                                                                  \
+        /* a sample outside the map carries weight 0: any finite line serves (the kernels above read the map's corner there) */ \
+        OK = !inside || (yc0 >= my0 && yc1 <= my1 && xc0 >= mx0 && xc1 <= mx1);                                   \
+        const bool use = inside && OK; /* (an address inside the buffer in every case) */                         \
+        const int ly0 = use ? yc0 - my0 : 0, lx0 = use ? xc0 - mx0 : 0;                                           \
+        pk[IT][T] = (unsigned)((ly0 * mww + lx0) * 128) | ((use && xc1 != xc0) ? (1u << 20) : 0u) |               \
+                    ((use && yc1 != yc0) ? (1u << 21) : 0u);                                                      \
+    }
+    unsigned any_slow = 0;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const float lg0 = lga[it], lg1 = lgb[it];
         float mx = fmaxf(lg0, lg1);
         mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x1F | (1 << 10))));
         mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x1F | (2 << 10))));
@@ -447,54 +541,151 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
             sum += group8_read(e1, o);
         }
         const float inv_sum = 1.f / sum;
-        bool inw = true;
-        unsigned so1[2], so2[2], so3[2], so4[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float ox = off[2 * t], oy = off[2 * t + 1];
-            float qx_ = ox * rW, qy_ = oy * rH;
-            qx_ = fmaf(fmaf(-qx_, Wf, ox), rW, qx_);
-            qy_ = fmaf(fmaf(-qy_, Hf, oy), rH, qy_);
-            const float lx = rx + qx_, ly = ry + qy_;
-            const float w = (t ? e1 : e0) * inv_sum;
-            const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
-            const bool inside = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
-            const float hf = floorf(h_im), wf = floorf(w_im);
-            const float lh = h_im - hf, lw = w_im - wf;
-            const float hh = 1.f - lh, hw = 1.f - lw;
-            const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
-            const bool y0 = h_low >= 0, y1 = h_low + 1 <= H - 1;
-            const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
-            const int yc0 = y0 ? h_low : 0, yc1 = y1 ? h_low + 1 : H - 1;
-            const int xc0 = x0 ? w_low : 0, xc1 = x1 ? w_low + 1 : W - 1;
-            const unsigned r0 = lvl + (unsigned)(yc0 * W), r1 = lvl + (unsigned)(yc1 * W);
-            so1[t] = (r0 + xc0) * (unsigned)v_rs * 4u + head;
-            so2[t] = (r0 + xc1) * (unsigned)v_rs * 4u + head;
-            so3[t] = (r1 + xc0) * (unsigned)v_rs * 4u + head;
-            so4[t] = (r1 + xc1) * (unsigned)v_rs * 4u + head;
-            sww[it][t] = inside ? w : 0.f;
-            sw1[it][t] = (y0 && x0) ? hh * hw : 0.f;
-            sw2[it][t] = (y0 && x1) ? hh * lw : 0.f;
-            sw3[it][t] = (y1 && x0) ? lh * hw : 0.f;
-            sw4[it][t] = (y1 && x1) ? lh * lw : 0.f;
-            // a sample outside the map carries weight 0: any finite line serves (the kernels above read the map's corner there)
-            const bool ok = !inside || (yc0 >= my0 && yc1 <= my1 && xc0 >= mx0 && xc1 <= mx1);
-            inw = inw && ok;
-            const int ly0 = inside ? yc0 - my0 : 0, lx0 = inside ? xc0 - mx0 : 0;
-            pk[it][t] = (unsigned)((ly0 * mww + lx0) * 128) | ((inside && xc1 != xc0) ? (1u << 20) : 0u) |
-                        ((inside && yc1 != yc0) ? (1u << 21) : 0u);
-        }
-        fast[it] = __builtin_amdgcn_ballot_w64(!inw) == 0;   // wave-uniform: all 8 queries' samples are inside their windows
+        bool ok0, ok1;
+        unsigned sa1, sa2, sa3, sa4;
+        MSDA_GEOMETRY(it, 0, offs[it], rxs[it], rys[it], e0, inv_sum, ok0, sa)
+        MSDA_GEOMETRY(it, 1, offs[it], rxs[it], rys[it], e1, inv_sum, ok1, sa)
+        (void)sa1; (void)sa2; (void)sa3; (void)sa4;
+        fast[it] = __builtin_amdgcn_ballot_w64(!(ok0 && ok1)) == 0;   // wave-uniform: every sample of the 8 queries is inside
+        any_slow |= fast[it] ? 0u : 1u;
         acc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!fast[it]) {
-            // the lane-distributed kernel's gather for this octet group, from global memory
+    }
+
+    // ---- level by level: fill the window, then the level's four samples of every octet group ----
+    // Fill = LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction moves 8 lines (1 KB) into 8 consecutive window lines,
+    // every lane from its own source address; all requests of a level are in flight together.  CAPB > 0: two buffers (levels
+    // 0, 2 in the first, 1, 3 in the second), the next level's fill is requested before this level's samples are read.
+    // (the level is a compile-time constant of every call: as a run-time loop the compiler keeps `lev` in a register, indexes the
+    // windows' arrays in scratch and turns every literal owner of a broadcast into an eight-way branch)
+    auto fill = [&](auto LEVC, unsigned char* buf) {
+        constexpr int lev = decltype(LEVC)::value;
+        const int ww_ = wwd[lev], n_lines = ww_ * (wy1[lev] - wy0[lev] + 1);
+        const float inv_w = 1.f / (float)ww_;
+        for (int base = wave * 8; base < n_lines; base += 32) {
+            int line = base + g;
+            if (line > n_lines - 1) line = n_lines - 1;      // the tail of the last group re-reads the last line
+            int yy = (int)(((float)line + 0.5f) * inv_w);
+            int xx = line - yy * ww_;
+            if (xx < 0) { --yy; xx += ww_; }
+            if (xx >= ww_) { ++yy; xx -= ww_; }
+            const unsigned src = (lv[lev] + (unsigned)((wy0[lev] + yy) * Ws[lev] + wx0[lev] + xx)) * (unsigned)v_rs * 4u + head + mine;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(buf + (size_t)base * 128), 16,
+                                                     (int)src, 0, 0, 0);
+        }
+    };
+    auto bcast = [](float v, int owner) { return DPP ? group8_bcast_rt(v, owner) : group8_read(v, owner); };
+    auto level_samples = [&](auto LEVC, const unsigned char* buf) {
+        constexpr int lev = decltype(LEVC)::value;
+        const unsigned row_bytes = (unsigned)wwd[lev] * 128u;
+#pragma unroll
+        for (int pnt = 0; pnt < POINTS; ++pnt) {
+            const int i = lev * POINTS + pnt, o = i >> 1, t = i & 1;
+#pragma unroll
+            for (int half = 0; half < ITERS; half += NB) {    // NB octet groups at a time: their swizzles, then their reads, then the FMAs
+                // (wave-uniform, almost never taken -- and it keeps every batch a basic block of its own: as straight-line code
+                // the compiler computes the swizzles of ALL levels in front of the first barrier and spills 3.6 KB per lane)
+                bool any_fast = false;
+#pragma unroll
+                for (int u = 0; u < NB; ++u) any_fast = any_fast || fast[half + u];
+                if (!any_fast) continue;
+                unsigned word[NB];
+                float w1[NB], w2[NB], w3[NB], w4[NB], ww[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int it = half + u;
+                    // (opaque: a ds_swizzle is not a memory operation, and without this the compiler computes the swizzles of ALL
+                    // levels in front of the first barrier -- 1500 live values, 3.6 KB of scratch per lane)
+                    asm volatile("" : "+v"(pk[it][t]), "+v"(sw1[it][t]), "+v"(sw2[it][t]), "+v"(sw3[it][t]), "+v"(sw4[it][t]), "+v"(sww[it][t]));
+                    word[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk[it][t]), o));
+                    w1[u] = bcast(sw1[it][t], o);
+                    w2[u] = bcast(sw2[it][t], o);
+                    w3[u] = bcast(sw3[it][t], o);
+                    w4[u] = bcast(sw4[it][t], o);
+                    ww[u] = bcast(sww[it][t], o);
+                }
+                f32x4 v1[NB], v2[NB], v3[NB], v4[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const unsigned a1 = (word[u] & 0xFFFFFu) + mine;
+                    const unsigned dx = (word[u] >> 20) & 1u, dy = (word[u] >> 21) & 1u;
+                    unsigned a2 = a1 + dx * 128u, a3 = a1 + dy * row_bytes, a4 = a3 + dx * 128u;
+                    // opaque: otherwise the compiler branches around the reads whose address may equal another one's (dx = 0 or
+                    // dy = 0 at the map's edge) -- 600 branches in this kernel, exec-masked paths per lane group
+                    asm volatile("" : "+v"(a2), "+v"(a3), "+v"(a4));
+                    v1[u] = *reinterpret_cast<const f32x4*>(buf + a1);
+                    v2[u] = *reinterpret_cast<const f32x4*>(buf + a2);
+                    v3[u] = *reinterpret_cast<const f32x4*>(buf + a3);
+                    v4[u] = *reinterpret_cast<const f32x4*>(buf + a4);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const f32x4 val = w1[u] * v1[u] + w2[u] * v2[u] + w3[u] * v3[u] + w4[u] * v4[u];
+                    acc[half + u] += val * ww[u];
+                }
+                __builtin_amdgcn_sched_barrier(0);           // (keeps the scheduler from hoisting later batches' loads: spills)
+            }
+        }
+    };
+#define MSDA_LEVEL_SINGLE(L)                                                                                      \
+    {                                                                                                             \
+        __syncthreads(); /* the previous level's reads are done */                                                \
+        fill(std::integral_constant<int, L>{}, win);                                                              \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+        __syncthreads();                                                                                          \
+        level_samples(std::integral_constant<int, L>{}, win);                                                     \
+    }
+#define MSDA_LEVEL_DOUBLE(L)                                                                                      \
+    {                                                                                                             \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+        __syncthreads(); /* level L has landed for everybody; the other buffer is free */                         \
+        if constexpr (L + 1 < LEVELS) fill(std::integral_constant<int, (L + 1 < LEVELS ? L + 1 : L)>{}, ((L + 1) & 1) ? bufb : win); \
+        level_samples(std::integral_constant<int, L>{}, (L & 1) ? bufb : win);                                    \
+    }
+    if constexpr (CAPB == 0) {
+        MSDA_LEVEL_SINGLE(0) MSDA_LEVEL_SINGLE(1) MSDA_LEVEL_SINGLE(2) MSDA_LEVEL_SINGLE(3)
+    } else {
+        unsigned char* bufb = win + (size_t)CAP * 128;
+        // (level 0's fill was requested in front of the owner part: see there)
+        MSDA_LEVEL_DOUBLE(0) MSDA_LEVEL_DOUBLE(1) MSDA_LEVEL_DOUBLE(2) MSDA_LEVEL_DOUBLE(3)
+    }
+#undef MSDA_LEVEL_SINGLE
+#undef MSDA_LEVEL_DOUBLE
+    if (any_slow) {
+        // octet groups with a sample outside its window: the lane-distributed kernel's gather from global memory (rare: never on
+        // the bench workload); the window result of such a group is discarded
+#pragma unroll                                                // (static indices: a run-time `it` would put the arrays in scratch)
+        for (int it = 0; it < ITERS; ++it) {
+            if (fast[it]) continue;
+            const long q_global = qrow[it];
+            const f32x4 off4 = *reinterpret_cast<const f32x4*>(raw + (size_t)q_global * ld_raw + m * (LP * 2) + 4 * k);
+            const float* lp = raw + (size_t)q_global * ld_raw + HEADS * LP * 2 + m * LP + 2 * k;
+            const float lg0 = lp[0], lg1 = lp[1];
+            float mx = fmaxf(lg0, lg1);
+            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x1F | (1 << 10))));
+            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x1F | (2 << 10))));
+            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x1F | (4 << 10))));
+            const float e0 = expf(lg0 - mx), e1 = expf(lg1 - mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                sum += group8_read(e0, o);
+                sum += group8_read(e1, o);
+            }
+            const float inv_sum = 1.f / sum;
+            bool ok_;
+            unsigned sa1, sa2, sa3, sa4, sb1, sb2, sb3, sb4;
+            const float rx_ = ref[q_global * 2], ry_ = ref[q_global * 2 + 1];
+            MSDA_GEOMETRY(it, 0, off4, rx_, ry_, e0, inv_sum, ok_, sa)
+            MSDA_GEOMETRY(it, 1, off4, rx_, ry_, e1, inv_sum, ok_, sb)
+            (void)ok_;
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < LP; ++i) {
                 const int o = i >> 1, t = i & 1;
-                const unsigned a1 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so1[t]), o)) + mine;
-                const unsigned a2 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so2[t]), o)) + mine;
-                const unsigned a3 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so3[t]), o)) + mine;
-                const unsigned a4 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, so4[t]), o)) + mine;
+                const unsigned a1 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, t ? sb1 : sa1), o)) + mine;
+                const unsigned a2 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, t ? sb2 : sa2), o)) + mine;
+                const unsigned a3 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, t ? sb3 : sa3), o)) + mine;
+                const unsigned a4 = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, t ? sb4 : sa4), o)) + mine;
                 const f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a1, 0, 0));
                 const f32x4 v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a2, 0, 0));
                 const f32x4 v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a3, 0, 0));
@@ -502,52 +693,17 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
                 const float w1 = group8_read(sw1[it][t], o), w2 = group8_read(sw2[it][t], o), w3 = group8_read(sw3[it][t], o),
                             w4 = group8_read(sw4[it][t], o), ww = group8_read(sww[it][t], o);
                 const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-                acc[it] += val * ww;
+                r += val * ww;
             }
-        }
-    }
-
-    // ---- level by level: fill the window, then the level's four samples of every octet group ----
-#pragma unroll
-    for (int lev = 0; lev < LEVELS; ++lev) {
-        const int ww_ = wwd[lev], n_lines = ww_ * (wy1[lev] - wy0[lev] + 1);
-        __syncthreads();                                     // the previous level's reads are done
-        for (int base = wave * 8; base < n_lines; base += 32) {
-            const int line = base + g;
-            if (line < n_lines) {
-                const int yy = line / ww_, xx = line - yy * ww_;
-                const unsigned src = (lv[lev] + (unsigned)((wy0[lev] + yy) * Ws[lev] + wx0[lev] + xx)) * (unsigned)v_rs * 4u + head + mine;
-                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)src, 0, 0));
-                *reinterpret_cast<f32x4*>(win + (size_t)line * 128 + mine) = v;
-            }
-        }
-        __syncthreads();
-        const unsigned row_bytes = (unsigned)ww_ * 128u;
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            if (!fast[it]) continue;
-#pragma unroll
-            for (int pnt = 0; pnt < POINTS; ++pnt) {
-                const int i = lev * POINTS + pnt, o = i >> 1, t = i & 1;
-                const unsigned word = __builtin_bit_cast(unsigned, group8_read(__builtin_bit_cast(float, pk[it][t]), o));
-                const unsigned a1 = (word & 0xFFFFFu) + mine;
-                const unsigned dx = (word >> 20) & 1u, dy = (word >> 21) & 1u;
-                const unsigned a2 = a1 + dx * 128u, a3 = a1 + dy * row_bytes, a4 = a3 + dx * 128u;
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(win + a1);
-                const f32x4 v2 = *reinterpret_cast<const f32x4*>(win + a2);
-                const f32x4 v3 = *reinterpret_cast<const f32x4*>(win + a3);
-                const f32x4 v4 = *reinterpret_cast<const f32x4*>(win + a4);
-                const float w1 = group8_read(sw1[it][t], o), w2 = group8_read(sw2[it][t], o), w3 = group8_read(sw3[it][t], o),
-                            w4 = group8_read(sw4[it][t], o), ww = group8_read(sww[it][t], o);
-                const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-                acc[it] += val * ww;
-            }
+            acc[it] = r;
         }
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it)
         if (live[it]) *reinterpret_cast<f32x4*>(out + (size_t)qrow[it] * (HEADS * CH) + m * CH + k * 4) = acc[it];
 }
+
+#undef MSDA_GEOMETRY
 
 }  // namespace
 
@@ -582,7 +738,7 @@ static int g_msda_window = 1;
 /* [host] 1 (default): the encoder entry below serves the level-0 queries from LDS windows; 0: everything on the lane-distributed
  * kernel (A/B runs, tests).  Same bits either way. */
 extern "C" int gom_msda_set_window(int on) {
-    g_msda_window = on ? 1 : 0;
+    g_msda_window = on < 0 ? 0 : on;                         // 2: the double-buffered form (experiments)
     return GOM_OK;
 }
 
@@ -598,19 +754,35 @@ extern "C" int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, cons
     GOM_CHECK_ARG(value_row_stride >= HEADS * CH && (value_row_stride % 4) == 0 && (value_batch_stride % 4) == 0);
     GOM_CHECK_ARG(((uintptr_t)raw % 16) == 0 && ((uintptr_t)value % 16) == 0);
     GOM_CHECK_ARG(h0 > 0 && w0 > 0 && (long)h0 * w0 <= num_query);
-    constexpr int TY = 8, TX = 16, R = 5, CAP = 576;         // 72 KB of LDS: two workgroups per CU
+    constexpr int TY = 8, TX = 16, R = 5, CAP = 576, CAPB = 384;   // 72 KB: two workgroups per CU; + 48 KB second buffer: one
     const long n0 = (long)h0 * w0;
     const int tiles_y = cdiv(h0, TY), tiles_x = cdiv(w0, TX);
     const long wgs = (long)batch * tiles_y * tiles_x * 8;
     if (!(g_msda_window && g_msda_lanes && value_batch_stride > 0 && value_batch_stride < (1L << 29) && wgs < (1L << 31)))
         return gom_msda_fused_forward(raw, ld_raw, ref, value, value_batch_stride, value_row_stride, spatial_shapes,
                                       level_start_index, output, batch, num_query, stream);
-    auto kern = msda_window_kernel<TY, TX, R, CAP>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CAP * 128);
-    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), CAP * 128, (hipStream_t)stream, value, spatial_shapes,
-                       level_start_index, raw, ld_raw, ref, output, num_query, value_batch_stride, value_row_stride, tiles_y,
-                       tiles_x);
+    if (g_msda_window == 2) {                                // double-buffered windows, one workgroup per CU
+        auto kern = msda_window_kernel<TY, TX, R, CAP, CAPB, 4>;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (CAP + CAPB) * 128);
+        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), (CAP + CAPB) * 128, (hipStream_t)stream, value, spatial_shapes,
+                           level_start_index, raw, ld_raw, ref, output, num_query, value_batch_stride, value_row_stride, tiles_y,
+                           tiles_x);
+    } else if (g_msda_window == 3) {                         // experiments: broadcasts by DPP instead of ds_swizzle
+        auto kern = msda_window_kernel<TY, TX, R, CAP, 0, 4, true>;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CAP * 128);
+        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), CAP * 128, (hipStream_t)stream, value, spatial_shapes,
+                           level_start_index, raw, ld_raw, ref, output, num_query, value_batch_stride, value_row_stride, tiles_y,
+                           tiles_x);
+    } else {
+        auto kern = msda_window_kernel<TY, TX, R, CAP, 0, 4>;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CAP * 128);
+        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), CAP * 128, (hipStream_t)stream, value, spatial_shapes,
+                           level_start_index, raw, ld_raw, ref, output, num_query, value_batch_stride, value_row_stride, tiles_y,
+                           tiles_x);
+    }
     const long rest = num_query - n0;
     if (rest > 0)
         hipLaunchKernelGGL((msda_fused_lanes_kernel<false>), dim3((unsigned)cdiv((long)batch * rest, 4)), dim3(256), 0,

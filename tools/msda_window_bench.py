@@ -31,12 +31,12 @@ Lh = lib.load()
 
 
 def run(window):
-    Lh.gom_msda_set_window(1 if window else 0)
+    Lh.gom_msda_set_window(int(window))
     return ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, None, encoder_hw0=geo["hw0"])
 
 
-a, b = run(False), run(True)
-print("bit-identical:", bool(torch.equal(a, b)), "max |d| %.3e" % float((a - b).abs().max()))
+a, b, c, d = run(0), run(1), run(2), run(3)
+print("bit-identical:", bool(torch.equal(a, b)), bool(torch.equal(a, c)), bool(torch.equal(a, d)), "max |d| %.3e" % float((a - b).abs().max()))
 
 
 def burst(window, n=10):
@@ -50,6 +50,6 @@ def burst(window, n=10):
 
 
 for rnd in range(4):
-    print("round %d: lane-distributed kernel %.1f us | level-0 from LDS windows + coarser levels on the lane kernel %.1f us" % (
-        rnd, burst(False), burst(True)), flush=True)
+    print("round %d: lane-distributed kernel %.1f us | level-0 from LDS windows + coarser levels on the lane kernel: single buffer %.1f us, "
+          "double-buffered %.1f us, single buffer + DPP broadcasts %.1f us" % (rnd, burst(0), burst(1), burst(2), burst(3)), flush=True)
 Lh.gom_msda_set_window(1)
