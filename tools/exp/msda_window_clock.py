@@ -18,9 +18,9 @@ def build():
     def once(s, a, b):
         assert s.count(a) == 1, (a, s.count(a))
         return s.replace(a, b)
-    src = once(src, 'template <int TY, int TX, int R, int CAP, int CAPB, int NB>\n__global__',
+    src = once(src, 'template <int TY, int TX, int R, int CAP, int CAPB, int NB, bool DPP = false>\n__global__',
                '__device__ unsigned long long g_stamp[4096 * 16];\n#define NOW() __builtin_amdgcn_s_memtime()\n'
-               'template <int TY, int TX, int R, int CAP, int CAPB, int NB>\n__global__')
+               'template <int TY, int TX, int R, int CAP, int CAPB, int NB, bool DPP = false>\n__global__')
     src = once(src, '    extern __shared__ __attribute__((aligned(16))) unsigned char win[];          // CAP lines of 128 bytes\n',
                '    extern __shared__ __attribute__((aligned(16))) unsigned char win[];\n    const unsigned long long t_start = NOW();\n'
                '    unsigned long long t_geo = 0, t_owner = 0, t_issue = 0, t_wait = 0, t_comp = 0, t_bar0 = 0;\n')
