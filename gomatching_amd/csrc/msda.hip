@@ -734,6 +734,38 @@ extern "C" int gom_msda_fused_forward(const float* raw, int ld_raw, const float*
     return gom_launch_status();
 }
 
+// one side stream + fork / join events per device, created on first use (an eager call: never inside a stream capture)
+struct SideLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool tried = false;
+};
+static SideLane g_side[16];
+static int g_msda_overlap = 1;
+static SideLane* side_lane() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideLane& sl = g_side[dev];
+    if (!sl.tried) {
+        sl.tried = true;
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        (void)st;
+        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sl.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sl.join, hipEventDisableTiming) != hipSuccess) {
+            sl.stream = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    return sl.stream ? &sl : nullptr;
+}
+/* [host] 1 (default): the encoder entry runs its two kernels side by side (fork / join on a library-owned stream); 0: one after
+ * the other on the caller's stream.  Same bits. */
+extern "C" int gom_msda_set_overlap(int on) {
+    g_msda_overlap = on ? 1 : 0;
+    return GOM_OK;
+}
+
 static int g_msda_window = 1;
 /* [host] 1 (default): the encoder entry below serves the level-0 queries from LDS windows; 0: everything on the lane-distributed
  * kernel (A/B runs, tests).  Same bits either way. */
@@ -761,6 +793,14 @@ extern "C" int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, cons
     if (!(g_msda_window && g_msda_lanes && value_batch_stride > 0 && value_batch_stride < (1L << 29) && wgs < (1L << 31)))
         return gom_msda_fused_forward(raw, ld_raw, ref, value, value_batch_stride, value_row_stride, spatial_shapes,
                                       level_start_index, output, batch, num_query, stream);
+    // fork BEFORE the window kernel is queued: the side stream then depends on what precedes this call only (see below)
+    const long rest = num_query - n0;
+    hipStream_t s = (hipStream_t)stream, lane_stream = s;
+    SideLane* sl = (rest > 0 && g_msda_overlap) ? side_lane() : nullptr;
+    if (sl) {
+        if (hipEventRecord(sl->fork, s) == hipSuccess && hipStreamWaitEvent(sl->stream, sl->fork, 0) == hipSuccess) lane_stream = sl->stream;
+        else sl = nullptr;
+    }
     if (g_msda_window == 2) {                                // double-buffered windows, one workgroup per CU
         auto kern = msda_window_kernel<TY, TX, R, CAP, CAPB, 4>;
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (CAP + CAPB) * 128);
@@ -783,11 +823,21 @@ extern "C" int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, cons
                            level_start_index, raw, ld_raw, ref, output, num_query, value_batch_stride, value_row_stride, tiles_y,
                            tiles_x);
     }
-    const long rest = num_query - n0;
-    if (rest > 0)
-        hipLaunchKernelGGL((msda_fused_lanes_kernel<false>), dim3((unsigned)cdiv((long)batch * rest, 4)), dim3(256), 0,
-                           (hipStream_t)stream, value, spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch,
-                           num_query, value_batch_stride, value_row_stride, (const float*)nullptr, (int)n0, (int)rest);
+    if (rest > 0) {
+        // The coarser levels' queries run on the lane-distributed kernel -- on a SIDE stream, beside the window kernel: that one
+        // is bound by the vector ALU (2 waves per SIMD, 4 cycles per instruction) and leaves the texture-address path idle, this
+        // one is bound by the texture-address path and needs few registers and no LDS, so its waves fit beside the window
+        // kernel's two workgroups per CU.  The two kernels write disjoint rows.  Fork / join by events (legal under stream
+        // capture: the detector's hipGraph records both branches).
+        hipLaunchKernelGGL((msda_fused_lanes_kernel<false>), dim3((unsigned)cdiv((long)batch * rest, 4)), dim3(256), 0, lane_stream,
+                           value, spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
+                           value_batch_stride, value_row_stride, (const float*)nullptr, (int)n0, (int)rest);
+        if (sl) {
+            hipError_t e2 = hipEventRecord(sl->join, sl->stream);
+            if (e2 == hipSuccess) e2 = hipStreamWaitEvent(s, sl->join, 0);
+            if (e2 != hipSuccess) return GOM_ERR_HIP_BASE + (int)e2;
+        }
+    }
     return gom_launch_status();
 }
 

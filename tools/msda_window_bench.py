@@ -30,7 +30,8 @@ rv = ops.linear(src, L0["attn"]["raw_value"], R=geo["pos_w"][0], r_cols=384, r_p
 Lh = lib.load()
 
 
-def run(window):
+def run(window, overlap=1):
+    Lh.gom_msda_set_overlap(overlap)
     Lh.gom_msda_set_window(int(window))
     return ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, None, encoder_hw0=geo["hw0"])
 
@@ -39,11 +40,11 @@ a, b, c, d = run(0), run(1), run(2), run(3)
 print("bit-identical:", bool(torch.equal(a, b)), bool(torch.equal(a, c)), bool(torch.equal(a, d)), "max |d| %.3e" % float((a - b).abs().max()))
 
 
-def burst(window, n=10):
+def burst(window, n=10, overlap=1):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
-        run(window)
+        run(window, overlap)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
