@@ -679,9 +679,24 @@ def main():
         dec_p = [p_ for p_ in msda_prof if int(p_[4].split("x")[1]) == nqp]
         md = sum(p_[0].elapsed_time(p_[1]) for p_ in msda_prof)
         mb = sum(p_[3] for p_ in msda_prof)
+        T_ = cfg.MODEL.TRANSFORMER
+        win_on = bool(getattr(ops, "MSDA_WINDOW", False)) and args.gemm == "f16x3"
+        # HBM bytes per ENCODER call from the PMC passes: the window kernel's launch + the lane kernel's tail launch (by grid)
+        n_tok = int(enc_p[0][4].split("x")[1]) if enc_p else 0
+        hw0 = getattr(model.detection_transformer, "_geom", None)
+        n0 = 0
+        for geo_ in (hw0 or {}).values():
+            n0 = geo_["hw0"][0] * geo_["hw0"][1]
+        tail_grid = ((FRAMES_PER_GPU * (n_tok - n0) + 3) // 4) * 256
+        t_win, t_tail = pmc_traffic("msda_window_kernel"), pmc_traffic("msda_fused_lanes_kernel<false> [grid %d]" % tail_grid)
+        enc_traffic = (t_win + t_tail) if (win_on and t_win is not None and t_tail is not None) else None
         line["roofline_msda"] = {
-            "bound": "hbm", "kernel": "msda_fused_lanes_kernel<false>", "achieved": mb / (md * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
-            "frac": mb / (md * 1e-3) / 1e12 / 8.0, "traffic": pmc_traffic("msda_fused_lanes_kernel<false>"),
+            "bound": "hbm", "kernel": ("msda_window_kernel<8,16,5,576,0,4> + msda_fused_lanes_kernel<false> (an encoder call = the two "
+                                       "launches side by side; a decoder call = the lane kernel)") if win_on else "msda_fused_lanes_kernel<false>",
+            "achieved": mb / (md * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
+            "frac": mb / (md * 1e-3) / 1e12 / 8.0,
+            "traffic": enc_traffic if win_on else pmc_traffic("msda_fused_lanes_kernel<false>"),
+            "traffic_note": "HBM bytes of one ENCODER call (window kernel + the lane kernel's tail launch, rocprofv3 PMC passes)" if win_on else None,
             "launches_per_step": len(msda_prof) // PROFILE_STEPS, "avg_launch_us": md * 1e3 / len(msda_prof),
             "algorithmic_bytes_per_launch_avg": mb / len(msda_prof),
             "share_of_step_time": (md / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
@@ -692,10 +707,13 @@ def main():
                                      "%.0f MB map) 'the map once' is an upper bound of the distinct lines touched, not a minimum -- "
                                      "read this launch's fraction as <= the printed one"
                                      % (nqp, FRAMES_PER_GPU * nqp * 512 * 128 / 1e6, FRAMES_PER_GPU * 37171 * 1024 / 1e6)) if dec_p else None,
-            "note": "softmax + sampling locations + bilinear gather in one pass (csrc/msda.hip), 6 encoder + 6 decoder launches; "
-                    "algorithmic bytes = value once + raw offsets | logits + output (SURVEY.md 8-d).  Against HBM the fraction is "
-                    "low because the binding unit is the texture-address path: 512 distinct 128-byte corner lines per query, "
-                    "TA busy 0.965 (profiles/r03_msda_ta_counters.txt)"}
+            "note": "softmax + sampling locations + bilinear gather in one pass (csrc/msda.hip), 6 encoder + 6 decoder calls; "
+                    "algorithmic bytes = value once + raw offsets | logits + output (SURVEY.md 8-d); avg_launch_us = HIP-event time "
+                    "of a CALL.  Round 4: an encoder call serves its level-0 queries (75 %) from per-workgroup LDS windows of the "
+                    "value map (msda_window_kernel: ~10 lines fetched per (query, head) instead of 64 gathered; bound by the vector "
+                    "ALU, tools/exp/msda_window_clock.py) and runs the coarser levels' queries on the lane kernel beside it; the lane "
+                    "kernel alone is bound by the texture-address path (512 corner lines per query, TA busy 0.965, "
+                    "profiles/r03_msda_ta_counters.txt; no cheaper gather shape or layout: profiles/r04_msda_ta_counters.txt)"}
     if bn_prof:
         bd = sum(p_[0].elapsed_time(p_[1]) for p_ in bn_prof)
         bb, bf = sum(p_[3] for p_ in bn_prof), sum(p_[2] for p_ in bn_prof)

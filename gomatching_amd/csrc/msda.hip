@@ -741,7 +741,7 @@ struct SideLane {
     bool tried = false;
 };
 static SideLane g_side[16];
-static int g_msda_overlap = 1;
+static int g_msda_overlap = 0;                           // measured in the step: the fork / join costs the hipGraph more than the overlap buys
 static SideLane* side_lane() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -759,8 +759,9 @@ static SideLane* side_lane() {
     }
     return sl.stream ? &sl : nullptr;
 }
-/* [host] 1 (default): the encoder entry runs its two kernels side by side (fork / join on a library-owned stream); 0: one after
- * the other on the caller's stream.  Same bits. */
+/* [host] 1: the encoder entry runs its two kernels side by side (fork / join on a library-owned stream); 0 (default): one after
+ * the other on the caller's stream.  Same bits.  Alone the call gains 3 % from the overlap (801 vs 812 us); inside the detector's
+ * hipGraph the step LOST 2 % (263.1 vs 268.4 frames/s with the window kernel off, same box), without the fork it gains 1.9 %. */
 extern "C" int gom_msda_set_overlap(int on) {
     g_msda_overlap = on ? 1 : 0;
     return GOM_OK;

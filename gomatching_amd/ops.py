@@ -901,6 +901,8 @@ _msda_lanes_set = [None]
 
 
 MSDA_WINDOW = _switch("MSDA_WINDOW")   # encoder calls: level-0 queries served from LDS windows of the value map (same bits)
+MSDA_OVERLAP = _switch("MSDA_OVERLAP", default=False)   # ... and the coarser levels' launch on a forked side stream (A/B only)
+_msda_overlap_set = [None]
 
 
 def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq, valid_ratios=None, encoder_hw0=None):
@@ -931,6 +933,9 @@ def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq, valid_ratios
         _after()
         return out
     if encoder_hw0 is not None and MSDA_WINDOW and MSDA_LANES:
+        if _msda_overlap_set[0] != MSDA_OVERLAP:
+            _L().gom_msda_set_overlap(1 if MSDA_OVERLAP else 0)
+            _msda_overlap_set[0] = MSDA_OVERLAP
         check(_L().gom_msda_fused_forward_encoder(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride, value2d.stride(0),
                                                   _p(shapes), _p(lsi), _p(out), B, Lq, int(encoder_hw0[0]), int(encoder_hw0[1]),
                                                   _stream()), "gom_msda_fused_forward_encoder")

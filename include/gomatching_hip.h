@@ -92,7 +92,8 @@ int gom_msda_fused_forward(const float* raw, int ld_raw, const float* ref, const
  * level, one head per workgroup; samples that leave the window fall back to global memory), the coarser levels' by the kernel
  * of gom_msda_fused_forward.  Bit-identical to gom_msda_fused_forward.  gom_msda_set_window(0) = always the latter (A/B, tests). */
 int gom_msda_set_window(int on);
-int gom_msda_set_overlap(int on);   /* [host] 1 = the two kernels of the encoder entry side by side on a forked stream (default) */
+int gom_msda_set_overlap(int on);   /* [host] 1 = the two kernels of the encoder entry side by side on a forked stream (default 0:
+                                     * inside the detector's hipGraph the fork / join cost more than the overlap bought) */
 int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, const float* ref, const float* value, long value_batch_stride,
                                    int value_row_stride, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                    float* output, int batch, int num_query, int h0, int w0, void* stream);

@@ -19,6 +19,10 @@ def per_kernel(path, counter, api_grids):
             name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
             name = name.split("(")[0].replace(" ", "")
             agg[name].append(float(r["Counter_Value"]))
+            if name.startswith("msda_fused_lanes_kernel<"):  # encoder tail / decoder launches of the lane kernel apart, by grid size
+                agg[name + " [grid %d]" % int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+            if name.startswith("msda_window_kernel<"):
+                agg["msda_window_kernel"].append(float(r["Counter_Value"]))
             if name.startswith("bneck_kernel<"):             # every instantiation of the fused bottleneck kernel together as well
                 agg["bneck_kernel"].append(float(r["Counter_Value"]))
             if name.startswith("conv3x3_patch_kernel<"):
