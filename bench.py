@@ -284,6 +284,9 @@ def main():
                          "configs[3] (GoMatching_PP_DSText: 1920x1080 -> 1280x2276, 300 queries) / configs[4] (GoMatching_BOVText: voc "
                          "5462, mixed-resolution clip) as `value_dstext` / `value_bovtext`; all = both (the default run's N=1 line carries both)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the secondary configs[3] / configs[4] legs of the default run")
+    ap.add_argument("--detector-lanes", type=int, default=1, choices=[1, 2],
+                    help="2: consecutive steps' detector passes alternate between two streams (GoMatching.detector_lanes), so that a "
+                         "pass starts while the previous one still runs")
     ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU,
                     help="diagnostic: frames of the clip each rank owns per step (BASELINE.json: 8; the self-launch test compares "
                          "N=2 x 8 with N=1 x 16, the same 16-frame clip)")
@@ -347,6 +350,7 @@ def main():
         model, sd = build_model(cfg, device)
         if args.h2d:
             model.h2d_mode = args.h2d
+        model.detector_lanes = args.detector_lanes
         cus = args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world >= 8 else 0)
         if cus > 0 and device.type == "cuda":
             try:
@@ -555,7 +559,7 @@ def main():
                    "tracker_alone_ms_per_step": tracker_alone_ms,
                    "tracker_cus": args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world >= 8 else 0),
                    "pipelining": "upload(step i+1) and detector(step i+1) overlap tracker(step i)",
-                   "detector_hipgraph": graphed,
+                   "detector_hipgraph": graphed, "detector_lanes": args.detector_lanes,
                    "parallelism": "frame-sharded dp%d + 1 all-gather/step"
                    % world if world > 1 else "single GPU",
                    "detect_frac": args.detect_frac,

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __re
 //   * workgroup id = tile * 8 + head: workgroups go round-robin to the 8 XCDs, so XCD m sees exactly head m's lines (1/8 of the
 //     value map per L2) and consecutive tiles, which share their halos, meet in the same L2.
 // Queries of the coarser levels (25 % of the tokens) keep the lane-distributed kernel (q_begin / q_count above).
-template <int TY, int TX, int R, int CAP, int CAPB, int NB, bool DPP = false>
+template <int TY, int TX, int R, int CAP, int CAPB, int NB, bool DPP = false, bool ADDR4 = false>
 __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const float* __restrict__ value,
                                                              const int64_t* __restrict__ shapes,
                                                              const int64_t* __restrict__ lsi,
@@ -468,6 +468,7 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
     // groups' loads, swizzles and LDS reads -- a wave has at most one partner on its SIMD to hide latency behind)
     float sw1[ITERS][2], sw2[ITERS][2], sw3[ITERS][2], sw4[ITERS][2], sww[ITERS][2];
     unsigned pk[ITERS][2];                                   // LDS byte address of corner (yc0, xc0) | dx << 20 | dy << 21
+    unsigned pk2[ITERS][2], pk3[ITERS][2], pk4[ITERS][2];    // ADDR4: the other three corners' addresses, computed at the owner
     f32x4 acc[ITERS];
     long qrow[ITERS];
     bool fast[ITERS], live[ITERS];
@@ -522,8 +523,16 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
         OK = !inside || (yc0 >= my0 && yc1 <= my1 && xc0 >= mx0 && xc1 <= mx1);                                   \
         const bool use = inside && OK; /* (an address inside the buffer in every case) */                         \
         const int ly0 = use ? yc0 - my0 : 0, lx0 = use ? xc0 - mx0 : 0;                                           \
-        pk[IT][T] = (unsigned)((ly0 * mww + lx0) * 128) | ((use && xc1 != xc0) ? (1u << 20) : 0u) |               \
-                    ((use && yc1 != yc0) ? (1u << 21) : 0u);                                                      \
+        const unsigned la_ = (unsigned)((ly0 * mww + lx0) * 128);                                                 \
+        if constexpr (ADDR4) {                                                                                    \
+            const unsigned ldx_ = (use && xc1 != xc0) ? 128u : 0u, ldy_ = (use && yc1 != yc0) ? (unsigned)mww * 128u : 0u; \
+            pk[IT][T] = la_;                                                                                      \
+            pk2[IT][T] = la_ + ldx_;                                                                              \
+            pk3[IT][T] = la_ + ldy_;                                                                              \
+            pk4[IT][T] = la_ + ldy_ + ldx_;                                                                       \
+        } else {                                                                                                  \
+            pk[IT][T] = la_ | ((use && xc1 != xc0) ? (1u << 20) : 0u) | ((use && yc1 != yc0) ? (1u << 21) : 0u);  \
+        }                                                                                                         \
     }
     unsigned any_slow = 0;
 #pragma unroll
@@ -588,7 +597,7 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
 #pragma unroll
                 for (int u = 0; u < NB; ++u) any_fast = any_fast || fast[half + u];
                 if (!any_fast) continue;
-                unsigned word[NB];
+                unsigned word[NB], wa2[NB], wa3[NB], wa4[NB];
                 float w1[NB], w2[NB], w3[NB], w4[NB], ww[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
@@ -596,7 +605,13 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
                     // (opaque: a ds_swizzle is not a memory operation, and without this the compiler computes the swizzles of ALL
                     // levels in front of the first barrier -- 1500 live values, 3.6 KB of scratch per lane)
                     asm volatile("" : "+v"(pk[it][t]), "+v"(sw1[it][t]), "+v"(sw2[it][t]), "+v"(sw3[it][t]), "+v"(sw4[it][t]), "+v"(sww[it][t]));
+                    if constexpr (ADDR4) asm volatile("" : "+v"(pk2[it][t]), "+v"(pk3[it][t]), "+v"(pk4[it][t]));
                     word[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk[it][t]), o));
+                    if constexpr (ADDR4) {
+                        wa2[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk2[it][t]), o));
+                        wa3[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk3[it][t]), o));
+                        wa4[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk4[it][t]), o));
+                    }
                     w1[u] = bcast(sw1[it][t], o);
                     w2[u] = bcast(sw2[it][t], o);
                     w3[u] = bcast(sw3[it][t], o);
@@ -606,9 +621,14 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
                 f32x4 v1[NB], v2[NB], v3[NB], v4[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const unsigned a1 = (word[u] & 0xFFFFFu) + mine;
-                    const unsigned dx = (word[u] >> 20) & 1u, dy = (word[u] >> 21) & 1u;
-                    unsigned a2 = a1 + dx * 128u, a3 = a1 + dy * row_bytes, a4 = a3 + dx * 128u;
+                    unsigned a1, a2, a3, a4;
+                    if constexpr (ADDR4) {
+                        a1 = word[u] + mine; a2 = wa2[u] + mine; a3 = wa3[u] + mine; a4 = wa4[u] + mine;
+                    } else {
+                        a1 = (word[u] & 0xFFFFFu) + mine;
+                        const unsigned dx = (word[u] >> 20) & 1u, dy = (word[u] >> 21) & 1u;
+                        a2 = a1 + dx * 128u; a3 = a1 + dy * row_bytes; a4 = a3 + dx * 128u;
+                    }
                     // opaque: otherwise the compiler branches around the reads whose address may equal another one's (dx = 0 or
                     // dy = 0 at the map's edge) -- 600 branches in this kernel, exec-masked paths per lane group
                     asm volatile("" : "+v"(a2), "+v"(a3), "+v"(a4));
@@ -809,8 +829,8 @@ extern "C" int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, cons
         hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), (CAP + CAPB) * 128, (hipStream_t)stream, value, spatial_shapes,
                            level_start_index, raw, ld_raw, ref, output, num_query, value_batch_stride, value_row_stride, tiles_y,
                            tiles_x);
-    } else if (g_msda_window == 3) {                         // experiments: broadcasts by DPP instead of ds_swizzle
-        auto kern = msda_window_kernel<TY, TX, R, CAP, 0, 4, true>;
+    } else if (g_msda_window == 3) {                         // experiments: the four corner addresses computed at the owner
+        auto kern = msda_window_kernel<TY, TX, R, CAP, 0, 4, false, true>;
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CAP * 128);
         if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
         hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), CAP * 128, (hipStream_t)stream, value, spatial_shapes,

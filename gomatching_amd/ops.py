@@ -126,8 +126,13 @@ def _dev_index(device):
     return d.index if d.index is not None else torch.cuda.current_device()
 
 
+_flag_override = None                # a detector lane's own flag word while that lane's kernels are queued (GoMatching.detector_lanes)
+
+
 def range_flag(device):
     """Device word the f16x3 kernels set when a result is not finite (an activation beyond fp16's range)."""
+    if _flag_override is not None:
+        return _flag_override
     key = _dev_index(device)
     if key not in _range_flags:
         _range_flags[key] = torch.zeros((1,), dtype=torch.int32, device=torch.device("cuda", key))
