@@ -402,7 +402,7 @@ def test_msda_encoder_window_kernel_is_bit_identical(shapes, B, scale):
     try:
         L.gom_msda_set_window(0)
         plain = ops.msda_fused(raw, ref, wide[:, 384:], S * 640, ss.to(DEV), lsi.to(DEV), B, S, encoder_hw0=shapes[0])
-        for mode in (1, 2, 3):                                        # single window buffer | double-buffered | batches of two
+        for mode in (1, 2, 3):                                        # single window buffer | double-buffered | owner-computed corner addresses
             L.gom_msda_set_window(mode)
             win = ops.msda_fused(raw, ref, wide[:, 384:], S * 640, ss.to(DEV), lsi.to(DEV), B, S, encoder_hw0=shapes[0])
             assert torch.equal(win, plain), (mode, float((win - plain).abs().max()))
