@@ -133,6 +133,19 @@ def test_rejects_bad_windows():
         assert rc != 0
         assert L.gom_tracker_run(None, 2, p(n), p(boxes), p(rows), p(ids), 0, 0, None, p(s_off), None, 1024, 1.0, 1.0, None,
                                  ctypes.byref(idc), None, None) != 0
+        # the per-frame-size entry (mixed-resolution clips): the sizes are mandatory, the window checks are the same
+        wh = np.asarray([[128, 96], [96, 128]], np.float32)
+        assert L.gom_tracker_run_wh(h, 2, p(n), p(boxes), p(rows), p(ids), 0, 0, None, p(s_off), None, 1024, None, None,
+                                    ctypes.byref(idc), None, None) != 0
+        assert L.gom_tracker_run_wh(h, 2, p(n), p(boxes), p(rows), p(ids), 0, 0, None, p(s_off), None, 1024, p(wh), None,
+                                    ctypes.byref(idc), None, None) != 0
+        # frame 0 alone needs neither scores nor a device: ids 1..n, id_count = n + 1
+        n1 = np.asarray([3], np.int32)
+        ids1 = np.full((3,), -1, np.int64)
+        s1 = np.full((1,), -1, np.int64)
+        assert L.gom_tracker_run_wh(h, 1, p(n1), p(boxes), p(rows), p(ids1), 0, 0, None, p(s1), None, 1024, p(wh), None,
+                                    ctypes.byref(idc), None, None) == 0
+        assert ids1.tolist() == [1, 2, 3] and idc.value == 4
     finally:
         L.gom_tracker_destroy(h)
 
