@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __re
 //   * workgroup id = tile * 8 + head: workgroups go round-robin to the 8 XCDs, so XCD m sees exactly head m's lines (1/8 of the
 //     value map per L2) and consecutive tiles, which share their halos, meet in the same L2.
 // Queries of the coarser levels (25 % of the tokens) keep the lane-distributed kernel (q_begin / q_count above).
-template <int TY, int TX, int R, int CAP, int CAPB, int NB, bool DPP = false, bool ADDR4 = false>
+template <int TY, int TX, int R, int CAP, int CAPB, int NB, bool DPP = false, int ADDR = 0>
 __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const float* __restrict__ value,
                                                              const int64_t* __restrict__ shapes,
                                                              const int64_t* __restrict__ lsi,
@@ -524,12 +524,16 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
         const bool use = inside && OK; /* (an address inside the buffer in every case) */                         \
         const int ly0 = use ? yc0 - my0 : 0, lx0 = use ? xc0 - mx0 : 0;                                           \
         const unsigned la_ = (unsigned)((ly0 * mww + lx0) * 128);                                                 \
-        if constexpr (ADDR4) {                                                                                    \
+        if constexpr (ADDR == 4) {                                                                                \
             const unsigned ldx_ = (use && xc1 != xc0) ? 128u : 0u, ldy_ = (use && yc1 != yc0) ? (unsigned)mww * 128u : 0u; \
             pk[IT][T] = la_;                                                                                      \
             pk2[IT][T] = la_ + ldx_;                                                                              \
             pk3[IT][T] = la_ + ldy_;                                                                              \
             pk4[IT][T] = la_ + ldy_ + ldx_;                                                                       \
+        } else if constexpr (ADDR == 2) {                                                                         \
+            /* two words: corner (yc0, xc0) with the x step in bit 27 (-> 128 after a shift by 20), and corner (yc1, xc0) */ \
+            pk[IT][T] = la_ | ((use && xc1 != xc0) ? (1u << 27) : 0u);                                            \
+            pk3[IT][T] = la_ + ((use && yc1 != yc0) ? (unsigned)mww * 128u : 0u);                                 \
         } else {                                                                                                  \
             pk[IT][T] = la_ | ((use && xc1 != xc0) ? (1u << 20) : 0u) | ((use && yc1 != yc0) ? (1u << 21) : 0u);  \
         }                                                                                                         \
@@ -605,13 +609,15 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
                     // (opaque: a ds_swizzle is not a memory operation, and without this the compiler computes the swizzles of ALL
                     // levels in front of the first barrier -- 1500 live values, 3.6 KB of scratch per lane)
                     asm volatile("" : "+v"(pk[it][t]), "+v"(sw1[it][t]), "+v"(sw2[it][t]), "+v"(sw3[it][t]), "+v"(sw4[it][t]), "+v"(sww[it][t]));
-                    if constexpr (ADDR4) asm volatile("" : "+v"(pk2[it][t]), "+v"(pk3[it][t]), "+v"(pk4[it][t]));
+                    if constexpr (ADDR == 4) asm volatile("" : "+v"(pk2[it][t]), "+v"(pk3[it][t]), "+v"(pk4[it][t]));
+                    if constexpr (ADDR == 2) asm volatile("" : "+v"(pk3[it][t]));
                     word[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk[it][t]), o));
-                    if constexpr (ADDR4) {
+                    if constexpr (ADDR == 4) {
                         wa2[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk2[it][t]), o));
                         wa3[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk3[it][t]), o));
                         wa4[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk4[it][t]), o));
                     }
+                    if constexpr (ADDR == 2) wa3[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk3[it][t]), o));
                     w1[u] = bcast(sw1[it][t], o);
                     w2[u] = bcast(sw2[it][t], o);
                     w3[u] = bcast(sw3[it][t], o);
@@ -622,8 +628,17 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     unsigned a1, a2, a3, a4;
-                    if constexpr (ADDR4) {
+                    if constexpr (ADDR == 4) {
                         a1 = word[u] + mine; a2 = wa2[u] + mine; a3 = wa3[u] + mine; a4 = wa4[u] + mine;
+                    } else if constexpr (ADDR == 2) {
+                        // VALU and the LDS pipe are both near their limit in this phase (per (group, sample): 38 vector
+                        // instructions x 4 cycles x 2 waves per SIMD against 6 swizzles + 4 reads = 28 LDS cycles x 8 waves):
+                        // one more broadcast (the second row's corner) buys seven fewer address instructions
+                        const unsigned dxb = (word[u] >> 20) & 0x80u;
+                        a1 = (word[u] & 0xFFFFFu) + mine;
+                        a2 = a1 + dxb;
+                        a3 = wa3[u] + mine;
+                        a4 = a3 + dxb;
                     } else {
                         a1 = (word[u] & 0xFFFFFu) + mine;
                         const unsigned dx = (word[u] >> 20) & 1u, dy = (word[u] >> 21) & 1u;
@@ -829,8 +844,8 @@ extern "C" int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, cons
         hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), (CAP + CAPB) * 128, (hipStream_t)stream, value, spatial_shapes,
                            level_start_index, raw, ld_raw, ref, output, num_query, value_batch_stride, value_row_stride, tiles_y,
                            tiles_x);
-    } else if (g_msda_window == 3) {                         // experiments: the four corner addresses computed at the owner
-        auto kern = msda_window_kernel<TY, TX, R, CAP, 0, 4, false, true>;
+    } else if (g_msda_window == 3) {                         // experiments: two corner addresses computed at the owner
+        auto kern = msda_window_kernel<TY, TX, R, CAP, 0, 4, false, 2>;
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CAP * 128);
         if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
         hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), CAP * 128, (hipStream_t)stream, value, spatial_shapes,

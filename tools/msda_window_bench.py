@@ -52,5 +52,5 @@ def burst(window, n=10, overlap=1):
 
 for rnd in range(4):
     print("round %d: lane-distributed kernel %.1f us | level-0 from LDS windows + coarser levels on the lane kernel: single buffer %.1f us, "
-          "double-buffered %.1f us, single buffer, corner addresses computed at the owner %.1f us" % (rnd, burst(0), burst(1), burst(2), burst(3)), flush=True)
+          "double-buffered %.1f us, single buffer, TWO corner addresses computed at the owner %.1f us" % (rnd, burst(0), burst(1), burst(2), burst(3)), flush=True)
 Lh.gom_msda_set_window(1)
