@@ -65,6 +65,7 @@ struct FfnArgs {
     int* flag;
     float eps;
     int ldx, ldy, M, chunks, stagger;
+    long row_base;                                           // first row of this launch's tiles (the half-height tail launch)
     int relu_out;                                            // PLAIN form: ReLU behind the second layer
 };
 
@@ -109,13 +110,19 @@ __device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned
 // pipeline: the decoder's ref_point_head (deformable_transformer.py:470-473, adet/modeling/model/utils.py MLP) and the first two
 // layers of its three-layer coordinate / boundary heads (:484-488, detection_transformer_wobackbone.py:238-253) at
 // M = frames x queries x points rows, where two launches of the row-resident GEMM cost two workgroup latencies.
-template <bool PLAIN>
+// RG = row groups of 16 per wave: 2 = the 128-row tile; 1 = a HALF-HEIGHT tile of 64 rows for the last, partly filled round of
+// a long launch (2 324 tiles on 256 CUs = 9.08 rounds: the 20 tiles of the tenth round cost a whole round).  A tile's time is
+// its MFMAs or its weight stream's issue, whichever is longer; half the rows halve the first, so 39 half-height tiles end the
+// launch ~half a round earlier.  Rows are independent and every row's arithmetic is the same: the same bits.
+template <bool PLAIN, int RG = 2>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fn = lane & 15, fg = lane >> 4;                // row inside a row group | k-group of an operand = feature quad of a result
-    const long row0 = (long)blockIdx.x * BM + wave * 32;
+    constexpr int WR = 16 * RG, BMT = 4 * WR;                // rows per wave, rows per tile
+    const long tile0 = p.row_base + (long)blockIdx.x * BMT;
+    const long row0 = tile0 + wave * WR;
 
     // Long launches (>= 4 rounds of workgroups): the first round starts STAGGERED, by up to 7 x stagger sleeps of ~0.4 us over
     // the CUs of an XCD.  With one workgroup per CU and equal durations every CU otherwise reaches its prologue, its weight
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     {
         float xmax = 0.f;
         auto xrow = [&](int r) {
-            long m = row0 + r;
+            long m = row0 + (RG == 2 ? r : (r & 15));          // (half-height: the unused second row group repeats the first)
             if (m > p.M - 1) m = p.M - 1;                     // tail rows recompute the last row (never stored)
             return p.X + (size_t)m * p.ldx;
         };
@@ -149,11 +156,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         range_bad = !(xmax <= 65504.f);
     }
 
-    f32x4 acc2[D / 16][2];                                   // [output group of 16][row group]
+    f32x4 acc2[D / 16][RG];                                  // [output group of 16][row group]
 #pragma unroll
     for (int t = 0; t < D / 16; ++t)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) acc2[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < RG; ++r) acc2[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -201,22 +208,22 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
         // ---- H^T chunk = W1c . X^T : 2 hidden groups x 2 row groups of 16 x 16, 8 k-steps x 3 plane products (smallest first);
         //      fragment 4 i + 2 Hh + p of a group = plane p of hidden group Hh at the group's k-step i ----
-        f32x4 acc1[2][2];
+        f32x4 acc1[2][RG];
 #pragma unroll
         for (int h_ = 0; h_ < 2; ++h_)
 #pragma unroll
-            for (int r_ = 0; r_ < 2; ++r_) acc1[h_][r_] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r_ = 0; r_ < RG; ++r_) acc1[h_][r_] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define FFN_GEMM1(src, g)                                                                                     \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                        \
         const int s_ = (g) * 2 + i_;                                                                          \
         _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                      \
-            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                                  \
+            _Pragma("unroll") for (int r_ = 0; r_ < RG; ++r_)                                                 \
                 acc1[h_][r_] = mfma16(src[4 * i_ + 2 * h_ + 1], xf[0][8 * r_ + s_], acc1[h_][r_]);            \
         _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                      \
-            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                                  \
+            _Pragma("unroll") for (int r_ = 0; r_ < RG; ++r_)                                                 \
                 acc1[h_][r_] = mfma16(src[4 * i_ + 2 * h_], xf[1][8 * r_ + s_], acc1[h_][r_]);                \
         _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                      \
-            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                                  \
+            _Pragma("unroll") for (int r_ = 0; r_ < RG; ++r_)                                                 \
                 acc1[h_][r_] = mfma16(src[4 * i_ + 2 * h_], xf[0][8 * r_ + s_], acc1[h_][r_]);                \
     }
         FFN_LOAD(fa, 0)
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         // ---- relu(acc / row scale + bias), split into two fp16 planes: the lane's 2 x 4 values of a row group are its eight
         //      k-slots of the second product's B fragment ----
         const float* aux = reinterpret_cast<const float*>(smem + st * STAGE_BYTES + (W1_FRAGS + W2_FRAGS) * FRAG);
-        half8 hf[2][2];                                          // [plane][row group]
+        half8 hf[2][RG];                                         // [plane][row group]
         {
             f32x4 sc[2], bi[2];
 #pragma unroll
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
                 bi[h_] = *reinterpret_cast<const f32x4*>(aux + CH + 16 * h_ + 4 * fg);
             }
 #pragma unroll
-            for (int r_ = 0; r_ < 2; ++r_) {
+            for (int r_ = 0; r_ < RG; ++r_) {
                 f32x4 v[2];
 #pragma unroll
                 for (int h_ = 0; h_ < 2; ++h_)
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
 #define FFN_GEMM2(src, g)                                                                                     \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
         const int t_ = (g) * 4 + i_;                                                                          \
-        _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                                    \
+        _Pragma("unroll") for (int r_ = 0; r_ < RG; ++r_) {                                                   \
             acc2[t_][r_] = mfma16(src[2 * i_ + 1], hf[0][r_], acc2[t_][r_]);                                  \
             acc2[t_][r_] = mfma16(src[2 * i_], hf[1][r_], acc2[t_][r_]);                                      \
             acc2[t_][r_] = mfma16(src[2 * i_], hf[0][r_], acc2[t_][r_]);                                      \
@@ -281,8 +288,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     // ---- epilogue: Y^T (row of X on the lane, output feature in the registers) -> row-major through LDS ----
     float* stg = reinterpret_cast<float*>(smem);             // [128][256] fp32; 16-byte chunk c of row r at chunk c ^ (r & 7)
 #pragma unroll
-    for (int r_ = 0; r_ < 2; ++r_) {
-        const int lr = wave * 32 + 16 * r_ + fn;
+    for (int r_ = 0; r_ < RG; ++r_) {
+        const int lr = wave * WR + 16 * r_ + fn;
         float* mine = stg + lr * D;
 #pragma unroll
         for (int t = 0; t < D / 16; ++t) {
@@ -294,10 +301,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     // the accumulators' registers: one HBM / L2 latency, under the barrier and the first staged reads, instead of one in front
     // of every pair of row groups.
     const int sub = lane & 15, rsel = lane >> 4;
-    f32x4 xres[8][4];
+    f32x4 xres[4 * RG][4];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const long m = (long)blockIdx.x * BM + wave * 32 + 4 * g + rsel;
+    for (int g = 0; g < 4 * RG; ++g) {
+        const long m = tile0 + wave * WR + 4 * g + rsel;
         const long mc = m < p.M ? m : p.M - 1;                  // tail rows recompute the last row, never stored
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -324,11 +331,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     int bad = range_bad;
     // Four row groups at a time: their sixteen staged chunks are read in one batch (one LDS latency, not sixteen).
 #pragma unroll
-    for (int gh = 0; gh < 2; ++gh) {
+    for (int gh = 0; gh < RG; ++gh) {
         f32x4 v[4][4];
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
-            const int lr = wave * 32 + 4 * (4 * gh + gi) + rsel;   // row inside the workgroup's tile
+            const int lr = wave * WR + 4 * (4 * gh + gi) + rsel;   // row inside the workgroup's tile
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int ch = sub + 16 * k;
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
             const int g = 4 * gh + gi;
-            const long m = (long)blockIdx.x * BM + wave * 32 + 4 * g + rsel;
+            const long m = tile0 + wave * WR + 4 * g + rsel;
             if constexpr (PLAIN) {
                 const float lo = p.relu_out ? 0.f : -INFINITY;
 #pragma unroll
@@ -409,6 +416,13 @@ __global__ __launch_bounds__(256) void ffn_image_kernel(const unsigned short* __
 
 }  // namespace
 
+static int g_ffn_half_tail = 1, g_ffn_cus = -1;
+/* [host] 1 (default): the partly filled last round of a long launch runs as half-height tiles; 0: one launch of 128-row tiles. */
+extern "C" int gom_ffn_set_half_tail(int on) {
+    g_ffn_half_tail = on ? 1 : 0;
+    return GOM_OK;
+}
+
 extern "C" long gom_ffn_fused_image_bytes(int d_model, int d_hidden) {
     if (d_model != D || d_hidden <= 0 || (d_hidden % CH) != 0) return -1;
     return (long)(d_hidden / CH) * STAGE_BYTES;
@@ -438,11 +452,32 @@ extern "C" int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, 
     FfnArgs a{};
     a.X = X; a.img = (const unsigned char*)image; a.s2 = w2_inv_scale; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = Y;
     a.flag = flag; a.eps = eps; a.ldx = ldx; a.ldy = ldy; a.M = M; a.chunks = d_hidden / CH;
-    a.stagger = cdiv(M, BM) >= 1024 ? 8 : 0;                 // >= 4 rounds of workgroups
+    const int tiles = cdiv(M, BM);
+    a.stagger = tiles >= 1024 ? 8 : 0;                       // >= 4 rounds of workgroups
     // (the attribute is per DEVICE: set on every launch -- a process-wide flag would miss a second GPU; it costs ~1 us)
     hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)ffn_fused_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-    hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    // long launches whose last round of one-per-CU tiles is less than half full: that round as half-height tiles (same bits)
+    int cus = g_ffn_cus;
+    if (cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        g_ffn_cus = cus;
+    }
+    const int rem = tiles % cus;
+    if (g_ffn_half_tail && tiles >= 4 * cus && rem > 0 && 2 * rem <= cus) {
+        const int full = tiles - rem;
+        hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3((unsigned)full), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+        a.row_base = (long)full * BM;
+        a.stagger = 0;
+        hipLaunchKernelGGL((ffn_fused_kernel<false, 1>), dim3((unsigned)cdiv(M - a.row_base, BM / 2)), dim3(256), LDS_BYTES,
+                           (hipStream_t)stream, a);
+        return gom_launch_status();
+    }
+    hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3((unsigned)tiles), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return gom_launch_status();
 }
 

@@ -48,6 +48,31 @@ def test_fused_ffn_vs_fp64(M, F):
     assert float((y - z).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("M", [128 * (1024 + 20) - 50, 128 * 1024 + 1, 128 * (1024 + 128), 128 * (1024 + 129) - 7])
+def test_fused_ffn_half_height_tail_is_bit_identical(M):
+    """Long launches whose last round of one-per-CU tiles is less than half full run that round as half-height (64-row) tiles
+    (csrc/ffn_fused.hip, RG = 1): the same bits as the single launch of 128-row tiles, ragged tails included; a last round that
+    is more than half full stays one launch."""
+    from gomatching_amd import lib, ops
+    t = _case(1, 128, seed=3)
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn((M, 256), generator=g).to(DEV)
+    _, w1, b1, w2, b2, ga, be = [v.to(DEV) for v in t]
+    ffn = ops.FusedFFN(w1, b1, w2, b2, ga, be)
+    L = lib.load()
+    try:
+        L.gom_ffn_set_half_tail(0)
+        one = ops.ffn_fused_ln(x, ffn)
+        L.gom_ffn_set_half_tail(1)
+        two = ops.ffn_fused_ln(x, ffn)
+    finally:
+        L.gom_ffn_set_half_tail(1)
+    assert torch.equal(one, two)
+    ref = _ref(x[-300:].cpu(), *[v.cpu() for v in (w1, b1, w2, b2, ga, be)])
+    assert float((two[-300:].cpu().double() - ref).abs().max()) <= 2e-5
+    ops.check_range_flag(DEV)
+
+
 def test_fused_ffn_wide_range_weights_and_strided_rows():
     """Row scales spanning 1e-4..1e2 (trained-like dynamic range), rows of a wider buffer, output in place."""
     from gomatching_amd import ops
