@@ -64,6 +64,16 @@ def pmc_traffic(kernel):
         return None
 
 
+def ffn_traffic(calls):
+    """HBM bytes per fused-FFN CALL from the PMC passes: the 128-row-tile launch + (long launches only) its half-height tail launch,
+    weighted by how many of the step's calls have one."""
+    main = pmc_traffic("ffn_fused_kernel<false,2>")
+    tail = pmc_traffic("ffn_fused_kernel<false,1>")
+    if main is None:
+        return None
+    return main + (0.5 * tail if tail is not None else 0.0)  # six encoder calls with a tail launch, six decoder calls without
+
+
 def build_model(cfg, device):
     from gomatching_amd.modeling import GoMatching
     from gomatching_amd.weights import synth_state_dict
@@ -620,11 +630,12 @@ def main():
         ff = sum(p_[2] for p_ in ffn_prof)
         line["roofline_fused_ffn"] = {
             "bound": "mfma", "kernel": "ffn_fused_kernel", "achieved": ff / (fd * 1e-3) / 1e12, "peak": PEAKS["f16x3"][1],
-            "unit": "TFLOP/s", "frac": ff / (fd * 1e-3) / 1e12 / PEAKS["f16x3"][1], "traffic": pmc_traffic("ffn_fused_kernel<false>") or pmc_traffic("ffn_fused_kernel"),
+            "unit": "TFLOP/s", "frac": ff / (fd * 1e-3) / 1e12 / PEAKS["f16x3"][1], "traffic": ffn_traffic(len(ffn_prof)),
             "launches_per_step": len(ffn_prof) // PROFILE_STEPS, "avg_launch_us": fd * 1e3 / len(ffn_prof),
             "share_of_step_time": (fd / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
-            "note": "linear1 + ReLU + linear2 + residual + LayerNorm of every encoder / decoder layer in one launch: 2 KB of HBM "
-                    "traffic per token instead of 13 (csrc/ffn_fused.hip)"}
+            "note": "linear1 + ReLU + linear2 + residual + LayerNorm of every encoder / decoder layer in one call: 2 KB of HBM "
+                    "traffic per token instead of 13 (csrc/ffn_fused.hip).  avg_launch_us = HIP-event time of a CALL; an encoder call "
+                    "is two launches (2 304 tiles of 128 rows, then the last round as 39 half-height tiles: ffn_fused_kernel<false, 1>)"}
         both_ms, both_fl = dur_ms + fd, flops + ff
         k256_long = [p_ for p_ in k256_prof if int(p_[4].split(":")[1].split("x")[0]) > 65536]   # encoder-sized launches
         k256_prof = [p_ for p_ in k256_prof if p_ not in k256_long]
