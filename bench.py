@@ -707,7 +707,7 @@ def main():
         enc_traffic = (t_win + t_tail) if (win_on and t_win is not None and t_tail is not None) else None
         line["roofline_msda"] = {
             "bound": "hbm", "kernel": ("msda_window_kernel<8,16,5,576,0,4> + msda_fused_lanes_kernel<false> (an encoder call = the two "
-                                       "launches side by side; a decoder call = the lane kernel)") if win_on else "msda_fused_lanes_kernel<false>",
+                                       "launches, one after the other; a decoder call = the lane kernel)") if win_on else "msda_fused_lanes_kernel<false>",
             "achieved": mb / (md * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
             "frac": mb / (md * 1e-3) / 1e12 / 8.0,
             "traffic": enc_traffic if win_on else pmc_traffic("msda_fused_lanes_kernel<false>"),
@@ -726,7 +726,7 @@ def main():
                     "algorithmic bytes = value once + raw offsets | logits + output (SURVEY.md 8-d); avg_launch_us = HIP-event time "
                     "of a CALL.  Round 4: an encoder call serves its level-0 queries (75 %) from per-workgroup LDS windows of the "
                     "value map (msda_window_kernel: ~10 lines fetched per (query, head) instead of 64 gathered; bound by the vector "
-                    "ALU, tools/exp/msda_window_clock.py) and runs the coarser levels' queries on the lane kernel beside it; the lane "
+                    "ALU, tools/exp/msda_window_clock.py) and runs the coarser levels' queries on the lane kernel behind it; the lane "
                     "kernel alone is bound by the texture-address path (512 corner lines per query, TA busy 0.965, "
                     "profiles/r03_msda_ta_counters.txt; no cheaper gather shape or layout: profiles/r04_msda_ta_counters.txt)"}
     if bn_prof:
