@@ -86,11 +86,12 @@ def unpack_records(buf, image_size, feature_dim, num_points):
     return out
 
 
-def all_gather_records(local, group=None):
-    """One fused collective per step: [F,nq+1,D] on every rank -> [world*F, nq+1, D] in rank order."""
+def all_gather_records(local, group=None, always_collective=False):
+    """One fused collective per step: [F,nq+1,D] on every rank -> [world*F, nq+1, D] in rank order.  `always_collective`:
+    issue the collective at world size 1 too (tests: the RCCL communicator and call path on the one GPU a test box has)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not always_collective:
         return local
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     if local.is_cuda and dist.get_backend(group) == "gloo":
