@@ -178,7 +178,9 @@ def _clip_vs_oracle(builtin, frames_rgb, frac, check_frames, log):
         assert torch.equal(g.recs.cpu(), r["recs"]), ("characters", f)
         d = max(float((g.bd.cpu() - r["bd"]).abs().max()), float((g.ctrl_points.cpu().flatten(1) - r["ctrl_points"]).abs().max()))
         mx = max(mx, d)
-        assert d <= (0.15 if FULL else px_tol), ("points", f, d)       # FULL: the oracle detected on its own (rank swaps, see above)
+        # FULL: the oracle detected on its own, in its own rank order -- where near-tied proposal winners fell differently (above),
+        # every query of the frame has moved by up to ~1e-4 of the image size: north_star's bound on normalised coordinates (1e-3)
+        assert d <= (1e-3 * max(max(im.shape[-2:]) for im in images) if FULL else px_tol), ("points", f, d)
     log["max_abs_px"] = mx
     log["px_tol"] = px_tol
     log["mode"] = "oracle.run_clip over every frame" if FULL else \
