@@ -416,7 +416,27 @@ __global__ __launch_bounds__(256) void ffn_image_kernel(const unsigned short* __
 
 }  // namespace
 
-static int g_ffn_half_tail = 1, g_ffn_cus = -1;
+static int g_ffn_half_tail = 1;
+static int g_ffn_dev_cus[16] = {0};                      // compute units per device (cached per device id)
+static int g_ffn_stream_cus = 0;                         // > 0: the launches run on a CU-masked stream with this many CUs
+
+// compute units the launch can use: the caller's figure for a CU-masked stream, else the device's
+static int ffn_effective_cus() {
+    if (g_ffn_stream_cus > 0) return g_ffn_stream_cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (g_ffn_dev_cus[dev] <= 0) {
+        int n = 0;
+        g_ffn_dev_cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return g_ffn_dev_cus[dev];
+}
+/* [host] the number of compute units the fused-FFN launches can run on when their stream is CU-masked (GoMatching.reserve_tracker_cus:
+ * the detector on 224 of 256); 0 = the whole device.  Only the tail-round heuristic reads it: same bits either way. */
+extern "C" int gom_ffn_set_stream_cus(int cus) {
+    g_ffn_stream_cus = cus > 0 ? cus : 0;
+    return GOM_OK;
+}
 /* [host] 1 (default): the partly filled last round of a long launch runs as half-height tiles; 0: one launch of 128-row tiles. */
 extern "C" int gom_ffn_set_half_tail(int on) {
     g_ffn_half_tail = on ? 1 : 0;
@@ -460,13 +480,7 @@ extern "C" int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, 
         e = hipFuncSetAttribute((const void*)ffn_fused_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
     // long launches whose last round of one-per-CU tiles is less than half full: that round as half-height tiles (same bits)
-    int cus = g_ffn_cus;
-    if (cus < 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        g_ffn_cus = cus;
-    }
+    const int cus = ffn_effective_cus();
     const int rem = tiles % cus;
     if (g_ffn_half_tail && tiles >= 4 * cus && rem > 0 && 2 * rem <= cus) {
         const int full = tiles - rem;

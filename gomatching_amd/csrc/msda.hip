@@ -11,7 +11,9 @@
 // lanes per head, each lane 4 channels, so every corner fetch is a 16-byte load, a head's corner
 // is one 128-byte line, and the query's 256 outputs leave as one contiguous 1 KiB store.  The op
 // is gather-bound (HBM/L2), not MFMA work.
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 
@@ -769,30 +771,42 @@ extern "C" int gom_msda_fused_forward(const float* raw, int ld_raw, const float*
     return gom_launch_status();
 }
 
-// one side stream + fork / join events per device, created on first use (an eager call: never inside a stream capture)
+// Side lanes for the A/B switch below: one side stream + fork / join event pair PER CALLER STREAM (two streams entering the encoder
+// entry concurrently -- two detector lanes, or the tracker lane beside the detector -- must not re-record each other's events),
+// created on first use.  A lane is never created while its caller's stream is capturing (stream / event creation is not a
+// capturable operation): the call then runs its two kernels one after the other, as with the switch off.
 struct SideLane {
+    int dev = -1;
+    hipStream_t caller = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    bool tried = false;
 };
-static SideLane g_side[16];
+static std::mutex g_side_mu;
+static std::vector<SideLane*> g_side;
 static int g_msda_overlap = 0;                           // measured in the step: the fork / join costs the hipGraph more than the overlap buys
-static SideLane* side_lane() {
+static SideLane* side_lane(hipStream_t caller) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideLane& sl = g_side[dev];
-    if (!sl.tried) {
-        sl.tried = true;
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        (void)st;
-        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&sl.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&sl.join, hipEventDisableTiming) != hipSuccess) {
-            sl.stream = nullptr;
-            (void)hipGetLastError();
-        }
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (SideLane* sl : g_side)
+        if (sl->dev == dev && sl->caller == caller) return sl;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(caller, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
     }
-    return sl.stream ? &sl : nullptr;
+    SideLane* sl = new SideLane();
+    sl->dev = dev;
+    sl->caller = caller;
+    if (hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&sl->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sl->join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        delete sl;
+        return nullptr;
+    }
+    g_side.push_back(sl);
+    return sl;
 }
 /* [host] 1: the encoder entry runs its two kernels side by side (fork / join on a library-owned stream); 0 (default): one after
  * the other on the caller's stream.  Same bits.  Alone the call gains 3 % from the overlap (801 vs 812 us); inside the detector's
@@ -832,7 +846,7 @@ extern "C" int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, cons
     // fork BEFORE the window kernel is queued: the side stream then depends on what precedes this call only (see below)
     const long rest = num_query - n0;
     hipStream_t s = (hipStream_t)stream, lane_stream = s;
-    SideLane* sl = (rest > 0 && g_msda_overlap) ? side_lane() : nullptr;
+    SideLane* sl = (rest > 0 && g_msda_overlap) ? side_lane(s) : nullptr;
     if (sl) {
         if (hipEventRecord(sl->fork, s) == hipSuccess && hipStreamWaitEvent(sl->stream, sl->fork, 0) == hipSuccess) lane_stream = sl->stream;
         else sl = nullptr;

@@ -71,6 +71,7 @@ SIGNATURES = {
     "gom_ffn_fused_image_bytes": (L, [I, I]),
     "gom_ffn_fused_image": (I, [P, L, I, P, P, P, L, I, I, I, P, L, P]),
     "gom_ffn_set_half_tail": (I, [I]),
+    "gom_ffn_set_stream_cus": (I, [I]),
     "gom_ffn_fused_ln_f32": (I, [P, I, P, P, P, P, P, F, P, I, I, I, I, P, P]),
     "gom_mlp2_fused_f32": (I, [P, I, P, P, P, I, P, I, I, I, I, P, P]),
     "gom_pack_records_f32": (I, [P, I, I, P, P, P, P, P, P, I, I, I, I, F, F, P, P]),

@@ -344,12 +344,12 @@ class GoMatching:
             self._lane_next = (slot + 1) % self.detector_lanes
             stream, flag = self._lanes[slot]
             stream.wait_stream(torch.cuda.current_stream())
-            self._in_lane, self._lane_slot, ops._flag_override = True, slot, flag
+            self._in_lane, self._lane_slot = True, slot
             try:
-                with torch.cuda.stream(stream):
+                with torch.cuda.stream(stream), ops.flag_scope(flag):
                     return self.detect_launch(batched_inputs, time_cost)
             finally:
-                self._in_lane, self._lane_slot, ops._flag_override = False, 0, None
+                self._in_lane, self._lane_slot = False, 0
         lane = getattr(self, "_det_stream", None)
         if lane is not None and torch.cuda.current_stream() != lane:     # CU-partitioned step: the detector's own lane
             lane.wait_stream(torch.cuda.current_stream())
@@ -864,6 +864,7 @@ class GoMatching:
         n_cus = 0 undoes the reservation.  Not worth it on one GPU, where the tracker of 8 frames is 2 ms of a 36 ms step."""
         torch.cuda.synchronize(self.device)
         self._lane_stream = self._det_stream = None              # (the queues stay cached per mask in ops.masked_stream)
+        ops._L().gom_ffn_set_stream_cus(0)
         if n_cus <= 0:
             return
         total = torch.cuda.get_device_properties(self.device).multi_processor_count
@@ -877,6 +878,7 @@ class GoMatching:
         # tracker stream: on 32 CUs they took twice as long (bench --emulate-world 8: short-term 6.1 -> 12.7 ms per step)
         self._lane_stream = ops.masked_stream(trk, self.device)
         self._det_stream = ops.masked_stream(det, self.device)
+        ops._L().gom_ffn_set_stream_cus(total - n_cus)           # the fused FFN's tail-round rule counts the detector's CUs
 
     def begin_batch(self, instances, num_new_frames):
         """Keep the carried-over window's embeddings addressable, drop everything older, size the pool."""

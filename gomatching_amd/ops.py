@@ -4,7 +4,9 @@ Every function launches hand-written HIP kernels from libgomatching_hip.so on to
 none has a CPU or torch-op fallback.
 """
 import contextlib
+import contextvars
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -126,13 +128,29 @@ def _dev_index(device):
     return d.index if d.index is not None else torch.cuda.current_device()
 
 
-_flag_override = None                # a detector lane's own flag word while that lane's kernels are queued (GoMatching.detector_lanes)
+# a detector lane's own flag word while that lane's kernels are queued (GoMatching.detector_lanes): context-local (a second model,
+# another thread or a fallback pass between launch and finish never sees it), entered with `flag_scope`
+_flag_override = contextvars.ContextVar("gom_range_flag_override", default=None)
+_lane_flags = []                     # every flag word ever handed to `flag_scope` (weak references): `check_range_flag` scans them too
+
+
+@contextlib.contextmanager
+def flag_scope(flag):
+    """Kernels queued inside the block raise `flag` (a one-word int32 device tensor) instead of the device's default word."""
+    if not any(r() is flag for r in _lane_flags):
+        _lane_flags[:] = [r for r in _lane_flags if r() is not None] + [weakref.ref(flag)]
+    tok = _flag_override.set(flag)
+    try:
+        yield flag
+    finally:
+        _flag_override.reset(tok)
 
 
 def range_flag(device):
     """Device word the f16x3 kernels set when a result is not finite (an activation beyond fp16's range)."""
-    if _flag_override is not None:
-        return _flag_override
+    ov = _flag_override.get()
+    if ov is not None:
+        return ov
     key = _dev_index(device)
     if key not in _range_flags:
         _range_flags[key] = torch.zeros((1,), dtype=torch.int32, device=torch.device("cuda", key))
@@ -141,9 +159,13 @@ def range_flag(device):
 
 def check_range_flag(device):
     """Host check at a sync point: raises instead of letting an out-of-range activation pass as a result."""
-    f = _range_flags.get(_dev_index(device))
-    if f is not None and int(f.item()) != 0:
-        f.zero_()
+    key = _dev_index(device)
+    words = [_range_flags.get(key)] + [r() for r in _lane_flags]
+    words = [f for f in words if f is not None and f.device.index == key]
+    up = [f for f in words if int(f.item()) != 0]
+    if up:
+        for f in up:
+            f.zero_()
         raise _lib_mod.GomError("f16x3 GEMM produced a non-finite value: an activation left fp16's range (|x| > 65504) "
                                 "or the input was not finite; run with ops.GEMM_MODE = 'bf16x6'")
 

@@ -286,6 +286,7 @@ long gom_ffn_fused_image_bytes(int d_model, int d_hidden);
 int gom_ffn_fused_image(const void* w1_planes, long w1_plane_stride, int ld1, const float* w1_inv_scale, const float* b1,
                         const void* w2_planes, long w2_plane_stride, int ld2, int d_model, int d_hidden, void* image,
                         long image_bytes, void* stream);
+int gom_ffn_set_stream_cus(int cus); /* [host] compute units of the (CU-masked) stream the fused FFN is launched on; 0 = whole device */
 int gom_ffn_set_half_tail(int on);   /* [host] 1 (default): the partly filled last round of a long launch as half-height (64-row) tiles; same bits */
 int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, const float* w2_inv_scale, const float* b2,
                          const float* gamma, const float* beta, float eps, float* Y, int ldy, int M, int d_model,

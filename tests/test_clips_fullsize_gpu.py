@@ -112,13 +112,15 @@ def _same_detections(got, ref, px_tol):
     return worst
 
 
-def _clip_vs_oracle(builtin, frames_rgb, frac, check_frames, log):
-    """Runs the clip through `GoMatching.batch_inference` + short-track removal + rescaling and through the oracle."""
+def _clip_vs_oracle(builtin, frames_rgb, frac, check_frames, log, full=FULL, opts=()):
+    """Runs the clip through `GoMatching.batch_inference` + short-track removal + rescaling and through the oracle.
+    `full`: `oracle.run_clip` over EVERY frame, the oracle detecting on its own in its own rank order (unconditioned)."""
+    FULL = full
     from oracle import gom_oracle as O
     from gomatching_amd.modeling import GoMatching
-    cfg = setup_cfg(builtin=builtin)
+    cfg = setup_cfg(builtin=builtin, opts=opts)
     cfg.MODEL.DEVICE = DEV
-    ocfg = setup_cfg(builtin=builtin)
+    ocfg = setup_cfg(builtin=builtin, opts=opts)
     ocfg.MODEL.DEVICE = "cpu"
     inputs, sizes = _prepare(cfg, frames_rgb)
     images = [x["image"] for x in inputs]
@@ -180,7 +182,13 @@ def _clip_vs_oracle(builtin, frames_rgb, frac, check_frames, log):
         mx = max(mx, d)
         # FULL: the oracle detected on its own, in its own rank order -- where near-tied proposal winners fell differently (above),
         # every query of the frame has moved by up to ~1e-4 of the image size: north_star's bound on normalised coordinates (1e-3)
-        assert d <= (1e-3 * max(max(im.shape[-2:]) for im in images) if FULL else px_tol), ("points", f, d)
+        side = max(max(im.shape[-2:]) for im in images)
+        assert d <= (1e-3 * side if FULL else px_tol), \
+            ("points: frame %d moved %.3e px = %.2e of the %d-px image side; north_star's bound is 1e-3 on NORMALISED coordinates "
+             "in the unconditioned run (a near-tied proposal rank swap moves every query of the frame by ~1e-4 of the image), "
+             "%.1e px in the rank-conditioned one" % (f, d, d / side, side, px_tol))
+        log.setdefault("max_norm", 0.0)
+        log["max_norm"] = max(log["max_norm"], d / side)
     log["max_abs_px"] = mx
     log["px_tol"] = px_tol
     log["mode"] = "oracle.run_clip over every frame" if FULL else \
@@ -198,6 +206,28 @@ def test_dstext_clip_300_queries_vs_oracle():
     assert max(log["detections"]) >= 20 and log["tracks"] > max(log["detections"])
 
 
+def test_dstext_clip_unconditioned_oracle_on_every_frame():
+    """VERDICT r4 "weak" 1: the same DSText clip with NOTHING of the oracle conditioned on the HIP path -- `oracle.run_clip`
+    detects and tracks all 8 frames on its own (its own top-k order).  ids and characters identical; points within 1e-3 of the
+    image side (normalised coordinates, north_star's unit): where two near-tied proposal winners fall the other way between
+    the two fp32 evaluations every query of that frame moves by ~1e-4 of the image (measured 0.16 px = 7e-5 at 2276 px)."""
+    from gomatching_amd.synth import make_clip
+    frames = make_clip(8, 1080, 1920, clip_id=4, num_rects=14)
+    log = _clip_vs_oracle("pp_dstext", frames, 0.3, check_frames=(), log={"config": "pp_dstext, unconditioned"}, full=True)
+    print("CLIP", log)
+    assert log["max_norm"] <= 1e-3 and log["tracks"] > max(log["detections"])
+
+
+def test_bovtext_clip_unconditioned_oracle_on_every_frame():
+    """As above for config #5 (mixed-resolution sources, voc 5462)."""
+    from gomatching_amd.synth import make_clip
+    frames = make_clip(3, 720, 1280, clip_id=6, num_rects=10) + make_clip(3, 1080, 1920, clip_id=6, num_rects=10) + \
+        make_clip(2, 1280, 720, clip_id=6, num_rects=10)
+    log = _clip_vs_oracle("bovtext", frames, 0.7, check_frames=(), log={"config": "bovtext, unconditioned"}, full=True)
+    print("CLIP", log)
+    assert log["max_norm"] <= 1e-3
+
+
 def test_dstext_tracker_stress_every_query_a_detection():
     """The tracker-stress variant of SURVEY.md 8-d at config #4: the class bias lets EVERY query through the threshold, so
     frames carry up to 300 detections before NMS and the long-term windows approach 6 x 300 rows."""
@@ -206,6 +236,18 @@ def test_dstext_tracker_stress_every_query_a_detection():
     log = _clip_vs_oracle("pp_dstext", frames, 1.0, check_frames=(), log={"config": "pp_dstext stress (every query passes)"})
     print("CLIP", log)
     assert max(log["detections"]) >= 60                              # (of 300 queries through the threshold, NMS 0.3 leaves ~75)
+
+
+def test_dstext_lstmatcher_300_queries_stress_vs_oracle_tracker():
+    """VERDICT r4 "missing" 4: `GoMatching_DSText.yaml` = the DSText geometry with the LSTMatcher head (separate short / long
+    matcher transformers, 128-dim heads) at 300 queries -- long-term windows of up to 6 x ~75 rows after NMS go through
+    `mha_core`'s 128-dim-head path.  Stress bias (every query passes the threshold); ids vs the oracle's tracker on all frames."""
+    from gomatching_amd.synth import make_clip
+    frames = make_clip(8, 1080, 1920, clip_id=5, num_rects=14)
+    log = _clip_vs_oracle("pp_dstext", frames, 1.0, check_frames=(), log={"config": "GoMatching_DSText (LSTMatcher, nq 300), stress"},
+                          opts=("MODEL.ROI_HEADS.NAME", "LSTMatcher", "MODEL.ASSO_HEAD.ASSO_THRESH_TEST", "0.5"))
+    print("CLIP", log)
+    assert max(log["detections"]) >= 60
 
 
 def test_bovtext_mixed_resolution_clip_vs_oracle():

@@ -95,32 +95,38 @@ def test_pack_kernel_equals_generic_path_and_carries_image_size():
 
 
 def _rccl_worker(port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    """Always answers: ('ok', ...) or ('error', traceback) -- a failed RCCL init must not leave the parent waiting."""
+    import traceback
     try:
-        from gomatching_amd.dist import all_gather_records, exchange_and_track, pack_records
-        model, g = _model()
-        hw = tuple(int(v) for v in g["hw"])
-        inputs = _inputs(hw, 8)
-        single, count = model.batch_inference(inputs, 0, 0, [], _tc())
-        want = [x.track_ids.cpu().tolist() for x in single]
-        T = model.cfg.MODEL.TRANSFORMER
-        model.begin_batch([], 8)
-        dets = model.detect_steps(inputs, _tc())
-        rec = pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, model.device)
-        out = all_gather_records(rec, always_collective=True)                 # ncclAllGather on the record buffer, RCCL
-        torch.cuda.synchronize()
-        same = bool(torch.equal(out, rec)) and out.data_ptr() != rec.data_ptr()
-        model.begin_batch([], 8)
-        dets = model.detect_steps(inputs, _tc())
-        insts, count2 = exchange_and_track(model, dets, 0, 0, [], _tc())      # the sharded step's second half under backend nccl
-        got = [x.track_ids.cpu().tolist() for x in insts]
-        q.put((same, dist.get_backend(), got == want and int(count2) == int(count)))
-    finally:
-        dist.destroy_process_group()
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        try:
+            from gomatching_amd.dist import all_gather_records, exchange_and_track, pack_records
+            model, g = _model()
+            hw = tuple(int(v) for v in g["hw"])
+            inputs = _inputs(hw, 8)
+            single, count = model.batch_inference(inputs, 0, 0, [], _tc())
+            want = [x.track_ids.cpu().tolist() for x in single]
+            T = model.cfg.MODEL.TRANSFORMER
+            model.begin_batch([], 8)
+            dets = model.detect_steps(inputs, _tc())
+            rec = pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, model.device)
+            out = all_gather_records(rec, always_collective=True)                 # ncclAllGather on the record buffer, RCCL
+            torch.cuda.synchronize()
+            same = bool(torch.equal(out, rec)) and out.data_ptr() != rec.data_ptr()
+            model.begin_batch([], 8)
+            dets = model.detect_steps(inputs, _tc())
+            insts, count2 = exchange_and_track(model, dets, 0, 0, [], _tc())      # the sharded step's second half under backend nccl
+            got = [x.track_ids.cpu().tolist() for x in insts]
+            q.put(("ok", same, dist.get_backend(), got == want and int(count2) == int(count)))
+        finally:
+            dist.destroy_process_group()
+    except BaseException:
+        q.put(("error", traceback.format_exc()))
+        raise
 
 
 def test_rccl_communicator_and_all_gather_at_world_size_one():
@@ -136,6 +142,14 @@ def test_rccl_communicator_and_all_gather_at_world_size_one():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(port, q))
     p.start()
-    same, backend, ids_ok = q.get(timeout=300)
+    import queue
+    try:
+        msg = q.get(timeout=300)
+    except queue.Empty:
+        p.join(5)
+        raise AssertionError("the RCCL worker sent nothing in 300 s (exit code %r)" % (p.exitcode,))
     p.join(60)
+    assert msg[0] == "ok", "the RCCL worker failed:\n" + str(msg[1])
+    _, same, backend, ids_ok = msg
+    assert p.exitcode == 0, p.exitcode
     assert backend == "nccl" and same and ids_ok

@@ -3,7 +3,7 @@
 for rnd in 1 2 3; do
   for which in old new; do
     cp gpurun_ab/lib_$which.so gomatching_amd/libgomatching_hip.so
-    timeout 300 python3 bench.py --no-alt-backends --no-cpu-baseline --steps 15 > gpurun_out/bench_ab.json 2> gpurun_out/bench_ab.err
+    timeout 300 python3 bench.py --no-alt-backends --no-cpu-baseline --no-config-legs --steps 15 > gpurun_out/bench_ab.json 2> gpurun_out/bench_ab.err
     python3 - "$which" <<'PY'
 import json, sys
 d = json.loads(open("gpurun_out/bench_ab.json").read().strip().splitlines()[-1])
