@@ -519,7 +519,7 @@ def main():
     msda_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("msda:")]    # fused multi-scale deformable attention
     c3_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("conv3:")]     # patch-resident 3x3 convolutions
     pwk_prof = [p_ for p_ in prof if len(p_) > 4 and p_[4].startswith("pwk256:")]  # 256-channel pointwise convolutions on the K = 256 kernel
-    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:", "projdot:", "decattn:", "bneck:", "msda:", "conv3:", "pwk256:")))]
+    prof = [p_ for p_ in prof if not (len(p_) > 4 and p_[4].startswith(("ffn", "k256:", "projln:", "projdot:", "decattn:", "dectail:", "bneck:", "msda:", "conv3:", "pwk256:")))]
     dur_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     flops = sum(p[2] for p in prof)
     alg_bytes = sum(p[3] for p in prof)

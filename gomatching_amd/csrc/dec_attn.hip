@@ -45,6 +45,8 @@ constexpr int SLOTS = 3;                                 // ring depth: stage i 
 constexpr int RING_BYTES = SLOTS * CHUNK_BYTES;
 constexpr int XCH_BYTES = 4 * 8 * FRAG;                  // inter: K (4) + V^T (4) fragments of each of the four waves, one head
 constexpr int IMAGE_BYTES = STAGES * CHUNK_BYTES;
+constexpr int RAW_STAGES = 12;                           // RAW form: the cross attention's offsets | logits product (N = 384) behind the block
+constexpr int RAW_IMAGE_BYTES = (STAGES + RAW_STAGES) * CHUNK_BYTES;
 
 struct DecArgs {
     const float* X;                                          // tgt [rows, 256]
@@ -58,6 +60,10 @@ struct DecArgs {
     int G;                                                   // tokens per group
     int per_wave;                                            // inter: tokens of a group per wave = ceil(G / 4)
     int inner;                                               // inter: rows between consecutive tokens of a group (= points)
+    // RAW form: raw = (Y + P2) Wraw^T + braw, the sampling offsets | attention logits of the cross attention that follows
+    const float* P2;                                         // query_pos [rows, 256]
+    float* RAWO;                                             // [rows, 384]
+    int ldp2, ldraw;
 };
 
 __device__ __forceinline__ void split2(float x, float y, unsigned int& q0, unsigned int& q1) { gom_split2_f16(x, y, q0, q1); }
@@ -155,8 +161,9 @@ __device__ __forceinline__ f32x16 mfma_x3(const half8 a_hi, const half8 a_lo, co
         yacc[t_] = mfma_x3(src[2 * i_], src[2 * i_ + 1], of[hh_][s_][0], of[hh_][s_][1], yacc[t_]);           \
     }
 
-template <bool INTER>
+template <bool INTER, bool RAW = false>
 __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
+    constexpr int NST = STAGES + (RAW ? RAW_STAGES : 0);     // stages of the image this instantiation streams
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xch = smem + RING_BYTES;                  // inter only
     const int tid = threadIdx.x, lane = tid & 63;
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
         row = (b * p.G + tq) * p.inner + pp;
     }
 
-    const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, IMAGE_BYTES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, NST * CHUNK_BYTES, 0x00020000);
     constexpr unsigned OOB = 0x7FFF0000u;                    // beyond num_records: the DMA writes zeros (into an unused stage)
     const unsigned lane16 = lane * 16;
 
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
 #define DA_STAGE_VARS(i)                                                                                      \
     const unsigned char* base = smem + ((i) % SLOTS) * CHUNK_BYTES + lane * 16;                               \
     const float* aux = reinterpret_cast<const float*>(smem + ((i) % SLOTS) * CHUNK_BYTES + W_FRAGS * FRAG);   \
-    const unsigned nsrc = (i) + 2 < STAGES ? (unsigned)((i) + 2) * CHUNK_BYTES + wave * FRAG : OOB;          \
+    const unsigned nsrc = (i) + 2 < NST ? (unsigned)((i) + 2) * CHUNK_BYTES + wave * FRAG : OOB;             \
     unsigned char* ndst = smem + (((i) + 2) % SLOTS) * CHUNK_BYTES + wave * FRAG;
     // end of a stage: everything older than this stage's nine requests (= stage i + 1, requested a stage ago) has landed --
     // loads return in issue order; stages that issue other vector-memory operations behind their requests wait for all
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
         const int hh_ = h;
         DA_STAGE_VARS(3 * NH + h)
         (void)aux;
-        if (h < NH - 2) {
+        if (RAW || h < NH - 2) {                             // (RAW: twelve more stages follow, the ring keeps running)
             DA_STAGE(DA_MFMA_O)
             DA_STAGE_END()
         } else {
@@ -469,7 +476,9 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
         const float* v_inv = reinterpret_cast<const float*>(smem + ((STAGES - 1) % SLOTS) * CHUNK_BYTES + (W_FRAGS + 1) * FRAG);
         const float* v_bias = v_inv + 256;
         const float* v_gamma = v_inv + 512;
-        const float* v_beta = reinterpret_cast<const float*>(smem + ((STAGES - 2) % SLOTS) * CHUNK_BYTES + (W_FRAGS + 1) * FRAG);
+        // (RAW: stage 30's slot is already being refilled with stage 33 -- beta rides in stage 31 as well, fragment 32)
+        const float* v_beta = RAW ? reinterpret_cast<const float*>(smem + ((STAGES - 1) % SLOTS) * CHUNK_BYTES + W_FRAGS * FRAG)
+                                  : reinterpret_cast<const float*>(smem + ((STAGES - 2) % SLOTS) * CHUNK_BYTES + (W_FRAGS + 1) * FRAG);
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < D / 32; ++t)
@@ -498,8 +507,10 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
         sq += __shfl_xor(sq, 32, 64);
         const float rstd = rsqrtf(sq * (1.f / D) + p.eps);
         float* yr = p.Y + (size_t)row * p.ldy + 4 * fh;
+        const float* pr = RAW ? p.P2 + (size_t)row * p.ldp2 + 4 * fh : nullptr;
 #pragma unroll
-        for (int t = 0; t < D / 32; ++t)
+        for (int t = 0; t < D / 32; ++t) {
+            f32x16 x2;                                       // RAW: (block output + query_pos) of tile t, accumulator order
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int col = 32 * t + 8 * q + 4 * fh;
@@ -512,8 +523,61 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
                     chk = fmaf(o[e], 0.f, chk);
                 }
                 if (valid) *reinterpret_cast<f32x4*>(yr + 32 * t + 8 * q) = o;
+                if constexpr (RAW) {
+                    const f32x4 pq = *reinterpret_cast<const f32x4*>(pr + 32 * t + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x2[4 * q + e] = o[e] + pq[e];
+                        amax = fmaxf(amax, fabsf(x2[4 * q + e]));
+                    }
+                }
             }
-        asm volatile("" : "+v"(chk));
+            if constexpr (RAW) {
+                // the rows of the NEXT product as B-operand fragments: registers 8 s .. 8 s + 7 of tile t = k-step 2 t + s in accumulator
+                // order (the order out_proj's image uses for O^T; baked into the raw stages' image)
+                half8 f2[2][2];
+                acc_to_frags(x2, f2);
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    xf[0][2 * t + s_] = f2[s_][0];
+                    xf[1][2 * t + s_] = f2[s_][1];
+                }
+            }
+        }
+        asm volatile("" : "+v"(chk), "+v"(amax));
+    }
+    if constexpr (RAW) {
+        // ---- raw = (Y + query_pos) Wraw^T + braw: twelve 32-column chunks, transposed (lane = token), stored as 16-byte pieces ----
+        __builtin_amdgcn_sched_barrier(0);
+        float* rr = p.RAWO + (size_t)row * p.ldraw + 4 * fh;
+#pragma unroll
+        for (int c = 0; c < RAW_STAGES; ++c) {
+            DA_STAGE_VARS(STAGES + c)
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+            if (c < RAW_STAGES - 2) {
+                DA_STAGE(DA_MFMA_T)
+            } else {
+                (void)nsrc;
+                (void)ndst;
+                DA_STAGE_LAST(DA_MFMA_T)
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(aux + 8 * q + 4 * fh);
+                const f32x4 bi = *reinterpret_cast<const f32x4*>(aux + 32 + 8 * q + 4 * fh);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = fmaf(acc[4 * q + e], sc[e], bi[e]);
+                    chk = fmaf(o[e], 0.f, chk);
+                }
+                if (valid) *reinterpret_cast<f32x4*>(rr + 32 * c + 8 * q) = o;
+            }
+            asm volatile("" : "+v"(chk));
+            if (c < RAW_STAGES - 1) { DA_STAGE_END_ALL() }      // (the stores sit behind this stage's requests: wait for all)
+        }
     }
     // an operand left fp16's range, or a result is not finite (gemm_f16x3.hip contract; fmaxf drops a NaN, `chk` catches it)
     if ((!(amax <= 65504.f) || !(chk == 0.f)) && p.flag) atomicOr(p.flag, 1);
@@ -574,7 +638,7 @@ __global__ __launch_bounds__(256) void dec_attn_image_kernel(const unsigned shor
             // unused fragments of the last two stages: stage 31: 1 / row scale | bias | gamma (fragments 33, 34, 35), stage 30:
             // beta (fragment 33) -- 256 floats each, read by the epilogue straight from the ring
             const float* vec = nullptr;
-            if (st == STAGES - 1) vec = f == W_FRAGS + 1 ? out_inv : f == W_FRAGS + 2 ? out_bias : f == W_FRAGS + 3 ? gamma : nullptr;
+            if (st == STAGES - 1) vec = f == W_FRAGS + 1 ? out_inv : f == W_FRAGS + 2 ? out_bias : f == W_FRAGS + 3 ? gamma : beta;   // (f == W_FRAGS: beta again, for the RAW form)
             if (st == STAGES - 2 && f == W_FRAGS + 1) vec = beta;
             unsigned short v16 = 0;
             if (vec) {
@@ -586,7 +650,46 @@ __global__ __launch_bounds__(256) void dec_attn_image_kernel(const unsigned shor
     }
 }
 
+// The RAW form's twelve extra stages behind a block's image: chunk c = rows 32 c .. 32 c + 31 of the [384, 256] offsets | logits
+// weight; fragment f = 2 S + p (S = 0..15): element j of lane (r, h) = plane p of Ws[32 c + r][32 (S >> 1) + 16 (S & 1) + 8 (j >> 2) + 4 h
+// + (j & 3)] -- the accumulator order in which the block's own output becomes this product's operand; fragment 32 = 1 / row scale | bias.
+__global__ __launch_bounds__(256) void dec_attn_raw_image_kernel(const unsigned short* __restrict__ planes, long stride, int ld,
+                                                                 const float* __restrict__ inv, const float* __restrict__ bias,
+                                                                 unsigned short* __restrict__ img) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)RAW_STAGES * CHUNK_FRAGS * 512;
+    if (idx >= total) return;
+    const int e = (int)(idx % 512), f = (int)((idx / 512) % CHUNK_FRAGS), c = (int)(idx / (512L * CHUNK_FRAGS));
+    const int l = e >> 3, j = e & 7, r = l & 31, h = l >> 5;
+    unsigned short v16 = 0;
+    if (f < W_FRAGS) {
+        const int S = f >> 1, pl = f & 1;
+        v16 = planes[pl * stride + (size_t)(32 * c + r) * ld + 32 * (S >> 1) + 16 * (S & 1) + 8 * (j >> 2) + 4 * h + (j & 3)];
+    } else if (f == W_FRAGS) {
+        const int fi = e >> 1;
+        float v = 0.f;
+        if (fi < 32) v = inv[32 * c + fi];
+        else if (fi < 64) v = bias ? bias[32 * c + fi - 32] : 0.f;
+        const unsigned bits = __builtin_bit_cast(unsigned, v);
+        v16 = (unsigned short)((e & 1) ? (bits >> 16) : (bits & 0xffffu));
+    }
+    img[idx] = v16;
+}
+
 }  // namespace
+
+extern "C" long gom_dec_attn_raw_image_bytes(void) { return RAW_IMAGE_BYTES; }
+
+/* appends the offsets | logits stages to a block image of RAW_IMAGE_BYTES whose first IMAGE_BYTES gom_dec_attn_image has filled */
+extern "C" int gom_dec_attn_raw_image(const void* raw_planes, long raw_plane_stride, int ld_raw, const float* raw_inv_scale,
+                                      const float* raw_bias, void* image, long image_bytes, void* stream) {
+    GOM_CHECK_ARG(raw_planes && raw_inv_scale && image && ld_raw >= D && image_bytes >= RAW_IMAGE_BYTES);
+    const long total = (long)RAW_STAGES * CHUNK_FRAGS * 512;
+    hipLaunchKernelGGL(dec_attn_raw_image_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)raw_planes, raw_plane_stride, ld_raw, raw_inv_scale, raw_bias,
+                       (unsigned short*)((unsigned char*)image + IMAGE_BYTES));
+    return gom_launch_status();
+}
 
 extern "C" long gom_dec_attn_image_bytes(int d_model, int heads) {
     if (d_model != D || heads != NH) return -1;
@@ -626,5 +729,26 @@ extern "C" int gom_dec_attn_f32(const float* X, int ldx, const float* P, int ldp
     if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
     if (inter) hipLaunchKernelGGL(dec_attn_kernel<true>, dim3((unsigned)groups), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(dec_attn_kernel<false>, dim3((unsigned)cdiv(groups, 4)), dim3(256), lds, (hipStream_t)stream, a);
+    return gom_launch_status();
+}
+
+/* The inter-instance block followed by the cross attention's offsets | logits product on its output (deformable_transformer.py:396-404
+ * then ms_deform_attn.py:117-131's two Linear layers on query = tgt + query_pos): raw [rows, 384] = (Y + P2) Wraw^T + braw, one launch.
+ * `image`: gom_dec_attn_image (inter = 1) + gom_dec_attn_raw_image. */
+extern "C" int gom_dec_attn_raw_f32(const float* X, int ldx, const void* image, float eps, float* Y, int ldy, const float* P2, int ldp2,
+                                    float* raw, int ldraw, int groups, int group_tokens, int inner, int* flag, void* stream) {
+    GOM_CHECK_ARG(X && image && Y && P2 && raw && groups >= 0 && group_tokens > 0 && group_tokens <= 128 && inner > 0);
+    GOM_CHECK_ARG(ldx >= D && ldy >= D && ldp2 >= D && ldraw >= 384 && (ldx % 4) == 0 && (ldy % 4) == 0 && (ldp2 % 4) == 0 && (ldraw % 4) == 0);
+    GOM_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)P2 % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)raw % 16) == 0 &&
+                  ((uintptr_t)image % 16) == 0);
+    if (groups == 0) return GOM_OK;
+    DecArgs a{};
+    a.X = X; a.P = nullptr; a.img = (const unsigned char*)image; a.Y = Y; a.flag = flag; a.eps = eps; a.scale = 1.0f / sqrtf(32.f);
+    a.ldx = ldx; a.ldp = 0; a.ldy = ldy; a.groups = groups; a.G = group_tokens; a.per_wave = cdiv(group_tokens, 4); a.inner = inner;
+    a.P2 = P2; a.ldp2 = ldp2; a.RAWO = raw; a.ldraw = ldraw;
+    const int lds = RING_BYTES + XCH_BYTES;
+    hipError_t e = hipFuncSetAttribute((const void*)dec_attn_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+    hipLaunchKernelGGL((dec_attn_kernel<true, true>), dim3((unsigned)groups), dim3(256), lds, (hipStream_t)stream, a);
     return gom_launch_status();
 }

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
 __global__ __launch_bounds__(256) void ffn_image_kernel(const unsigned short* __restrict__ p1, long ps1, int ld1,
                                                         const float* __restrict__ inv1, const float* __restrict__ b1,
                                                         const unsigned short* __restrict__ p2, long ps2, int ld2, int F,
-                                                        unsigned short* __restrict__ img) {
+                                                        unsigned short* __restrict__ img, int perm) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;      // one fp16 element of the image
     const long total = (long)(F / CH) * STAGE_FRAGS * 512;
     if (i >= total) return;
@@ -400,7 +400,10 @@ __global__ __launch_bounds__(256) void ffn_image_kernel(const unsigned short* __
     const int l = e >> 3, j = e & 7, m = l & 15, kg = l >> 4;
     if (f < W1_FRAGS) {
         const int s = f >> 2, hh = (f >> 1) & 1, pl = f & 1;
-        img[i] = p1[pl * ps1 + (size_t)(CH * c + 16 * hh + m) * ld1 + 32 * s + 8 * kg + j];
+        // perm: the block's input arrives in ACCUMULATOR order (dec_tail.hip: the previous block's Y^T registers, split in place):
+        // k-slot j of lane group kg at k-step s <-> input feature 32 s + 16 (j >> 2) + 4 kg + (j & 3)
+        const int k = perm ? 32 * s + 16 * (j >> 2) + 4 * kg + (j & 3) : 32 * s + 8 * kg + j;
+        img[i] = p1[pl * ps1 + (size_t)(CH * c + 16 * hh + m) * ld1 + k];
     } else if (f < W1_FRAGS + W2_FRAGS) {
         const int id = f - W1_FRAGS, t = id >> 1, pl = id & 1;
         img[i] = p2[pl * ps2 + (size_t)(16 * t + m) * ld2 + CH * c + 16 * (j >> 2) + 4 * kg + (j & 3)];
@@ -448,17 +451,32 @@ extern "C" long gom_ffn_fused_image_bytes(int d_model, int d_hidden) {
     return (long)(d_hidden / CH) * STAGE_BYTES;
 }
 
-extern "C" int gom_ffn_fused_image(const void* w1_planes, long w1_plane_stride, int ld1, const float* w1_inv_scale,
-                                   const float* b1, const void* w2_planes, long w2_plane_stride, int ld2, int d_model,
-                                   int d_hidden, void* image, long image_bytes, void* stream) {
+static int ffn_image(const void* w1_planes, long w1_plane_stride, int ld1, const float* w1_inv_scale, const float* b1,
+                     const void* w2_planes, long w2_plane_stride, int ld2, int d_model, int d_hidden, void* image, long image_bytes,
+                     int perm, void* stream) {
     GOM_CHECK_ARG(w1_planes && w1_inv_scale && w2_planes && image);
     GOM_CHECK_ARG(d_model == D && d_hidden > 0 && (d_hidden % CH) == 0 && ld1 >= D && ld2 >= d_hidden);
     GOM_CHECK_ARG(image_bytes >= gom_ffn_fused_image_bytes(d_model, d_hidden));
     const long total = (long)(d_hidden / CH) * STAGE_FRAGS * 512;
     hipLaunchKernelGGL(ffn_image_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)w1_planes, w1_plane_stride, ld1, w1_inv_scale, b1,
-                       (const unsigned short*)w2_planes, w2_plane_stride, ld2, d_hidden, (unsigned short*)image);
+                       (const unsigned short*)w2_planes, w2_plane_stride, ld2, d_hidden, (unsigned short*)image, perm);
     return gom_launch_status();
+}
+
+extern "C" int gom_ffn_fused_image(const void* w1_planes, long w1_plane_stride, int ld1, const float* w1_inv_scale,
+                                   const float* b1, const void* w2_planes, long w2_plane_stride, int ld2, int d_model,
+                                   int d_hidden, void* image, long image_bytes, void* stream) {
+    return ffn_image(w1_planes, w1_plane_stride, ld1, w1_inv_scale, b1, w2_planes, w2_plane_stride, ld2, d_model, d_hidden, image,
+                     image_bytes, 0, stream);
+}
+
+/* the same image for a block whose INPUT arrives in accumulator order (a block chained behind another one in dec_tail.hip) */
+extern "C" int gom_ffn_fused_image_acc_order(const void* w1_planes, long w1_plane_stride, int ld1, const float* w1_inv_scale,
+                                             const float* b1, const void* w2_planes, long w2_plane_stride, int ld2, int d_model,
+                                             int d_hidden, void* image, long image_bytes, void* stream) {
+    return ffn_image(w1_planes, w1_plane_stride, ld1, w1_inv_scale, b1, w2_planes, w2_plane_stride, ld2, d_model, d_hidden, image,
+                     image_bytes, 1, stream);
 }
 
 extern "C" int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, const float* w2_inv_scale, const float* b2,

@@ -56,6 +56,9 @@ SIGNATURES = {
     "gom_dec_attn_image_bytes": (L, [I, I]),
     "gom_dec_attn_image": (I, [P, L, I, P, P, P, L, I, P, P, P, P, I, P, L, P]),
     "gom_dec_attn_f32": (I, [P, I, P, I, P, F, P, I, I, I, I, I, P, P]),
+    "gom_dec_attn_raw_image_bytes": (L, []),
+    "gom_dec_attn_raw_image": (I, [P, L, I, P, P, P, L, P]),
+    "gom_dec_attn_raw_f32": (I, [P, I, P, F, P, I, P, I, P, I, I, I, I, P, P]),
     "gom_dec_inter_heads_f32": (I, [P, I, P, P, I, I, I, I, P, P]),
     "gom_proj_ln_image_bytes": (L, [I, I]),
     "gom_proj_ln_image": (I, [P, L, I, I, I, P, L, P]),
@@ -73,6 +76,12 @@ SIGNATURES = {
     "gom_ffn_set_half_tail": (I, [I]),
     "gom_ffn_set_stream_cus": (I, [I]),
     "gom_ffn_fused_ln_f32": (I, [P, I, P, P, P, P, P, F, P, I, I, I, I, P, P]),
+    "gom_ffn_fused_image_acc_order": (I, [P, L, I, P, P, P, L, I, I, I, P, L, P]),
+    "gom_dec_tail_image_bytes": (L, [I, I, I]),
+    "gom_dec_tail_f32": (I, [P, I, P, I, P, P, P, P, F, P, P, P, P, P, P, P, P, P, I, P, P, I, I, P, P]),
+    "gom_dec_tail_lin_image_bytes": (L, []),
+    "gom_dec_tail_lin_image": (I, [P, L, I, P, L, P]),
+    "gom_dec_tail_proj_f32": (I, [P, I, P, I, P, I, P, P, P, P, F, P, P, P, P, F, P, P, P, P, P, P, P, P, P, I, P, P, I, I, P, P]),
     "gom_mlp2_fused_f32": (I, [P, I, P, P, P, I, P, I, I, I, I, P, P]),
     "gom_pack_records_f32": (I, [P, I, I, P, P, P, P, P, P, I, I, I, I, F, F, P, P]),
     "gom_relu_backward_f32": (I, [P, P, P, L, P]),

@@ -119,7 +119,9 @@ class DeepSolo:
                 "intra_block": ops.dec_attn_block(wi, bi, intra_out, n_intra, inter=False),
                 # up to 128 queries per frame one launch (csrc/dec_attn.hip); up to 352 (GoMatching++: 300) the block's image feeds
                 # csrc/dec_inter.hip (in_proj + attention per (group, head)) followed by the out_proj + LayerNorm launch
-                "inter_block": ops.dec_attn_block(wx, bx, inter_out, n_inter, inter=True)
+                # ... with the cross attention's offsets | logits product (N = 384) on its output in the same launch (<= 128 queries)
+                "inter_block": ops.dec_attn_block(wx, bx, inter_out, n_inter, inter=True,
+                                                  raw=cross["raw"] if self.nq <= ops.DEC_INTER_MAX_FUSED else None)
                 if self.nq <= ops.DEC_INTER_MAX_HEADS else None,
                 "intra_qk": qlin((wi[:2 * E], bi[:2 * E])), "intra_v": qlin((wi[2 * E:], bi[2 * E:])),
                 "intra_out": qlin(intra_out), "norm_intra": n_intra, "intra_out_ln": ops.proj_ln_block(intra_out, n_intra),
@@ -157,6 +159,18 @@ class DeepSolo:
         dim_t = torch.arange(128, dtype=_f32)
         dim_t = T.TEMPERATURE ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / 128)
         self.dim_t = dim_t.to(device)
+        # the row-local tail of every decoder layer -- FFN + norm3, ctrl_point_coord + reference refinement, the NEXT layer's
+        # ref_point_head over the sine embedding of the refined points -- as ONE launch (csrc/dec_tail.hip), f16x3 back-end
+        wb = lambda name: (g(name + ".weight"), g(name + ".bias"))
+        for i, L in enumerate(self.dec):
+            p = t + "decoder.layers.%d." % i
+            L["tail"] = ops.dec_tail_block(
+                (g(p + "linear1.weight"), g(p + "linear1.bias"), g(p + "linear2.weight"), g(p + "linear2.bias"),
+                 g(p + "norm3.weight"), g(p + "norm3.bias")),
+                [wb("ctrl_point_coord.0.layers.%d" % k) for k in range(3)],
+                [wb(t + "decoder.ref_point_head.layers.%d" % k) for k in range(2)], self.dim_t,
+                # ... and the cross attention's out_proj + norm_cross in front of it: the launch starts from the sampled rows
+                proj_w=wb(p + "attn_cross.output_proj") + wb(p + "norm_cross")) if T.DIM_FEEDFORWARD % 32 == 0 else None
         from scipy.special import comb                      # the reference's table (deformable_transformer.py:83-86)
         ts = torch.linspace(0, 1, self.P)
         self.bernstein = torch.tensor([[tt ** k * (1 - tt) ** (3 - k) * comb(3, k) for k in range(4)]
@@ -330,25 +344,27 @@ class DeepSolo:
         inter_refs = []
         E = 256
         emb = None                   # the layer's point embedding, when the previous layer's refinement launch already made it
+        qpos = None                  # ... or the layer's query position itself (the previous layer's tail launch)
         for lid, L in enumerate(self.dec):
-            refs, tgt, emb = self._decoder_layer(lid, L, tgt, refs, values, geo, B, vr, emb, lid + 1 < len(self.dec))
+            refs, tgt, emb, qpos = self._decoder_layer(lid, L, tgt, refs, values, geo, B, vr, emb, lid + 1 < len(self.dec), qpos)
             inter_refs.append(refs)
         return tgt, inter_refs
 
-    def _decoder_layer(self, lid, L, tgt, refs, values, geo, B, vr, emb=None, more=False):
+    def _decoder_layer(self, lid, L, tgt, refs, values, geo, B, vr, emb=None, more=False, qpos=None):
         nq, P, E = self.nq, self.P, 256
         Q = B * nq * P
         with ops.profile_scope("decoder_layer"):                 # bench.py: the launches that perform a layer's Q-side products
             # reference_points_input = reference_points * valid_ratios; the query position comes from level 0's (:470-473)
-            if emb is None:
-                qref = refs if vr is None else ops.scale_xy_(refs.clone(), *geo["vr0"])
-                emb = ops.point_pos_embed(qref, self.dim_t)
-            qpos = emb
-            if self.ref_point_mlp2 is not None:
-                qpos = ops.mlp2_fused(qpos, self.ref_point_mlp2)
-            else:
-                qpos = ops.linear(qpos, self.ref_point_head[0], relu=True)
-                qpos = ops.linear(qpos, self.ref_point_head[1])
+            if qpos is None:
+                if emb is None:
+                    qref = refs if vr is None else ops.scale_xy_(refs.clone(), *geo["vr0"])
+                    emb = ops.point_pos_embed(qref, self.dim_t)
+                qpos = emb
+                if self.ref_point_mlp2 is not None:
+                    qpos = ops.mlp2_fused(qpos, self.ref_point_mlp2)
+                else:
+                    qpos = ops.linear(qpos, self.ref_point_head[0], relu=True)
+                    qpos = ops.linear(qpos, self.ref_point_head[1])
             # intra-instance attention over the 25 points of each query (deformable_transformer.py:386-394)
             attn = None
             if L["intra_block"] is not None and P <= 32:
@@ -362,8 +378,12 @@ class DeepSolo:
                              [P * 2 * E, 0, 2 * E, P * 2 * E, 0, 2 * E, P * E, 0, E, P * E, 0, E])
                 tgt = self._out_norm(attn, L, "intra", tgt)
             # inter-instance attention over the nq queries, batched over (frame, point) (:396-404)
+            raw = None
             if L["inter_block"] is not None and nq <= ops.DEC_INTER_MAX_FUSED:
-                tgt = ops.dec_attn(tgt, L["inter_block"], B * P, nq, inner=P)
+                if L["inter_block"].has_raw and vr is None:
+                    tgt, raw = ops.dec_attn(tgt, L["inter_block"], B * P, nq, inner=P, raw_pos=qpos)
+                else:
+                    tgt = ops.dec_attn(tgt, L["inter_block"], B * P, nq, inner=P)
             elif L["inter_block"] is not None and L["inter_out_ln"] is not None:
                 tgt = ops.proj_ln(ops.dec_inter_heads(tgt, L["inter_block"], B * P, nq, inner=P), L["inter_out_ln"], tgt)
             else:
@@ -378,8 +398,17 @@ class DeepSolo:
             # deformable cross attention into the encoder memory (:406-422)
             value = values[:, lid * E:(lid + 1) * E]
             samp = self._msda_strided(L["cross"], tgt, qpos, refs.view(Q, 1, 2), value, values.stride(0), geo, B,
-                                      nq * P, vr)
+                                      nq * P, vr, raw=raw)
+            tail = L.get("tail") if vr is None else None
+            if tail is not None and tail.proj is not None:
+                # out_proj + norm_cross, FFN + norm3, the coordinate MLP + reference refinement (:484-488) and the next layer's query
+                # position: one launch from the sampled rows
+                tgt, refs, nqpos = ops.dec_tail(samp, tail, refs, want_qpos=more, residual=tgt)
+                return refs, tgt, None, nqpos
             tgt = self._out_norm(samp, L, "cross", tgt)
+            if tail is not None:
+                tgt, refs, nqpos = ops.dec_tail(tgt, tail, refs, want_qpos=more)
+                return refs, tgt, None, nqpos
             if L["ffn"] is not None:
                 tgt = ops.ffn_fused_ln(tgt, L["ffn"])
             else:
@@ -394,7 +423,7 @@ class DeepSolo:
             else:
                 d = self._mlp3(tgt, self.ctrl_coord)
                 refs, emb = ops.ref_sigmoid(d, refs, 2), None
-        return refs, tgt, emb
+        return refs, tgt, emb, None
 
     @staticmethod
     def _out_norm(x, L, name, tgt):
@@ -405,9 +434,11 @@ class DeepSolo:
         out = L["cross"]["out"] if name == "cross" else L[name + "_out"]
         return ops.layernorm(ops.linear(x, out, R=tgt), *L["norm_" + name])
 
-    def _msda_strided(self, W, query, query_pos, ref, value_view, ld_value, geo, B, Lq, vr=None):
-        """Cross-attention sampling straight out of the fused [B*S, 1536] value buffer (no compaction copy)."""
-        raw = ops.linear(query, W["raw"], A2=query_pos)
+    def _msda_strided(self, W, query, query_pos, ref, value_view, ld_value, geo, B, Lq, vr=None, raw=None):
+        """Cross-attention sampling straight out of the fused [B*S, 1536] value buffer (no compaction copy); `raw` = the offsets |
+        logits when the inter block's launch already made them."""
+        if raw is None:
+            raw = ops.linear(query, W["raw"], A2=query_pos)
         return ops.msda_fused(raw, ref, value_view, geo["S"] * ld_value, geo["shapes"], geo["lsi"], B, Lq, vr)
 
     def _mlp3(self, x, layers):

@@ -679,11 +679,16 @@ class DecAttnBlock:
     out_proj.weight [256, 256] in the kernel's stage order + what its epilogue needs.  `inter`: attention over the queries of a
     (frame, point) (deformable_transformer.py:396-404) instead of over the points of a query (:386-394)."""
 
-    def __init__(self, in_w, in_b, out_w, out_b, gamma, beta, inter, eps=1e-5):
+    def __init__(self, in_w, in_b, out_w, out_b, gamma, beta, inter, eps=1e-5, raw=None):
+        """raw = (weight [384, 256] as a SplitWeight or fp32 tensor, bias [384]) of the cross attention's sampling_offsets |
+        attention_weights layers: an inter block then also serves `dec_attn(..., raw_pos=query_pos)`."""
         assert tuple(in_w.shape) == (768, 256) and tuple(out_w.shape) == (256, 256)
         nbytes = _L().gom_dec_attn_image_bytes(256, 8)
         if nbytes < 0:
             raise _lib_mod.GomError("decoder attention kernel serves d_model 256 / 8 heads only")
+        if raw is not None:
+            assert inter and tuple(raw[0].shape) == (384, 256)
+            nbytes = _L().gom_dec_attn_raw_image_bytes()
         si = in_w if isinstance(in_w, SplitWeight) else split_weight(in_w.contiguous(), kind="f16x3")
         so = out_w if isinstance(out_w, SplitWeight) else split_weight(out_w.contiguous(), kind="f16x3")
         assert si.kind == "f16x3" and so.kind == "f16x3"
@@ -693,25 +698,59 @@ class DecAttnBlock:
         check(_L().gom_dec_attn_image(_p(pi), pi.stride(0), pi.stride(1), _p(si.inv_scale), _p(in_b), _p(po), po.stride(0),
                                       po.stride(1), _p(so.inv_scale), _p(out_b), _p(gamma), _p(beta), 1 if inter else 0,
                                       _p(self.image), nbytes, _stream()), "gom_dec_attn_image")
-        self.eps, self.inter = eps, bool(inter)
+        self.eps, self.inter, self.has_raw = eps, bool(inter), raw is not None
+        if raw is not None:
+            sr = raw[0] if isinstance(raw[0], SplitWeight) else split_weight(raw[0].contiguous(), kind="f16x3")
+            assert sr.kind == "f16x3"
+            _chk_f32(raw[1])
+            check(_L().gom_dec_attn_raw_image(_p(sr.planes), sr.planes.stride(0), sr.planes.stride(1), _p(sr.inv_scale), _p(raw[1]),
+                                              _p(self.image), nbytes, _stream()), "gom_dec_attn_raw_image")
 
 
-def dec_attn_block(in_w, in_b, out_pair, norm, inter):
+DEC_ATTN_RAW = _switch("DEC_ATTN_RAW")      # the inter block's launch also makes the cross attention's offsets | logits
+
+
+def dec_attn_block(in_w, in_b, out_pair, norm, inter, raw=None):
     """DecAttnBlock when the back-end allows, else None (callers keep the five-launch path)."""
     w, b = out_pair if not isinstance(out_pair, K256Linear) else (out_pair.W, out_pair.bias)
     on = DEC_ATTN and (DEC_ATTN_INTER if inter else DEC_ATTN_INTRA)
     if on and GEMM_MODE == "f16x3" and isinstance(in_w, SplitWeight) and in_w.kind == "f16x3" and tuple(in_w.shape) == (768, 256) \
             and isinstance(w, SplitWeight) and w.kind == "f16x3" and tuple(w.shape) == (256, 256):
-        return DecAttnBlock(in_w, in_b, w, b, norm[0], norm[1], inter)
+        if raw is not None:
+            rw, rb = raw if not isinstance(raw, K256Linear) else (raw.W, raw.bias)
+            raw = (rw, rb) if (DEC_ATTN_RAW and inter and isinstance(rw, SplitWeight) and rw.kind == "f16x3" and tuple(rw.shape) == (384, 256)) else None
+        return DecAttnBlock(in_w, in_b, w, b, norm[0], norm[1], inter, raw=raw)
     return None
 
 
-def dec_attn(x, blk, groups, group_tokens, inner=1, pos=None, out=None):
+def dec_attn(x, blk, groups, group_tokens, inner=1, pos=None, out=None, raw_pos=None):
     """LayerNorm(x + out_proj(MHA(...))) of one decoder self-attention block in one launch.  x [rows, 256]; intra (blk.inter
     False): `groups` runs of `group_tokens` <= 32 consecutive rows, q = k = x + pos, v = x; inter: token t of group g is row
-    ((g // inner) * group_tokens + t) * inner + g % inner, q = k = v = x."""
+    ((g // inner) * group_tokens + t) * inner + g % inner, q = k = v = x.  raw_pos (inter blocks built with `raw`): returns
+    (out, raw [rows, 384]) with raw = (out + raw_pos) Wraw^T + braw, the cross attention's sampling offsets | attention logits."""
     assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == 256 and x.dtype == _f32
     assert (pos is None) == blk.inter
+    if raw_pos is not None:
+        assert blk.inter and blk.has_raw and raw_pos.shape == x.shape and raw_pos.stride(1) == 1 and raw_pos.dtype == _f32
+        rows = groups * group_tokens
+        assert x.shape[0] == rows
+        if out is None:
+            out = torch.empty((rows, 256), dtype=_f32, device=x.device)
+        raw = torch.empty((rows, 384), dtype=_f32, device=x.device)
+        prof = _gemm_profile if (_gemm_profile is not None and rows > 0) else None
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(_L().gom_dec_attn_raw_f32(_p(x), x.stride(0) if rows > 1 else 256, _p(blk.image), blk.eps, _p(out),
+                                        out.stride(0) if rows > 1 else 256, _p(raw_pos), raw_pos.stride(0) if rows > 1 else 256,
+                                        _p(raw), 384, groups, group_tokens, inner, _p(range_flag(x.device)), _stream()),
+              "gom_dec_attn_raw_f32")
+        if prof is not None:
+            e1.record()
+            flops = 2.0 * rows * 256 * (1024 + 384) + 4.0 * rows * group_tokens * 256
+            prof.append((e0, e1, flops, 4.0 * rows * (256 * 3 + 384) + blk.image.numel(), "decattn:inter+raw:%dx%d" % (groups, group_tokens),
+                         _profile_scope))
+        return out, raw
     if pos is not None:
         assert pos.shape == x.shape and pos.stride(1) == 1 and pos.dtype == _f32
     rows = groups * group_tokens
@@ -845,6 +884,110 @@ def ffn_fused_ln(x, ffn, out=None):
         e1.record()
         prof.append((e0, e1, 4.0 * M * ffn.D * ffn.F, 8.0 * M * ffn.D + ffn.image.numel(), "ffn%dx%dx%d" % (M, ffn.D, ffn.F), _profile_scope))
     return out
+
+
+DEC_TAIL = _switch("DEC_TAIL")       # f16x3 back-end: FFN + ctrl_point_coord + reference refinement + the next ref_point_head, one launch
+
+
+class DecTail:
+    """The row-local tail of a composite decoder layer prepared for gom_dec_tail_f32 (csrc/dec_tail.hip): the concatenated
+    fragment-linear image of the FFN block, ctrl_point_coord's two hidden layers and ref_point_head (the latter two with their
+    first weight in accumulator order), plus the vectors the three epilogues need."""
+
+    def __init__(self, ffn_w, coord_w, qpos_w, dim_t, eps=1e-5, proj_w=None):
+        """proj_w = (out_proj weight [256, 256], bias, norm gain, norm bias) of the cross-attention block: the launch then starts from
+        the sampled rows (`dec_tail(..., residual=tgt)`)."""
+        w1, b1, w2, b2, gamma, beta = ffn_w
+        (c1, cb1), (c2, cb2), (W3, b3) = coord_w
+        (q1, qb1), (q2, qb2) = qpos_w
+        F_, D_ = w1.shape
+        assert D_ == 256 and tuple(w2.shape) == (D_, F_) and tuple(W3.shape) == (2, 256)
+        for w in (c1, c2, q1, q2):
+            assert tuple(w.shape) == (256, 256)
+        L = _L()
+        nbytes = L.gom_dec_tail_image_bytes(D_, F_, 1)
+        if nbytes < 0:
+            raise _lib_mod.GomError("decoder tail kernel does not serve d_model %d / d_hidden %d" % (D_, F_))
+        lin_bytes = L.gom_dec_tail_lin_image_bytes() if proj_w is not None else 0
+        nbytes += lin_bytes
+        self.image = torch.empty((nbytes,), dtype=torch.uint8, device=w1.device)
+        off = 0
+        self.proj = None
+        if proj_w is not None:
+            wo, bo, pg, pb = proj_w
+            assert tuple(wo.shape) == (256, 256)
+            so = split_weight(wo.contiguous(), kind="f16x3")
+            check(L.gom_dec_tail_lin_image(_p(so.planes), so.planes.stride(0), so.planes.stride(1), _p(self.image), lin_bytes, _stream()),
+                  "gom_dec_tail_lin_image")
+            off = lin_bytes
+            self.proj = (so.inv_scale, bo.contiguous(), pg.contiguous(), pb.contiguous())
+        keep = []
+        for (wa, ba, wb), fn, F_blk in (((w1, b1, w2), L.gom_ffn_fused_image_acc_order if proj_w is not None else L.gom_ffn_fused_image, F_),
+                                        ((c1, cb1, c2), L.gom_ffn_fused_image_acc_order, 256),
+                                        ((q1, qb1, q2), L.gom_ffn_fused_image_acc_order, 256)):
+            sa, sb = split_weight(wa.contiguous(), kind="f16x3"), split_weight(wb.contiguous(), kind="f16x3")
+            n = L.gom_ffn_fused_image_bytes(D_, F_blk)
+            pa, pb = sa.planes, sb.planes
+            check(fn(_p(pa), pa.stride(0), pa.stride(1), _p(sa.inv_scale), _p(ba), _p(pb), pb.stride(0), pb.stride(1), D_, F_blk,
+                     ctypes.c_void_p(self.image.data_ptr() + off), n, _stream()), "gom_ffn_fused_image*")
+            off += n
+            keep.append(sb.inv_scale)
+        assert off == nbytes
+        self.inv2, self.c_inv2, self.q_inv2 = keep
+        self.b2, self.gamma, self.beta = b2.contiguous(), gamma.contiguous(), beta.contiguous()
+        self.c_b2, self.q_b2 = cb2.contiguous(), qb2.contiguous()
+        self.W3, self.b3, self.dim_t, self.eps, self.D, self.F = W3.contiguous(), b3.contiguous(), dim_t, eps, D_, F_
+
+
+DEC_TAIL_PROJ = _switch("DEC_TAIL_PROJ")    # ... with the cross-attention's out_proj + norm_cross in front of it
+
+
+def dec_tail_block(ffn_w, coord_w, qpos_w, dim_t, proj_w=None):
+    """DecTail when the back-end and shapes allow, else None (callers keep the four-launch path)."""
+    ok = DEC_TAIL and FUSED_FFN and FUSED_MLP2 and REF_UPDATE and GEMM_MODE == "f16x3" and ffn_w[0].shape[1] == 256 and \
+        ffn_w[0].shape[0] % 32 == 0 and all(tuple(w.shape) == (256, 256) for w in (coord_w[0][0], coord_w[1][0], qpos_w[0][0], qpos_w[1][0]))
+    if proj_w is not None and not (DEC_TAIL_PROJ and tuple(proj_w[0].shape) == (256, 256)):
+        proj_w = None
+    return DecTail(ffn_w, coord_w, qpos_w, dim_t, proj_w=proj_w) if ok else None
+
+
+def dec_tail(x, blk, ref, want_qpos=True, residual=None):
+    """(tgt [M,256], new_ref [M,2], qpos [M,256] | None) of one launch: LayerNorm(x + FFN(x)), the refined reference points and the
+    NEXT layer's query position (deformable_transformer.py:352-369, :484-488, :470-473).  A block built with `proj_w` takes
+    x = the rows sampled by the cross attention and residual = tgt in front of that block: out_proj + norm_cross run first."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == 256 and x.dtype == _f32
+    assert (residual is not None) == (blk.proj is not None)
+    _chk_f32(ref)
+    M = x.shape[0]
+    assert ref.numel() == 2 * M
+    out = torch.empty((M, 256), dtype=_f32, device=x.device)
+    new_ref = torch.empty_like(ref)
+    qpos = torch.empty((M, 256), dtype=_f32, device=x.device) if want_qpos else None
+    prof = _gemm_profile if (_gemm_profile is not None and M > 0) else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if blk.proj is None:
+        check(_L().gom_dec_tail_f32(_p(x), x.stride(0) if M > 1 else 256, _p(blk.image), blk.F, _p(blk.inv2), _p(blk.b2), _p(blk.gamma),
+                                    _p(blk.beta), blk.eps, _p(blk.c_inv2), _p(blk.c_b2), _p(blk.W3), _p(blk.b3), _p(ref), _p(blk.dim_t),
+                                    _p(blk.q_inv2), _p(blk.q_b2), _p(out), 256, _p(new_ref), _p(qpos), 256, M,
+                                    _p(range_flag(x.device)), _stream()), "gom_dec_tail_f32")
+    else:
+        r = residual
+        assert r.dim() == 2 and r.stride(1) == 1 and r.shape == x.shape and r.dtype == _f32
+        pi, pb, pg, pbe = blk.proj
+        check(_L().gom_dec_tail_proj_f32(_p(x), x.stride(0) if M > 1 else 256, _p(r), r.stride(0) if M > 1 else 256, _p(blk.image), blk.F,
+                                         _p(pi), _p(pb), _p(pg), _p(pbe), blk.eps, _p(blk.inv2), _p(blk.b2), _p(blk.gamma), _p(blk.beta),
+                                         blk.eps, _p(blk.c_inv2), _p(blk.c_b2), _p(blk.W3), _p(blk.b3), _p(ref), _p(blk.dim_t),
+                                         _p(blk.q_inv2), _p(blk.q_b2), _p(out), 256, _p(new_ref), _p(qpos), 256, M,
+                                         _p(range_flag(x.device)), _stream()), "gom_dec_tail_proj_f32")
+    if prof is not None:
+        e1.record()
+        flops = 4.0 * M * 256 * blk.F + 4.0 * M * 256 * 256 * (2 if want_qpos else 1) + 4.0 * M * 256 + \
+            (2.0 * M * 256 * 256 if blk.proj is not None else 0.0)
+        prof.append((e0, e1, flops, 4.0 * M * 256 * (3 if want_qpos else 2) + blk.image.numel(), "dectail:%dx%d%s" % (M, blk.F, "+qpos" if want_qpos else ""),
+                     _profile_scope))
+    return out, new_ref, qpos
 
 
 # ------------------------------------------------------------------------------------------ MSDA

@@ -237,6 +237,16 @@ int gom_dec_attn_image(const void* in_planes, long in_plane_stride, int ld_in, c
                        void* stream);
 int gom_dec_attn_f32(const float* X, int ldx, const float* P, int ldp, const void* image, float eps, float* Y, int ldy, int groups,
                      int group_tokens, int inner, int inter, int* flag, void* stream);
+/* The inter-instance block (inter = 1) followed, in the same launch, by the cross attention's sampling_offsets | attention_weights
+ * product on its output (deformable_transformer.py:396-404, then ms_deform_attn.py:117-131 on query = tgt + query_pos):
+ *     raw [rows, 384] = (Y + P2) Wraw^T + braw        P2 = query_pos [rows, 256]
+ * `image`: gom_dec_attn_raw_image_bytes() bytes, filled by gom_dec_attn_image (inter = 1) and then gom_dec_attn_raw_image (the
+ * gom_split_f16x2 planes of the [384, 256] weight, its inverse row scales and bias).  group_tokens <= 128. */
+long gom_dec_attn_raw_image_bytes(void);
+int gom_dec_attn_raw_image(const void* raw_planes, long raw_plane_stride, int ld_raw, const float* raw_inv_scale,
+                           const float* raw_bias, void* image, long image_bytes, void* stream);
+int gom_dec_attn_raw_f32(const float* X, int ldx, const void* image, float eps, float* Y, int ldy, const float* P2, int ldp2,
+                         float* raw, int ldraw, int groups, int group_tokens, int inner, int* flag, void* stream);
 
 /* The inter-instance attention (deformable_transformer.py:396-404) for MORE than 128 queries per frame (GoMatching_PP_DSText.yaml:
  * 300), csrc/dec_inter.hip: in_proj + the 8 x 32 attention core, one workgroup per (group, head) with the head's K / V^T of all
@@ -297,6 +307,36 @@ int gom_ffn_fused_ln_f32(const float* X, int ldx, const void* image, const float
  * coordinate / boundary heads (:484-488, detection_transformer_wobackbone.py:238-253).  `image` = gom_ffn_fused_image. */
 int gom_mlp2_fused_f32(const float* X, int ldx, const void* image, const float* w2_inv_scale, const float* b2, int relu_out,
                        float* Y, int ldy, int M, int d_model, int d_hidden, int* flag, void* stream);
+
+/* The row-local TAIL of a composite decoder layer as one launch (csrc/dec_tail.hip; deformable_transformer.py:352-354,368-369
+ * FFN + norm3, :484-488 ctrl_point_coord MLP + reference refinement, :470-473 the NEXT layer's ref_point_head over the sine
+ * embedding of the refined points):
+ *     Y       = LayerNorm(X + relu(X W1^T + b1) W2^T + b2) * gamma + beta
+ *     new_ref = sigmoid(W3 relu(Wc2 relu(Wc1 Y + bc1) + bc2) + b3 + inverse_sigmoid(ref))           [M, 2]
+ *     qpos    = Wq2 relu(Wq1 point_pos_embed(new_ref) + bq1) + bq2                                   [M, 256]; qpos == NULL: skipped
+ * `image` = gom_ffn_fused_image(FFN) | gom_ffn_fused_image_acc_order(ctrl_point_coord layers 1-2) [| gom_ffn_fused_image_acc_order(
+ * ref_point_head)], concatenated (gom_dec_tail_image_bytes).  *_inv_scale / *_b2: the inverse row scales and bias of each block's
+ * SECOND weight.  Same f16x3 accuracy / range contract and *flag as gom_ffn_fused_ln_f32. */
+long gom_dec_tail_image_bytes(int d_model, int d_hidden, int with_qpos);
+int gom_ffn_fused_image_acc_order(const void* w1_planes, long w1_plane_stride, int ld1, const float* w1_inv_scale, const float* b1,
+                                  const void* w2_planes, long w2_plane_stride, int ld2, int d_model, int d_hidden, void* image,
+                                  long image_bytes, void* stream);
+int gom_dec_tail_f32(const float* X, int ldx, const void* image, int d_hidden, const float* w2_inv_scale, const float* b2,
+                     const float* gamma, const float* beta, float eps, const float* c_inv_scale, const float* c_b2,
+                     const float* W3, const float* b3, const float* ref, const float* dim_t128, const float* q_inv_scale,
+                     const float* q_b2, float* Y, int ldy, float* new_ref, float* qpos, int ldq, int M, int* flag, void* stream);
+/* ... with the cross-attention's out_proj + residual + norm_cross in front (deformable_transformer.py:406-422):
+ *     tgt3 = LayerNorm(R + S Wo^T + bo) * p_gamma + p_beta     S = the rows sampled by the fused MSDA op, R = tgt in front of the block
+ * then the chain above on tgt3.  `image` = gom_dec_tail_lin_image(out_proj planes) | gom_ffn_fused_image_acc_order x 3 (the FFN's
+ * input now arrives in accumulator order too).  Y must not alias S or R (it holds tgt3 while the FFN runs). */
+long gom_dec_tail_lin_image_bytes(void);
+int gom_dec_tail_lin_image(const void* w_planes, long w_plane_stride, int ld, void* image, long image_bytes, void* stream);
+int gom_dec_tail_proj_f32(const float* S, int lds, const float* R, int ldr, const void* image, int d_hidden,
+                          const float* p_inv_scale, const float* p_bias, const float* p_gamma, const float* p_beta, float p_eps,
+                          const float* w2_inv_scale, const float* b2, const float* gamma, const float* beta, float eps,
+                          const float* c_inv_scale, const float* c_b2, const float* W3, const float* b3, const float* ref,
+                          const float* dim_t128, const float* q_inv_scale, const float* q_b2, float* Y, int ldy, float* new_ref,
+                          float* qpos, int ldq, int M, int* flag, void* stream);
 
 /* Split-K form for convolutions with few output tiles and a long K (input_proj[3]: 3x3 s2 2048 -> 256 on res5, M = 3584,
  * K = 18432): `splits` K-slices run as separate workgroups into workspace [splits][M][Cout] fp32, a second kernel sums

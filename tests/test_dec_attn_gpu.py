@@ -137,3 +137,33 @@ def test_blocks_raise_the_range_flag():
     ops.dec_attn(torch.randn(100, 256, device=DEV), _block(ops, big, True), 4, 25, inner=1)
     with pytest.raises(Exception, match="fp16's range"):
         ops.check_range_flag(dev)
+
+
+@pytest.mark.parametrize("B,nq,P", [(1, 100, 25), (8, 100, 25), (2, 12, 25), (1, 128, 3), (3, 7, 2), (1, 97, 1)])
+def test_inter_block_with_offsets_and_logits_behind_it(B, nq, P):
+    """The RAW form: the inter block's launch also makes the cross attention's sampling_offsets | attention_weights product,
+    raw = (out + query_pos) Wraw^T + braw (ms_deform_attn.py:117-131 on query = tgt + query_pos).  `out` must be the plain
+    form's bits; raw against float64 and against the row-resident GEMM launch it replaces."""
+    from gomatching_amd import ops
+    g = torch.Generator().manual_seed(B * 131 + nq * 7 + P + 1)
+    w = _weights(2)
+    rows = B * nq * P
+    x, qpos = torch.randn(rows, 256, generator=g), torch.randn(rows, 256, generator=g) * 0.7
+    rw = torch.randn(384, 256, generator=g) / 16 * torch.logspace(-1, 1, 384).view(-1, 1) ** 0.3
+    rb = torch.randn(384, generator=g) * 0.1
+    d = [t.to(DEV) for t in w]
+    blk = ops.DecAttnBlock(d[0], d[1], d[2], d[3], d[4], d[5], True, raw=(rw.to(DEV), rb.to(DEV)))
+    plain = _block(ops, w, True)
+    xd, qd = x.to(DEV), qpos.to(DEV)
+    out, raw = ops.dec_attn(xd, blk, B * P, nq, inner=P, raw_pos=qd)
+    want = ops.dec_attn(xd, plain, B * P, nq, inner=P)
+    assert torch.equal(out, want)
+    idx = torch.arange(rows).view(B, nq, P).permute(0, 2, 1).reshape(B * P, nq)
+    ref = _ref(x, None, w, idx)
+    ref_raw = (ref + qpos.double()) @ rw.double().t() + rb.double()
+    err = float((raw.cpu().double() - ref_raw).abs().max())
+    assert err < 5e-5, err
+    lin = ops.k256_linear(ops.split_weight(rw.to(DEV), kind="f16x3"), rb.to(DEV))
+    two = ops.linear(want, lin, A2=qd)
+    assert float((raw - two).abs().max()) < 2e-5
+    ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
