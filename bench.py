@@ -293,6 +293,9 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="N=1 diagnostic: run the replicated tracker over W copies of this GPU's records per step, i.e. "
                          "the tracker load of a W-GPU run, beside one GPU's detection (value still counts 8 frames/step)")
+    ap.add_argument("--replicate-short-term", action="store_true",
+                    help="multi-GPU / --emulate-world: every rank scores EVERY frame pair of the clip (rounds 1-4) instead of its own "
+                         "8 pairs + a second all-gather of the score blocks (dist.exchange_and_track, default)")
     ap.add_argument("--gemm", default="f16x3", choices=["f16x3", "bf16x6", "fp32"],
                     help="contraction back-end: two-plane fp16 split on the fp16 matrix cores (default), three-plane bf16 "
                          "split, or exact-fp32 MFMA")
@@ -384,6 +387,7 @@ def main():
                 model.roi_heads._rescoring[1].add_(shifts["r"])
         tc_box = [new_time_cost()]
         last_rec = [None]
+        st_cache = [None]
         model._bench_last_rec = last_rec
 
         def finish(h):
@@ -396,17 +400,31 @@ def main():
             dets = model.detect_finish(h, tc)
             w2 = time.time()
             if args.emulate_world > 1 and world == 1:
-                from gomatching_amd.dist import pack_records, unpack_records
+                from gomatching_amd.dist import pack_records, unpack_records, pack_short_term, unpack_short_term
                 T = cfg.MODEL.TRANSFORMER
                 rec = pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, device)
                 last_rec[0] = (rec, dets[0].image_size)
                 dets = unpack_records(torch.cat([rec] * args.emulate_world), dets[0].image_size,
                                       model.roi_heads.feature_dim, T.NUM_POINTS)
                 w3 = time.time()
-                insts, id_count = model.track_frames(dets, 0, 0, [], tc)
+                st = None
+                if not args.replicate_short_term:
+                    # dist.exchange_and_track's sharded short-term precompute, emulated: THIS rank scores its own 8 frame pairs;
+                    # the other ranks' blocks (copies of the same records: computed once, outside the measurement) arrive as one
+                    # buffer copy standing for the second all-gather, and are unpacked (one D2H) as on a real rank
+                    model._home_features(list(dets))
+                    mine = list(range(FRAMES_PER_GPU))
+                    blocks = pack_short_term(model.precompute_short_term(list(dets), only=set(mine)), mine, T.NUM_QUERIES, device)
+                    if st_cache[0] is None:
+                        st_cache[0] = pack_short_term(model.precompute_short_term(list(dets)), list(range(len(dets))),
+                                                      T.NUM_QUERIES, device)
+                    allblk = st_cache[0].clone()
+                    allblk[:FRAMES_PER_GPU] = blocks
+                    st = unpack_short_term(allblk, list(range(len(dets))))
+                insts, id_count = model.track_frames(dets, 0, 0, [], tc, st=st)
             elif world > 1:
                 w3 = time.time()
-                insts, id_count = exchange_and_track(model, dets, 0, 0, [], tc)
+                insts, id_count = exchange_and_track(model, dets, 0, 0, [], tc, shard_short_term=not args.replicate_short_term)
             else:
                 w3 = time.time()
                 insts, id_count = model.track_frames(dets, 0, 0, [], tc)
@@ -574,6 +592,9 @@ def main():
                    if args.inputs == "host" else "frames resident in HBM when the timed window starts",
                    "frames_per_step": FRAMES_PER_GPU * world, "emulated_world": args.emulate_world,
                    "tracker_alone_ms_per_step": tracker_alone_ms,
+                   "short_term_scores": ("replicated on every rank" if args.replicate_short_term else
+                                         "sharded: a rank scores the frame pairs it detected, second all-gather of the [F, 2 + nq^2] blocks")
+                   if world * args.emulate_world > 1 else "single rank",
                    "tracker_cus": args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world >= 8 else 0),
                    "pipelining": "upload(step i+1) and detector(step i+1) overlap tracker(step i)",
                    "detector_hipgraph": graphed, "detector_lanes": args.detector_lanes,

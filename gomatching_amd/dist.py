@@ -117,12 +117,63 @@ def sharded_batch_inference(model, local_inputs, batch_id, id_count, instances, 
     return exchange_and_track(model, dets, batch_id, id_count, instances, time_cost, group)
 
 
-def exchange_and_track(model, dets, batch_id, id_count, instances, time_cost, group=None):
-    """Second half of the sharded step: pack this rank's detections, ONE all-gather, replicated tracker."""
+def pack_short_term(st, t_list, nq, device="cpu"):
+    """The short-term score blocks of a rank's frame pairs as one fixed-shape buffer for the second all-gather:
+    [len(t_list), 2 + nq * nq] fp32, row j = (n_cur, n_prev | S of pair t_list[j], row-major, zero-padded); a pair without a
+    block (an empty frame, the clip's first frame) has n_cur = n_prev = 0."""
+    buf = np.zeros((len(t_list), 2 + nq * nq), np.float32)
+    for j, t in enumerate(t_list):
+        S = st.get(t)
+        if S is None:
+            continue
+        n_cur, n_prev = S.shape
+        assert n_cur <= nq and n_prev <= nq
+        buf[j, 0], buf[j, 1] = n_cur, n_prev
+        buf[j, 2:2 + n_cur * n_prev] = np.asarray(S, np.float32).reshape(-1)
+    return torch.from_numpy(buf).to(device)
+
+
+def unpack_short_term(buf, t_all):
+    """[len(t_all), 2 + nq * nq] (rank order = frame order) -> {t: S numpy [n_cur, n_prev]} as `precompute_short_term` returns it."""
+    host = buf.cpu().numpy()
+    out = {}
+    for j, t in enumerate(t_all):
+        n_cur, n_prev = int(host[j, 0]), int(host[j, 1])
+        if n_cur and n_prev:
+            out[t] = host[j, 2:2 + n_cur * n_prev].reshape(n_cur, n_prev).copy()
+    return out
+
+
+SHARD_SHORT_TERM = True      # every rank scores only its own frame pairs; a second, small all-gather exchanges the blocks
+
+
+def exchange_and_track(model, dets, batch_id, id_count, instances, time_cost, group=None, shard_short_term=None):
+    """Second half of the sharded step: pack this rank's detections, ONE all-gather, replicated tracker.  The tracker's
+    id-independent device work -- the short-term association scores of every consecutive frame pair
+    (`precompute_short_term`, gom_lstmatcher.py:405-465 up to the assignment) -- is SHARDED: rank r scores the pairs whose
+    current frame it detected (the embeddings of both frames are in the gathered buffer), and a second all-gather of the
+    [F, 2 + nq^2] blocks (40 KB per frame at 100 queries) gives every rank all of them; the serial id recurrence
+    (short-term assignment, long-term matches: :467-564) then runs replicated on identical inputs."""
+    import torch.distributed as dist
     T = model.cfg.MODEL.TRANSFORMER
     hw = dets[0].image_size
+    F_local = len(dets)
     rec = pack_records(dets, T.NUM_QUERIES, model.roi_heads.feature_dim, T.NUM_POINTS, model.device)
     allrec = all_gather_records(rec, group)
     model._last_gathered_frames = int(allrec.shape[0])         # bench.py reports the ranks seen in the gathered buffer
     all_dets = unpack_records(allrec, hw, model.roi_heads.feature_dim, T.NUM_POINTS)
-    return model.track_frames(all_dets, batch_id, id_count, instances, time_cost)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    shard = SHARD_SHORT_TERM if shard_short_term is None else shard_short_term
+    if world == 1 or not shard:
+        return model.track_frames(all_dets, batch_id, id_count, instances, time_cost)
+    rank = dist.get_rank(group)
+    base = 1 if len(instances) else 0
+    window = ([instances[-1]] if base else []) + list(all_dets)
+    carried = list(instances[-max(model.test_len - 1, 1):]) if base else []
+    model._home_features(carried + list(all_dets))             # (what track_frames does first: the pool rows of every frame)
+    mine = [base + rank * F_local + j for j in range(F_local)]  # indices into `window` of the frames this rank detected
+    st_local = model.precompute_short_term(window, only=set(mine))
+    blocks = pack_short_term(st_local, mine, T.NUM_QUERIES, model.device)
+    allblk = all_gather_records(blocks, group)
+    st = unpack_short_term(allblk, [base + j for j in range(world * F_local)])
+    return model.track_frames(all_dets, batch_id, id_count, instances, time_cost, st=st)

@@ -704,11 +704,14 @@ class GoMatching:
                     track_ids[i] = uniq[j]
         return track_ids
 
-    def precompute_short_term(self, frames):
+    def precompute_short_term(self, frames, only=None):
         """Id-independent device work of every consecutive-frame short-term match of `frames`, batched
-        (roi_heads.short_term_scores); one D2H for all pairs.  Returns {index of cur frame: S numpy}."""
+        (roi_heads.short_term_scores); one D2H for all pairs.  Returns {index of cur frame: S numpy}.  `only`: the indices of the
+        cur frames to evaluate (a rank's share of a sharded clip, dist.exchange_and_track); None = every pair."""
         pairs, rows, boxes, which, off = [], [], [], [], 0
         for t in range(1, len(frames)):
+            if only is not None and t not in only:
+                continue
             n_prev, n_cur = len(frames[t - 1]), len(frames[t])
             if n_prev == 0 or n_cur == 0:
                 continue
@@ -916,17 +919,20 @@ class GoMatching:
             dets.extend(self.inference(batched_inputs[s0:s1], time_cost))
         return dets
 
-    def track_frames(self, dets, batch_id, id_count, instances, time_cost, frame_offset=0):
+    def track_frames(self, dets, batch_id, id_count, instances, time_cost, frame_offset=0, st=None):
         """The per-frame id recurrence of gom_lstmatcher.py:369-403 over already detected frames
-        (`frame_offset` = number of this batch's frames already tracked by earlier calls)."""
+        (`frame_offset` = number of this batch's frames already tracked by earlier calls).  `st`: the short-term score matrices of
+        `precompute_short_term(([instances[-1]] if instances else []) + dets)` when the caller already holds them (a sharded clip:
+        every rank scores its own frame pairs and the blocks are exchanged, dist.exchange_and_track)."""
         if ops.NATIVE_TRACKER and len(dets):
-            return self._track_frames_native(dets, batch_id, id_count, instances, time_cost, frame_offset)
+            return self._track_frames_native(dets, batch_id, id_count, instances, time_cost, frame_offset, st=st)
         start_frame_id = batch_id * 100 + frame_offset
         t0 = time.time()
         base = len(instances)
         window = ([instances[-1]] if base else []) + list(dets)
         self._home_features(window)
-        st = self.precompute_short_term(window)                  # keyed by index into `window`
+        if st is None:
+            st = self.precompute_short_term(window)              # keyed by index into `window`
         shift = 1 if base else 0
         time_cost["short_match"] += time.time() - t0
         self._defer_ids = True
@@ -965,7 +971,7 @@ class GoMatching:
         self._flush_ids(dets)
         return instances, id_count
 
-    def _track_frames_native(self, dets, batch_id, id_count, instances, time_cost, frame_offset):
+    def _track_frames_native(self, dets, batch_id, id_count, instances, time_cost, frame_offset, st=None):
         """`track_frames` with the per-frame loop in native code (csrc/tracker_rt.hip): this method only gathers the host
         mirrors of the window (carried frames + new ones), runs the batched short-term device work, and hands everything
         over in ONE call; ids come back for all new frames."""
@@ -976,8 +982,10 @@ class GoMatching:
         base = len(instances)
         carried = list(instances[-max(self.test_len - 1, 1):]) if base else []
         self._home_features(carried + list(dets))
-        st = self.precompute_short_term(([instances[-1]] if base else []) + list(dets))
-        if os.environ.get("GOM_TRACKER_DOUBLE_CHECK") == "1":    # diagnostic: the same device work again, same bits?
+        given = st is not None
+        if not given:
+            st = self.precompute_short_term(([instances[-1]] if base else []) + list(dets))
+        if os.environ.get("GOM_TRACKER_DOUBLE_CHECK") == "1" and not given:    # diagnostic: the same device work again, same bits?
             st2 = self.precompute_short_term(([instances[-1]] if base else []) + list(dets))
             for key in st:
                 if not np.array_equal(st[key], st2[key]):

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gomatching_amd.dist import pack_records, unpack_records, all_gather_records, record_dim
+from gomatching_amd.dist import pack_records, unpack_records, all_gather_records, record_dim, pack_short_term, unpack_short_term
 from gomatching_amd.structures import Boxes, Instances
 
 NQ, F, P = 12, 1024, 25
@@ -118,3 +118,53 @@ def test_gradient_allreduce_world2():
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+def _st_blocks(rank, frames=3):
+    """The short-term score blocks a rank would hold for its `frames` frame pairs (indices rank * frames + j into the window):
+    ragged sizes, an empty pair, a full nq x nq one."""
+    g = np.random.default_rng(50 + rank)
+    out = {}
+    for j in range(frames):
+        n_cur, n_prev = [(5, 7), (0, 0), (NQ, NQ)][j] if rank == 0 else [(1, NQ), (3, 2), (0, 0)][j]
+        if n_cur and n_prev:
+            out[rank * frames + j] = g.random((n_cur, n_prev), dtype=np.float32)
+    return out
+
+
+def _st_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = [rank * 3 + j for j in range(3)]
+        blk = pack_short_term(_st_blocks(rank), mine, NQ)
+        assert blk.shape == (3, 2 + NQ * NQ)
+        allblk = all_gather_records(blk)
+        got = unpack_short_term(allblk, list(range(3 * world)))
+        want = {}
+        for r in range(world):
+            want.update(_st_blocks(r))
+        ok = sorted(got) == sorted(want) and all(np.array_equal(got[t], want[t]) for t in want)
+        q.put((rank, bool(ok), float(allblk.double().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_short_term_block_exchange_world2():
+    """The SECOND exchange of a sharded step (dist.exchange_and_track): every rank scores the frame pairs it detected and the
+    [F, 2 + nq^2] blocks are all-gathered; every rank must end up with every pair's matrix, bit for bit, in frame order."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_st_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2]

@@ -32,12 +32,14 @@ def _tc():
     return {k: 0.0 for k in ("pre_process", "backbone", "detector", "rescore", "tracker", "short_match", "long_match")}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, shard=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from gomatching_amd import dist as gdist
         from gomatching_amd.dist import sharded_batch_inference
+        gdist.SHARD_SHORT_TERM = shard                        # True: every rank scores its own frame pairs + a second all-gather
         model, g = _model()
         hw = tuple(int(v) for v in g["hw"])
         inputs = _inputs(hw, 8)
@@ -49,7 +51,10 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_equals_single_process():
+@pytest.mark.parametrize("shard", [True, False])
+def test_sharded_equals_single_process(shard):
+    """shard: the short-term scores of a rank's own frame pairs only + the second all-gather (default) | every rank scores every
+    pair (the replicated tracker of rounds 1-4).  Identical ids either way."""
     model, g = _model()
     hw = tuple(int(v) for v in g["hw"])
     insts, id_count = model.batch_inference(_inputs(hw, 8), 0, 0, [], _tc())
@@ -61,7 +66,7 @@ def test_sharded_equals_single_process():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, shard)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in procs)
