@@ -105,9 +105,10 @@ __device__ __forceinline__ float groups_sum(float v) {
     return v;
 }
 
-// ONLY_FFN: the launch ends behind the FFN block's epilogue -- the fused FFN block of ffn_fused.hip with THIS kernel's epilogue
-// (residual, LayerNorm and stores in the accumulator layout, no LDS staging, no barrier).
-template <bool WITH_QPOS, bool WITH_PROJ, bool ONLY_FFN = false>
+// (Measured, round 5: the FFN block ALONE on this kernel's register epilogue -- residual, LayerNorm and 16-byte stores in the
+// accumulator layout instead of ffn_fused.hip's LDS-staged whole-row pass -- is SLOWER: 884 vs 811 us at M = 297 368, 83 vs 79 us at
+// M = 20 000.  The register epilogue pays here only because it is what lets the blocks chain.)
+template <bool WITH_QPOS, bool WITH_PROJ>
 __global__ __launch_bounds__(256, 1) void dec_tail_kernel(const TailArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256, 1) void dec_tail_kernel(const TailArgs p) {
     const long tile0 = (long)blockIdx.x * BM;
     const long row0 = tile0 + wave * 32;
     constexpr int C0 = WITH_PROJ ? LIN_STAGES : 0;           // stages of the out_proj block in front of the FFN's
-    const int total_chunks = ONLY_FFN ? p.ffn_chunks : C0 + p.ffn_chunks + MLP_CHUNKS + (WITH_QPOS ? MLP_CHUNKS : 0);
+    const int total_chunks = C0 + p.ffn_chunks + MLP_CHUNKS + (WITH_QPOS ? MLP_CHUNKS : 0);
 
     const __amdgpu_buffer_rsrc_t rs_img =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, total_chunks * STAGE_BYTES, 0x00020000);
@@ -407,16 +408,10 @@ __global__ __launch_bounds__(256, 1) void dec_tail_kernel(const TailArgs p) {
                     if (live[r]) *reinterpret_cast<f32x4*>(p.Y + (size_t)(row0 + 16 * r + fn) * p.ldy + col) = o[hh][r];
                 }
             }
-            if constexpr (!ONLY_FFN) {
 #pragma unroll
-                for (int r = 0; r < 2; ++r) gom_split8_f16(o[0][r], o[1][r], xf[0][8 * r + s], xf[1][8 * r + s]);
-            }
+            for (int r = 0; r < 2; ++r) gom_split8_f16(o[0][r], o[1][r], xf[0][8 * r + s], xf[1][8 * r + s]);
         }
         asm volatile("" : "+v"(amax), "+v"(chk));
-    }
-    if constexpr (ONLY_FFN) {
-        if ((!(amax <= 65504.f) || !(hmax <= 65504.f) || !(chk == 0.f)) && p.flag) atomicOr(p.flag, 1);
-        return;
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -629,21 +624,3 @@ extern "C" int gom_dec_tail_proj_f32(const float* S, int lds, const float* R, in
     return dec_tail_launch(a, true, stream);
 }
 
-/* Experiment / A-B: the fused FFN block alone on this kernel (register epilogue); image = gom_ffn_fused_image, arguments as
- * gom_ffn_fused_ln_f32. */
-extern "C" int gom_ffn_fused_ln_reg_f32(const float* X, int ldx, const void* image, const float* w2_inv_scale, const float* b2,
-                                        const float* gamma, const float* beta, float eps, float* Y, int ldy, int M, int d_model,
-                                        int d_hidden, int* flag, void* stream) {
-    GOM_CHECK_ARG(X && image && w2_inv_scale && b2 && gamma && beta && Y);
-    GOM_CHECK_ARG(M >= 0 && d_model == D && d_hidden > 0 && (d_hidden % CH) == 0 && ldx >= D && ldy >= D && (ldx % 4) == 0 && (ldy % 4) == 0);
-    GOM_CHECK_ARG(GOM_ALIGNED16(X) && GOM_ALIGNED16(Y) && GOM_ALIGNED16(image) && GOM_ALIGNED16(w2_inv_scale) && GOM_ALIGNED16(b2) &&
-                  GOM_ALIGNED16(gamma) && GOM_ALIGNED16(beta));
-    if (M == 0) return GOM_OK;
-    TailArgs a{};
-    a.X = X; a.img = (const unsigned char*)image; a.s2 = w2_inv_scale; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = Y; a.flag = flag;
-    a.eps = eps; a.ldx = ldx; a.ldy = ldy; a.M = M; a.ffn_chunks = d_hidden / CH;
-    hipError_t e = hipFuncSetAttribute((const void*)dec_tail_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-    hipLaunchKernelGGL((dec_tail_kernel<false, false, true>), dim3((unsigned)cdiv(M, BM)), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
-    return gom_launch_status();
-}

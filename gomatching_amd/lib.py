@@ -79,7 +79,6 @@ SIGNATURES = {
     "gom_ffn_fused_image_acc_order": (I, [P, L, I, P, P, P, L, I, I, I, P, L, P]),
     "gom_dec_tail_image_bytes": (L, [I, I, I]),
     "gom_dec_tail_f32": (I, [P, I, P, I, P, P, P, P, F, P, P, P, P, P, P, P, P, P, I, P, P, I, I, P, P]),
-    "gom_ffn_fused_ln_reg_f32": (I, [P, I, P, P, P, P, P, F, P, I, I, I, I, P, P]),
     "gom_dec_tail_lin_image_bytes": (L, []),
     "gom_dec_tail_lin_image": (I, [P, L, I, P, L, P]),
     "gom_dec_tail_proj_f32": (I, [P, I, P, I, P, I, P, P, P, P, F, P, P, P, P, F, P, P, P, P, P, P, P, P, P, I, P, P, I, I, P, P]),

@@ -329,9 +329,6 @@ int gom_dec_tail_f32(const float* X, int ldx, const void* image, int d_hidden, c
  *     tgt3 = LayerNorm(R + S Wo^T + bo) * p_gamma + p_beta     S = the rows sampled by the fused MSDA op, R = tgt in front of the block
  * then the chain above on tgt3.  `image` = gom_dec_tail_lin_image(out_proj planes) | gom_ffn_fused_image_acc_order x 3 (the FFN's
  * input now arrives in accumulator order too).  Y must not alias S or R (it holds tgt3 while the FFN runs). */
-int gom_ffn_fused_ln_reg_f32(const float* X, int ldx, const void* image, const float* w2_inv_scale, const float* b2,
-                             const float* gamma, const float* beta, float eps, float* Y, int ldy, int M, int d_model,
-                             int d_hidden, int* flag, void* stream);   /* gom_ffn_fused_ln_f32 on dec_tail.hip's register epilogue (A/B) */
 long gom_dec_tail_lin_image_bytes(void);
 int gom_dec_tail_lin_image(const void* w_planes, long w_plane_stride, int ld, void* image, long image_bytes, void* stream);
 int gom_dec_tail_proj_f32(const float* S, int lds, const float* R, int ldr, const void* image, int d_hidden,
