@@ -572,6 +572,11 @@ def main():
             d[0] += 1
             d[1] += p_[0].elapsed_time(p_[1])
             d[2] += p_[2]
+    if rank == 0 and os.environ.get("GOM_BENCH_ALL_SHAPES"):    # diagnostic: every instrumented launch shape of a step, by time
+        with open(os.environ["GOM_BENCH_ALL_SHAPES"], "w") as f:
+            for k_, v_ in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
+                f.write("%-44s x%-3d %9.1f us each %9.1f us per step %7.1f TFLOP/s\n" % (
+                    k_, v_[0] // PROFILE_STEPS, v_[1] * 1e3 / v_[0], v_[1] * 1e3 / PROFILE_STEPS, v_[2] / (v_[1] * 1e-3) / 1e12))
     line = {
         "metric": "frames/sec (whole node), 1280x720 clip, 100 queries/frame",
         "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

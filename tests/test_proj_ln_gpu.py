@@ -66,7 +66,7 @@ def test_proj_ln_strided_rows_wide_range_weights_in_place_and_range_flag():
         with pytest.raises(Exception, match="fp16's range"):
             ops.check_range_flag(dev)
         from gomatching_amd import lib
-        assert lib.load().gom_proj_ln_image_bytes(256, 512) == -1 and lib.load().gom_proj_ln_image_bytes(256, 256) == 4 * 65536
+        assert lib.load().gom_proj_ln_image_bytes(256, 512) == -1 and lib.load().gom_proj_ln_image_bytes(256, 256) == 4 * 65536 + 8 * 32768   # both forms
     finally:
         ops.GEMM_MODE = old
 
@@ -100,3 +100,31 @@ def test_no_residual_and_dot_form(M):
             assert torch.equal(ops.proj_ln_dot(x[rows].contiguous(), blk, cw, cb), logit[rows])
     finally:
         ops.GEMM_MODE = old
+
+
+@pytest.mark.parametrize("M", [1, 63, 64, 65, 1000, 20000, 128 * 300 + 17])
+def test_two_workgroups_per_cu_form_against_the_128_row_form(M):
+    """Round 5: launches run on 64-row tiles at two workgroups per CU (16x16x32 MFMA, k-steps of 32) by default; the 128-row form
+    (32x32x16, the tile kernel's bits) stays behind `ops.PROJ_LN_V2 = False` (`gom_proj_ln_set_v2`).  fp32-class agreement, and a row's bits do not depend
+    on the launch (batch invariance) in either form."""
+    from gomatching_amd import lib, ops
+    g = torch.Generator().manual_seed(M)
+    w = (torch.randn((256, 256), generator=g) * 0.06).to(DEV)
+    b = (torch.randn((256,), generator=g) * 0.1).to(DEV)
+    ga, be = (torch.rand((256,), generator=g) + 0.5).to(DEV), (torch.randn((256,), generator=g) * 0.1).to(DEV)
+    blk = ops.ProjLN(ops.split_weight(w, kind="f16x3"), b, ga, be)
+    x, r = torch.randn((M, 256), generator=g).to(DEV), torch.randn((M, 256), generator=g).to(DEV)
+    try:
+        ops.PROJ_LN_V2 = False
+        old = ops.proj_ln(x, blk, r)
+        ops.PROJ_LN_V2 = True
+        new = ops.proj_ln(x, blk, r)
+        part = ops.proj_ln(x[M // 2:].contiguous(), blk, r[M // 2:].contiguous())
+    finally:
+        ops.PROJ_LN_V2 = True
+    ops.check_range_flag(DEV)
+    assert float((old - new).abs().max()) <= 2e-5
+    assert torch.equal(part, new[M // 2:])
+    d = lambda t: t.double().cpu()
+    ref = torch.nn.functional.layer_norm(d(x) @ d(w).T + d(b) + d(r), (256,), d(ga), d(be), 1e-5)
+    assert float((d(new) - ref).abs().max()) <= 2e-5
