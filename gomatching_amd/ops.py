@@ -632,6 +632,9 @@ def proj_ln_dot(x, blk, w, b):
 BNECK_FUSED = _switch("BNECK_FUSED")   # f16x3 back-end: a bottleneck block's conv3 + residual + ReLU fused with the next block's conv1
 
 
+BNECK2 = _switch("BNECK2")           # res4's bottleneck tails + next heads (256 -> 1024 -> 256) fused on csrc/bneck2.hip (two workgroups per CU)
+
+
 class BneckFused:
     """conv3 (1x1, [c4, k1]) + folded BatchNorm + residual + ReLU of one ResNet bottleneck block and conv1 (1x1, [mp, c4]) +
     folded BatchNorm + ReLU of the NEXT block prepared for gom_bneck_f32 (csrc/bneck_fused.hip): the block's output is written once
@@ -643,6 +646,18 @@ class BneckFused:
         assert w1.K == self.c4
         _chk_f32(scale3, shift3, scale1, shift1)
         p3, p1 = w3.planes, w1.planes
+        self.v2 = BneckFused._wide(self.k1, self.c4, self.mp)
+        if self.v2:
+            # res4 (256 -> 1024 -> 256): csrc/bneck2.hip, two workgroups per CU; its image IS the fused FFN kernel's (W1 := conv3,
+            # W2 := conv1'; the stage's last fragment carries 1 / row scale x BN scale | BN shift)
+            nbytes = _L().gom_ffn_fused_image_bytes(256, self.c4)
+            self.image = torch.empty((nbytes,), dtype=torch.uint8, device=p3.device)
+            sc3 = (w3.inv_scale * scale3).contiguous()           # exact: the row scale is a power of two
+            check(_L().gom_ffn_fused_image(_p(p3), p3.stride(0), p3.stride(1), _p(sc3), _p(shift3.contiguous()), _p(p1), p1.stride(0),
+                                           p1.stride(1), 256, self.c4, _p(self.image), nbytes, _stream()), "gom_ffn_fused_image")
+            self.sc1 = (scale1 * w1.inv_scale).contiguous()
+            self.sh1 = shift1.contiguous()
+            return
         nbytes = _L().gom_bneck_image_bytes(self.k1, self.c4, self.mp)
         if nbytes < 0:
             raise _lib_mod.GomError("fused bottleneck kernel does not serve %d -> %d -> %d" % (self.k1, self.c4, self.mp))
@@ -653,10 +668,14 @@ class BneckFused:
         self.sh1 = shift1.contiguous()
 
     @staticmethod
+    def _wide(k1, c4, mp):
+        return bool(BNECK2) and k1 == 256 and mp == 256 and c4 == 1024
+
+    @staticmethod
     def serves(w3, w1):
         return (BNECK_FUSED and GEMM_MODE == "f16x3" and isinstance(w3, SplitWeight) and isinstance(w1, SplitWeight)
                 and w3.kind == "f16x3" and w1.kind == "f16x3" and w1.K == w3.N
-                and _L().gom_bneck_image_bytes(w3.K, w3.N, w1.N) > 0)
+                and (BneckFused._wide(w3.K, w3.N, w1.N) or _L().gom_bneck_image_bytes(w3.K, w3.N, w1.N) > 0))
 
 
 def bneck_fused(a, blk, R):
@@ -671,8 +690,9 @@ def bneck_fused(a, blk, R):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_L().gom_bneck_f32(_p(a), k1, _p(blk.image), _p(R), blk.c4, _p(blk.sc1), _p(blk.sh1), _p(X), blk.c4, _p(Y1), blk.mp, M,
-                             blk.k1, blk.c4, blk.mp, _p(range_flag(a.device)), _stream()), "gom_bneck_f32")
+    fn = _L().gom_bneck2_f32 if blk.v2 else _L().gom_bneck_f32
+    check(fn(_p(a), k1, _p(blk.image), _p(R), blk.c4, _p(blk.sc1), _p(blk.sh1), _p(X), blk.c4, _p(Y1), blk.mp, M,
+             blk.k1, blk.c4, blk.mp, _p(range_flag(a.device)), _stream()), "gom_bneck2_f32" if blk.v2 else "gom_bneck_f32")
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * blk.c4 * (blk.k1 + blk.mp), 4.0 * M * (blk.k1 + 2 * blk.c4 + blk.mp) + blk.image.numel(),

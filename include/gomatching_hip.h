@@ -220,6 +220,11 @@ int gom_bneck_image(const void* w3_planes, long w3_plane_stride, int ld3, const 
                     long image_bytes, void* stream);
 int gom_bneck_f32(const float* A, int lda, const void* image, const float* R, int ldr, const float* scale1, const float* shift1,
                   float* X, int ldx, float* Y1, int ldy, int M, int k1, int c4, int mp, int* flag, void* stream);
+/* The same pair for the wide stage (res4: k1 = 256, c4 = 1024, mp = 256) on csrc/bneck2.hip: 64-pixel tiles, 16x16x32 MFMA, two
+ * workgroups per CU.  `image` = gom_ffn_fused_image(conv3 planes [c4, 256], its inverse row scales x the BN scale, the BN shift, conv1'
+ * planes [256, c4], 256, c4).  Arguments as gom_bneck_f32. */
+int gom_bneck2_f32(const float* A, int lda, const void* image, const float* R, int ldr, const float* scale1, const float* shift1,
+                   float* X, int ldx, float* Y1, int ldy, int M, int k1, int c4, int mp, int* flag, void* stream);
 
 /* The two self-attention blocks of a DeepSolo composite decoder layer, each as ONE launch (csrc/dec_attn.hip), replacing
  * nn.MultiheadAttention + residual + LayerNorm of deformable_transformer.py:386-394 (inter = 0: attention over the
