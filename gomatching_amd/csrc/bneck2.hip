@@ -33,18 +33,23 @@ __device__ __forceinline__ f32x4 mfma16(const half8 a, const half8 b, const f32x
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-constexpr int K1 = 256, MP = 256;                        // conv3 inputs, conv1' outputs
 constexpr int CH = 32;                                   // X channels per chunk = one 128-byte line per pixel
 constexpr int FRAG = 1024;
-constexpr int WA_FRAGS = (K1 / 32) * (CH / 16) * 2;      // first product: k-steps x channel groups x planes = 32
-constexpr int WB_FRAGS = (MP / 16) * 2;                  // second product: output groups x planes = 32
-constexpr int STAGE_FRAGS = WA_FRAGS + WB_FRAGS + 1;     // gom_ffn_fused_image's stage: 65 fragments
-constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG;
-constexpr int RING_BYTES = 2 * STAGE_BYTES;
 constexpr int WAVES = 8, BM = 16 * WAVES;
 constexpr int XT_ROW = 36;                               // floats per pixel row of a wave's transpose tile (32 + 4: conflict-free b128)
 constexpr int XT_BYTES = 16 * XT_ROW * 4;
-constexpr int LDS_BYTES = RING_BYTES + WAVES * XT_BYTES;
+// K1 = conv3's inputs (256: res4; 128: the res3 -> res4 transition), MP = conv1' outputs (256)
+template <int K1, int MP>
+struct Cfg2 {
+    static constexpr int WA_FRAGS = (K1 / 32) * (CH / 16) * 2;   // first product: k-steps x channel groups x planes
+    static constexpr int WB_FRAGS = (MP / 16) * 2;               // second product: output groups x planes
+    static constexpr int STAGE_FRAGS = WA_FRAGS + WB_FRAGS + 1;  // (K1 = MP = 256: gom_ffn_fused_image's stage, 65 fragments)
+    static constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG;
+    static constexpr int RING_BYTES = 2 * STAGE_BYTES;
+    static constexpr int SCRATCH_BYTES = WAVES * 16 * 128 * 4;   // the prologue's rows -> fragments scratch (64 KB)
+    static constexpr int LDS_BYTES = (RING_BYTES > STAGE_BYTES + SCRATCH_BYTES ? RING_BYTES : STAGE_BYTES + SCRATCH_BYTES) + WAVES * XT_BYTES;
+    static constexpr int XT_OFF = LDS_BYTES - WAVES * XT_BYTES;
+};
 
 struct B2Args {
     const float* A;
@@ -62,14 +67,17 @@ __device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)byte_offset, 0, 0, 0);
 }
 
+template <int K1, int MP>
 __global__ __launch_bounds__(512, 1) void bneck2_kernel(const B2Args p) {
+    using C = Cfg2<K1, MP>;
+    constexpr int WA_FRAGS = C::WA_FRAGS, WB_FRAGS = C::WB_FRAGS, STAGE_FRAGS = C::STAGE_FRAGS, STAGE_BYTES = C::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fn = lane & 15, fg = lane >> 4;
     const long row0 = (long)blockIdx.x * BM + wave * 16;
     const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, p.chunks * STAGE_BYTES, 0x00020000);
-    float* xt = reinterpret_cast<float*>(smem + RING_BYTES + wave * XT_BYTES);
+    float* xt = reinterpret_cast<float*>(smem + C::XT_OFF + wave * XT_BYTES);
 
     // R in and X out move as whole 128-byte lines: lane l handles 16-byte piece (l & 7) of pixels (l >> 3) + 8 i of the wave's 16
     long crow[2];
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(512, 1) void bneck2_kernel(const B2Args p) {
         float* scratch = reinterpret_cast<float*>(smem + STAGE_BYTES) + wave * (16 * 128);   // the ring's second slot: free until chunk 0 requests stage 1
         const int pc = lane & 31, r0 = lane >> 5;
 #pragma unroll
-        for (int part = 0; part < 2; ++part) {
+        for (int part = 0; part < K1 / 128; ++part) {
             f32x4 v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -174,12 +182,21 @@ __global__ __launch_bounds__(512, 1) void bneck2_kernel(const B2Args p) {
         _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) acc1[h_] = mfma16(src[4 * i_ + 2 * h_], xf[1][s_], acc1[h_]);      \
         _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) acc1[h_] = mfma16(src[4 * i_ + 2 * h_], xf[0][s_], acc1[h_]);      \
     }
+            // (DMA pieces of this wave: fragments wave, wave + 8, ... below STAGE_FRAGS - 1; the last fragment went out above)
+#define B2_DMAX(i) if ((i) * WAVES < WA_FRAGS + WB_FRAGS) B2_DMA(i)
             B2_LOAD(fa, 0)
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            B2_LOAD(fb, 1) B2_GEMM1(fa, 0) B2_DMA(0) B2_DMA(1) B2_PIN()
-            B2_LOAD(fa, 2) B2_GEMM1(fb, 1) B2_DMA(2) B2_DMA(3) B2_PIN()
-            B2_LOAD(fb, 3) B2_GEMM1(fa, 2) B2_DMA(4) B2_DMA(5) B2_PIN()
-            B2_GEMM1(fb, 3) B2_DMA(6) B2_DMA(7)
+            if constexpr (K1 == 256) {
+                B2_LOAD(fb, 1) B2_GEMM1(fa, 0) B2_DMAX(0) B2_DMAX(1) B2_PIN()
+                B2_LOAD(fa, 2) B2_GEMM1(fb, 1) B2_DMAX(2) B2_DMAX(3) B2_PIN()
+                B2_LOAD(fb, 3) B2_GEMM1(fa, 2) B2_DMAX(4) B2_DMAX(5) B2_PIN()
+                B2_GEMM1(fb, 3) B2_DMAX(6) B2_DMAX(7)
+            } else {
+                static_assert(K1 == 128 || K1 == 256, "K1");
+                B2_LOAD(fb, 1) B2_GEMM1(fa, 0) B2_DMAX(0) B2_DMAX(1) B2_DMAX(2) B2_PIN()
+                B2_GEMM1(fb, 1) B2_DMAX(3) B2_DMAX(4) B2_DMAX(5)
+            }
+#undef B2_DMAX
 #undef B2_GEMM1
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -235,6 +252,7 @@ __global__ __launch_bounds__(512, 1) void bneck2_kernel(const B2Args p) {
 #define B2_PIN0()                                         \
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            static_assert(MP == 256, "MP");
             B2_LOAD(fa, 0)
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
             B2_LOAD(fb, 1) B2_GEMM2(fa, 0) B2_PIN0()
@@ -273,13 +291,72 @@ __global__ __launch_bounds__(512, 1) void bneck2_kernel(const B2Args p) {
     if ((!(amax <= 65504.f) || !(chk == 0.f)) && p.flag) atomicOr(p.flag, 1);
 }
 
+// Fragment-linear weight image, per chunk c of 32 X-channels; element j of lane l = (m, kg) = (l & 15, l >> 4):
+//   f = 4 s + 2 Hh + p       (s < K1 / 32, Hh < 2)  : plane p of W3s[32 c + 16 Hh + m][32 s + 8 kg + j]
+//   f = WA + 2 t + p         (t < MP / 16)          : plane p of W1s[16 t + m][32 c + 16 (j >> 2) + 4 kg + (j & 3)]
+//   f = WA + WB                                     : floats 0..31 = BN scale x 1 / row scale of W3s, 32..63 = BN shift of the chunk
+__global__ __launch_bounds__(256) void bneck2_image_kernel(const unsigned short* __restrict__ p3, long ps3, int ld3,
+                                                           const float* __restrict__ inv3, const float* __restrict__ scale3,
+                                                           const float* __restrict__ shift3, const unsigned short* __restrict__ p1,
+                                                           long ps1, int ld1, int k1, int c4, int mp, unsigned short* __restrict__ img) {
+    const int wa = (k1 / 32) * 4, wb = (mp / 16) * 2, sf = wa + wb + 1;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)(c4 / CH) * sf * 512;
+    if (i >= total) return;
+    const int e = (int)(i % 512), f = (int)((i / 512) % sf), c = (int)(i / (512L * sf));
+    const int l = e >> 3, j = e & 7, m = l & 15, kg = l >> 4;
+    if (f < wa) {
+        const int s_ = f >> 2, hh = (f >> 1) & 1, pl = f & 1;
+        img[i] = p3[pl * ps3 + (size_t)(CH * c + 16 * hh + m) * ld3 + 32 * s_ + 8 * kg + j];
+    } else if (f < wa + wb) {
+        const int id = f - wa, t = id >> 1, pl = id & 1;
+        img[i] = p1[pl * ps1 + (size_t)(16 * t + m) * ld1 + CH * c + 16 * (j >> 2) + 4 * kg + (j & 3)];
+    } else {
+        const int fi = e >> 1;
+        float v = 0.f;
+        if (fi < CH) v = inv3[CH * c + fi] * (scale3 ? scale3[CH * c + fi] : 1.f);   // exact: the row scale is a power of two
+        else if (fi < 2 * CH) v = shift3 ? shift3[CH * c + fi - CH] : 0.f;
+        const unsigned bits = __builtin_bit_cast(unsigned, v);
+        img[i] = (unsigned short)((e & 1) ? (bits >> 16) : (bits & 0xffffu));
+    }
+}
+
+bool served2(int k1, int c4, int mp) { return c4 == 4 * k1 && mp == 256 && (k1 == 256 || k1 == 128); }
+
+template <int K1, int MP>
+int launch2(const B2Args& a, hipStream_t s) {
+    using C = Cfg2<K1, MP>;
+    auto kern = bneck2_kernel<K1, MP>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(a.M, BM)), dim3(64 * WAVES), C::LDS_BYTES, s, a);
+    return gom_launch_status();
+}
+
 }  // namespace
 
-/* image: gom_ffn_fused_image(conv3 planes [1024, 256], its inverse row scales x BN scale, BN shift, conv1' planes [256, 1024]) */
+extern "C" long gom_bneck2_image_bytes(int k1, int c4, int mp) {
+    if (!served2(k1, c4, mp)) return -1;
+    return (long)(c4 / CH) * ((k1 / 32) * 4 + (mp / 16) * 2 + 1) * FRAG;
+}
+
+extern "C" int gom_bneck2_image(const void* w3_planes, long w3_plane_stride, int ld3, const float* w3_inv_scale, const float* scale3,
+                                const float* shift3, const void* w1_planes, long w1_plane_stride, int ld1, int k1, int c4, int mp,
+                                void* image, long image_bytes, void* stream) {
+    GOM_CHECK_ARG(w3_planes && w3_inv_scale && w1_planes && image && served2(k1, c4, mp) && ld3 >= k1 && ld1 >= c4);
+    GOM_CHECK_ARG(image_bytes >= gom_bneck2_image_bytes(k1, c4, mp));
+    const long total = (long)(c4 / CH) * ((k1 / 32) * 4 + (mp / 16) * 2 + 1) * 512;
+    hipLaunchKernelGGL(bneck2_image_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)w3_planes, w3_plane_stride, ld3, w3_inv_scale, scale3, shift3,
+                       (const unsigned short*)w1_planes, w1_plane_stride, ld1, k1, c4, mp, (unsigned short*)image);
+    return gom_launch_status();
+}
+
+/* image: gom_bneck2_image */
 extern "C" int gom_bneck2_f32(const float* A, int lda, const void* image, const float* R, int ldr, const float* scale1,
                               const float* shift1, float* X, int ldx, float* Y1, int ldy, int M, int k1, int c4, int mp, int* flag,
                               void* stream) {
-    GOM_CHECK_ARG(A && image && R && scale1 && shift1 && X && Y1 && M >= 0 && k1 == K1 && mp == MP && c4 > 0 && (c4 % CH) == 0);
+    GOM_CHECK_ARG(A && image && R && scale1 && shift1 && X && Y1 && M >= 0 && served2(k1, c4, mp));
     GOM_CHECK_ARG(lda >= k1 && ldr >= c4 && ldx >= c4 && ldy >= mp && (lda % 4) == 0 && (ldr % 4) == 0 && (ldx % 4) == 0 && (ldy % 4) == 0);
     GOM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)R % 16) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y1 % 16) == 0 &&
                   ((uintptr_t)image % 16) == 0 && ((uintptr_t)scale1 % 16) == 0 && ((uintptr_t)shift1 % 16) == 0);
@@ -287,8 +364,6 @@ extern "C" int gom_bneck2_f32(const float* A, int lda, const void* image, const 
     B2Args a{};
     a.A = A; a.img = (const unsigned char*)image; a.R = R; a.sc1 = scale1; a.sh1 = shift1; a.X = X; a.Y1 = Y1; a.flag = flag;
     a.lda = lda; a.ldr = ldr; a.ldx = ldx; a.ldy = ldy; a.M = M; a.chunks = c4 / CH;
-    hipError_t e = hipFuncSetAttribute((const void*)bneck2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-    hipLaunchKernelGGL(bneck2_kernel, dim3((unsigned)cdiv(M, BM)), dim3(64 * WAVES), LDS_BYTES, (hipStream_t)stream, a);
-    return gom_launch_status();
+    if (k1 == 256) return launch2<256, 256>(a, (hipStream_t)stream);
+    return launch2<128, 256>(a, (hipStream_t)stream);
 }

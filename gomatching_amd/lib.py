@@ -53,6 +53,8 @@ SIGNATURES = {
     "gom_bneck_image_bytes": (L, [I, I, I]),
     "gom_bneck_image": (I, [P, L, I, P, P, P, P, L, I, I, I, I, P, L, P]),
     "gom_bneck_f32": (I, [P, I, P, P, I, P, P, P, I, P, I, I, I, I, I, P, P]),
+    "gom_bneck2_image_bytes": (L, [I, I, I]),
+    "gom_bneck2_image": (I, [P, L, I, P, P, P, P, L, I, I, I, I, P, L, P]),
     "gom_bneck2_f32": (I, [P, I, P, P, I, P, P, P, I, P, I, I, I, I, I, P, P]),
     "gom_dec_attn_image_bytes": (L, [I, I]),
     "gom_dec_attn_image": (I, [P, L, I, P, P, P, L, I, P, P, P, P, I, P, L, P]),

@@ -648,13 +648,12 @@ class BneckFused:
         p3, p1 = w3.planes, w1.planes
         self.v2 = BneckFused._wide(self.k1, self.c4, self.mp)
         if self.v2:
-            # res4 (256 -> 1024 -> 256): csrc/bneck2.hip, two workgroups per CU; its image IS the fused FFN kernel's (W1 := conv3,
-            # W2 := conv1'; the stage's last fragment carries 1 / row scale x BN scale | BN shift)
-            nbytes = _L().gom_ffn_fused_image_bytes(256, self.c4)
+            # res4 (256 -> 1024 -> 256) and the res3 -> res4 transition (128 -> 512 -> 256): csrc/bneck2.hip, 16-pixel waves, eight per
+            # workgroup sharing one weight ring
+            nbytes = _L().gom_bneck2_image_bytes(self.k1, self.c4, self.mp)
             self.image = torch.empty((nbytes,), dtype=torch.uint8, device=p3.device)
-            sc3 = (w3.inv_scale * scale3).contiguous()           # exact: the row scale is a power of two
-            check(_L().gom_ffn_fused_image(_p(p3), p3.stride(0), p3.stride(1), _p(sc3), _p(shift3.contiguous()), _p(p1), p1.stride(0),
-                                           p1.stride(1), 256, self.c4, _p(self.image), nbytes, _stream()), "gom_ffn_fused_image")
+            check(_L().gom_bneck2_image(_p(p3), p3.stride(0), p3.stride(1), _p(w3.inv_scale), _p(scale3), _p(shift3), _p(p1), p1.stride(0),
+                                        p1.stride(1), self.k1, self.c4, self.mp, _p(self.image), nbytes, _stream()), "gom_bneck2_image")
             self.sc1 = (scale1 * w1.inv_scale).contiguous()
             self.sh1 = shift1.contiguous()
             return
@@ -669,7 +668,7 @@ class BneckFused:
 
     @staticmethod
     def _wide(k1, c4, mp):
-        return bool(BNECK2) and k1 == 256 and mp == 256 and c4 == 1024
+        return bool(BNECK2) and _L().gom_bneck2_image_bytes(k1, c4, mp) > 0
 
     @staticmethod
     def serves(w3, w1):

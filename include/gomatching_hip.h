@@ -220,9 +220,13 @@ int gom_bneck_image(const void* w3_planes, long w3_plane_stride, int ld3, const 
                     long image_bytes, void* stream);
 int gom_bneck_f32(const float* A, int lda, const void* image, const float* R, int ldr, const float* scale1, const float* shift1,
                   float* X, int ldx, float* Y1, int ldy, int M, int k1, int c4, int mp, int* flag, void* stream);
-/* The same pair for the wide stage (res4: k1 = 256, c4 = 1024, mp = 256) on csrc/bneck2.hip: 64-pixel tiles, 16x16x32 MFMA, two
- * workgroups per CU.  `image` = gom_ffn_fused_image(conv3 planes [c4, 256], its inverse row scales x the BN scale, the BN shift, conv1'
- * planes [256, c4], 256, c4).  Arguments as gom_bneck_f32. */
+/* The same pair for the wide shapes (res4: k1 = 256, c4 = 1024, mp = 256; the res3 -> res4 transition: 128, 512, 256) on
+ * csrc/bneck2.hip: 16-pixel waves on the 16x16x32 MFMA shape, eight per workgroup (two per SIMD) sharing one weight ring.
+ * gom_bneck2_image / gom_bneck2_f32: arguments as gom_bneck_image / gom_bneck_f32 (gom_bneck2_image_bytes: -1 = shape not served). */
+long gom_bneck2_image_bytes(int k1, int c4, int mp);
+int gom_bneck2_image(const void* w3_planes, long w3_plane_stride, int ld3, const float* w3_inv_scale, const float* scale3,
+                     const float* shift3, const void* w1_planes, long w1_plane_stride, int ld1, int k1, int c4, int mp, void* image,
+                     long image_bytes, void* stream);
 int gom_bneck2_f32(const float* A, int lda, const void* image, const float* R, int ldr, const float* scale1, const float* shift1,
                    float* X, int ldx, float* Y1, int ldy, int M, int k1, int c4, int mp, int* flag, void* stream);
 

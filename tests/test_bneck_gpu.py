@@ -10,7 +10,7 @@ DEV = "cuda"
 @pytest.mark.parametrize("k1,mp,hw", [(64, 64, (13, 21)), (64, 128, (9, 30)), (128, 128, (12, 11)), (128, 256, (7, 19)),
                                       (64, 64, (125, 223)),
                                       # res4 (256 -> 1024 -> 256): csrc/bneck2.hip, 64-pixel tiles at two workgroups per CU
-                                      (256, 256, (1, 1)), (256, 256, (7, 19)), (256, 256, (63, 112))])
+                                      (256, 256, (1, 1)), (256, 256, (7, 19)), (256, 256, (63, 112)), (128, 256, (125, 223))])
 def test_fused_pair_equals_two_launches(k1, mp, hw):
     from gomatching_amd import ops
     g = torch.Generator().manual_seed(k1 + mp + hw[0])
@@ -31,7 +31,7 @@ def test_fused_pair_equals_two_launches(k1, mp, hw):
     ops.check_range_flag(dev)
     # X: the same products in the same order; the epilogue's fma contraction may differ in the last bit (bneck2.hip: k-steps of 32 on
     # the 16x16x32 shape -- fp32-class, another order)
-    assert float((X - X0).abs().max()) <= (1e-5 if k1 == 256 else 2e-6) * float(X0.abs().max())
+    assert float((X - X0).abs().max()) <= (1e-5 if blk.v2 else 2e-6) * float(X0.abs().max())
     # Y1: another summation order over c4 (accumulator order inside a 16-wide MFMA step)
     assert float((Y1 - Y0).abs().max()) <= 1e-5 * float(Y0.abs().max()) + 1e-6
     xr = torch.relu((a.double().cpu().view(-1, k1) @ w3.double().cpu().view(c4, k1).t()) * sc3.double().cpu() + sh3.double().cpu()

@@ -25,7 +25,7 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for k1, mp, hw in ((256, 256, (63, 112)), (64, 64, (250, 445)), (128, 128, (125, 223))):
+for k1, mp, hw in ((256, 256, (63, 112)), (128, 256, (125, 223)), (128, 128, (125, 223))):
     c4, B = 4 * k1, 8
     a = torch.randn(B, hw[0], hw[1], k1, generator=g).abs().to(DEV)
     R = torch.randn(B, hw[0], hw[1], c4, generator=g).to(DEV)
