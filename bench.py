@@ -43,7 +43,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha1()
     for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "proj_ln.hip", "msda.hip",
-                 "dec_attn.hip", "bneck_fused.hip", "conv3x3_patch.hip", "common.h"):
+                 "dec_attn.hip", "dec_tail.hip", "bneck_fused.hip", "bneck2.hip", "conv3x3_patch.hip", "common.h"):
         with open(os.path.join(ROOT, "gomatching_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -71,7 +71,9 @@ def ffn_traffic(calls):
     tail = pmc_traffic("ffn_fused_kernel<false,1>")
     if main is None:
         return None
-    return main + (0.5 * tail if tail is not None else 0.0)  # six encoder calls with a tail launch, six decoder calls without
+    # (round 5: the decoder's FFN blocks run inside the tail launch, csrc/dec_tail.hip -- every remaining call is an encoder call =
+    # the 128-row-tile launch + its half-height tail launch)
+    return main + (tail if tail is not None else 0.0)
 
 
 def build_model(cfg, device):
@@ -666,9 +668,11 @@ def main():
             "unit": "TFLOP/s", "frac": ff / (fd * 1e-3) / 1e12 / PEAKS["f16x3"][1], "traffic": ffn_traffic(len(ffn_prof)),
             "launches_per_step": len(ffn_prof) // PROFILE_STEPS, "avg_launch_us": fd * 1e3 / len(ffn_prof),
             "share_of_step_time": (fd / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
-            "note": "linear1 + ReLU + linear2 + residual + LayerNorm of every encoder / decoder layer in one call: 2 KB of HBM "
-                    "traffic per token instead of 13 (csrc/ffn_fused.hip).  avg_launch_us = HIP-event time of a CALL; an encoder call "
-                    "is two launches (2 304 tiles of 128 rows, then the last round as 39 half-height tiles: ffn_fused_kernel<false, 1>)"}
+            "note": "linear1 + ReLU + linear2 + residual + LayerNorm of every ENCODER layer in one call: 2 KB of HBM traffic per token "
+                    "instead of 13 (csrc/ffn_fused.hip).  avg_launch_us = HIP-event time of a CALL = two launches (2 304 tiles of 128 "
+                    "rows, then the last round as 39 half-height tiles: ffn_fused_kernel<false, 1>).  Rounds 2-4 averaged the six "
+                    "decoder calls (M = 20 000, ~85 us) into this object; from round 5 the decoder's FFN blocks run inside the tail "
+                    "launch (csrc/dec_tail.hip, `roofline_decoder_qside`), so launches_per_step is 6 and avg_launch_us an encoder call's"}
         both_ms, both_fl = dur_ms + fd, flops + ff
         k256_long = [p_ for p_ in k256_prof if int(p_[4].split(":")[1].split("x")[0]) > 65536]   # encoder-sized launches
         k256_prof = [p_ for p_ in k256_prof if p_ not in k256_long]
@@ -702,8 +706,8 @@ def main():
             pd = sum(p_[0].elapsed_time(p_[1]) for p_ in pl_prof)
             pb = sum(p_[3] for p_ in pl_prof)
             line["roofline_proj_ln"] = {
-                "bound": "hbm", "kernel": "proj_ln_kernel", "achieved": pb / (pd * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
-                "frac": pb / (pd * 1e-3) / 1e12 / 8.0, "traffic": pmc_traffic("proj_ln_kernel<0>") or pmc_traffic("proj_ln_kernel"),
+                "bound": "hbm", "kernel": "proj_ln2_kernel<FORM, 4> (64-row tiles, two workgroups per CU)" if getattr(ops, "PROJ_LN_V2", False) else "proj_ln_kernel<FORM>", "achieved": pb / (pd * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
+                "frac": pb / (pd * 1e-3) / 1e12 / 8.0, "traffic": pmc_traffic("proj_ln_kernel"),
                 "launches_per_step": len(pl_prof) // PROFILE_STEPS, "avg_launch_us": pd * 1e3 / len(pl_prof),
                 "share_of_step_time": (pd / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
                 "note": "out_proj + residual + LayerNorm of every attention block in one launch (csrc/proj_ln.hip): 3 KB of "
@@ -766,7 +770,7 @@ def main():
         bd = sum(p_[0].elapsed_time(p_[1]) for p_ in bn_prof)
         bb, bf = sum(p_[3] for p_ in bn_prof), sum(p_[2] for p_ in bn_prof)
         line["roofline_bneck"] = {
-            "bound": "hbm", "kernel": "bneck_kernel<K1,MP,OCC>", "achieved": bb / (bd * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
+            "bound": "hbm", "kernel": "bneck_kernel<K1,MP,OCC> (res2, res3) + bneck2_kernel<K1,256> (res4 and the res3 -> res4 transition)", "achieved": bb / (bd * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
             "frac": bb / (bd * 1e-3) / 1e12 / 8.0, "traffic": pmc_traffic("bneck_kernel"),
             "mfma_view": {"achieved": bf / (bd * 1e-3) / 1e12, "peak": PEAKS["f16x3"][1], "unit": "TFLOP/s",
                           "frac": bf / (bd * 1e-3) / 1e12 / PEAKS["f16x3"][1]},

@@ -23,8 +23,10 @@ def per_kernel(path, counter, api_grids):
                 agg[name + " [grid %d]" % int(r["Grid_Size"])].append(float(r["Counter_Value"]))
             if name.startswith("msda_window_kernel<"):
                 agg["msda_window_kernel"].append(float(r["Counter_Value"]))
-            if name.startswith("bneck_kernel<"):             # every instantiation of the fused bottleneck kernel together as well
+            if name.startswith("bneck_kernel<") or name.startswith("bneck2_kernel<"):   # every fused bottleneck launch together as well
                 agg["bneck_kernel"].append(float(r["Counter_Value"]))
+            if name.startswith("proj_ln_kernel<") or name.startswith("proj_ln2_kernel<"):   # both forms, all three FORMs
+                agg["proj_ln_kernel"].append(float(r["Counter_Value"]))
             if name.startswith("conv3x3_patch_kernel<"):
                 agg["conv3x3_patch_kernel"].append(float(r["Counter_Value"]))
             if name.startswith("gemm_f16x3_kernel<128,128,0,0") or name.startswith("gemm_bf16x6_kernel<128,128,0,0") or \
@@ -40,7 +42,7 @@ def kernel_source_hash():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha1()
     for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "proj_ln.hip", "msda.hip",
-                 "dec_attn.hip", "bneck_fused.hip", "conv3x3_patch.hip", "common.h"):
+                 "dec_attn.hip", "dec_tail.hip", "bneck_fused.hip", "bneck2.hip", "conv3x3_patch.hip", "common.h"):
         with open(os.path.join(root, "gomatching_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

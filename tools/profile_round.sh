@@ -2,7 +2,7 @@
 # Round profiles (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats, the two PMC passes, per-shape GEMM
 # trace.  Everything lands under gpurun_out/final/; copy what is judged into profiles/.
 #   usage: bash tools/profile_round.sh [tag]
-tag=${1:-r04}
+tag=${1:-r05}
 out=gpurun_out/final_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -30,4 +30,6 @@ for cfg in "1 0" "4 0" "8 0" "8 32"; do
   set -- $cfg
   timeout 200 python3 bench.py --emulate-world $1 --tracker-cus $2 --steps 6 --warmup 2 --no-alt-backends --no-cpu-baseline --no-config-legs > $out/emu_w$1_cu$2.json 2> $out/emu.err
 done
+# ... and with every rank scoring every frame pair (rounds 1-4) instead of its own share + the second all-gather
+timeout 200 python3 bench.py --emulate-world 8 --tracker-cus 32 --replicate-short-term --steps 6 --warmup 2 --no-alt-backends --no-cpu-baseline --no-config-legs > $out/emu_w8_cu32_replicated.json 2> $out/emu.err
 bash tools/ablation.sh > $out/${tag}_ablation_same_box.log 2>&1
