@@ -127,7 +127,16 @@ BUILTIN = {
     "icdar15": os.path.join(_HERE, "configs", "gom_icdar15.yaml"),
     "pp_dstext": os.path.join(_HERE, "configs", "gompp_dstext.yaml"),
     "bovtext": os.path.join(_HERE, "configs", "gom_bovtext.yaml"),
+    # the reference's other five configs/*.yaml (the same inference-path keys; tests/test_all_configs_gpu.py)
+    "dstext": os.path.join(_HERE, "configs", "gom_dstext.yaml"),
+    "artvideo": os.path.join(_HERE, "configs", "gom_artvideo.yaml"),
+    "pp_artvideo": os.path.join(_HERE, "configs", "gompp_artvideo.yaml"),
+    "pp_icdar15": os.path.join(_HERE, "configs", "gompp_icdar15.yaml"),
+    "pp_bovtext": os.path.join(_HERE, "configs", "gompp_bovtext.yaml"),
 }
+REFERENCE_YAML = {"icdar15": "GoMatching_ICDAR15.yaml", "pp_dstext": "GoMatching_PP_DSText.yaml", "bovtext": "GoMatching_BOVText.yaml",
+                  "dstext": "GoMatching_DSText.yaml", "artvideo": "GoMatching_ArTVideo.yaml", "pp_artvideo": "GoMatching_PP_ArTVideo.yaml",
+                  "pp_icdar15": "GoMatching_PP_ICDAR15.yaml", "pp_bovtext": "GoMatching_PP_BOVText.yaml"}
 
 
 def setup_cfg(config_file=None, opts=(), builtin=None):

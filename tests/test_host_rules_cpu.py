@@ -63,3 +63,33 @@ def test_pmc_reduction_splits_the_dominant_kernels_populations(tmp_path):
         assert bench.pmc_traffic(key) is None                # counters of another build are never printed
     else:
         assert bench.pmc_traffic(key) == rec[key]["hbm_bytes_per_launch"]
+
+
+def test_builtin_configs_cover_the_reference_yamls():
+    """The eight builtin configs = the inference-path keys of the reference's eight configs/*.yaml (values transcribed from them; when
+    /root/reference is present -- the build container -- the yamls themselves are parsed and compared)."""
+    import os
+    from gomatching_amd.config import BUILTIN, REFERENCE_YAML, setup_cfg
+    want = {  # head, rescoring, queries, vocabulary, score threshold, min / max size, NMS threshold
+        "icdar15": ("LSTMatcher", True, 100, 37, 0.3, 1000, 3000, 0.5), "pp_icdar15": ("SHA_FFN_CRSATTN", True, 100, 37, 0.3, 1000, 3000, 0.5),
+        "dstext": ("LSTMatcher", False, 300, 37, 0.5, 1280, 3000, 0.3), "pp_dstext": ("SHA_FFN_CRSATTN", False, 300, 37, 0.5, 1280, 3000, 0.3),
+        "bovtext": ("LSTMatcher", False, 100, 5462, 0.5, 1000, 2400, 0.3), "pp_bovtext": ("SHA_FFN_CRSATTN", False, 100, 5462, 0.5, 1000, 2400, 0.3),
+        "artvideo": ("LSTMatcher", True, 100, 37, 0.5, 1280, 3000, 0.3), "pp_artvideo": ("SHA_FFN_CRSATTN", True, 100, 37, 0.5, 1280, 3000, 0.3)}
+    assert sorted(BUILTIN) == sorted(want) == sorted(REFERENCE_YAML)
+
+    def keys(c):
+        T = c.MODEL.TRANSFORMER
+        return (c.MODEL.ROI_HEADS.NAME, bool(c.MODEL.ROI_HEADS.WITH_RESR), T.NUM_QUERIES, T.VOC_SIZE, T.INFERENCE_TH_TEST,
+                c.INPUT.MIN_SIZE_TEST, c.INPUT.MAX_SIZE_TEST, c.VIDEO_TEST.NMS_THRESH)
+
+    def more(c):
+        A = c.MODEL.ASSO_HEAD
+        return (A.ASSO_THRESH_TEST, A.NUM_WEIGHT_LAYERS, A.NUM_FC, A.NO_POS_EMB, c.INPUT.VIDEO.TEST_LEN, c.INPUT.FORMAT,
+                tuple(sorted(dict(c.VIDEO_TEST).items())))
+    for name, w in want.items():
+        c = setup_cfg(builtin=name)
+        assert keys(c) == w, name
+        ref = os.path.join("/root/reference/configs", REFERENCE_YAML[name])
+        if os.path.exists(ref):
+            r = setup_cfg(ref)
+            assert keys(r) == w and more(r) == more(c), name
