@@ -809,6 +809,16 @@ def main():
         # ctrl-point MLP 2 x (d x d) + d x 2
         qside = 2.0 * rows * d_ * (2 * d_ + 2 * 4 * d_ + 384 + d_ + 2 * F_ + 2 * d_ + 2) * L_
         dd = sum(p_[0].elapsed_time(p_[1]) for p_ in dec_prof) / PROFILE_STEPS * 1e-3
+        def pipe_busy(kind, us_per_launch):
+            """Static MFMA work of the decoder's launches per wave (see csrc/dec_attn.hip, dec_tail.hip) against their duration."""
+            wgs = {"decattn intra": (rows // T_.NUM_POINTS + 3) // 4, "decattn inter": FRAMES_PER_GPU * T_.NUM_POINTS,
+                   "decattn inter+raw": FRAMES_PER_GPU * T_.NUM_POINTS, "dectail": (rows + 127) // 128}
+            cyc = {"decattn intra": (32 * 48 + 8 * 12) * 32, "decattn inter": (32 * 48 + 8 * 48) * 32,
+                   "decattn inter+raw": (44 * 48 + 8 * 48) * 32, "dectail": (4 + F_ // 32 + 8 + 8 * (L_ - 1) / L_) * 192 * 16}     # (the last layer's launch has no ref_point_head block)
+            if kind not in cyc or us_per_launch <= 0:
+                return {}
+            return {"mfma_cycles_per_wave": cyc[kind], "matrix_pipe_busy": cyc[kind] / (us_per_launch * 2400.0),
+                    "cus_with_work": min(1.0, wgs[kind] / 256.0)}
         kinds = {}
         for p_ in dec_prof:
             k_ = p_[4].split(":")[0] if ":" in p_[4] else ("ffn" if p_[4].startswith("ffn") else "tile / fp32 GEMM")
@@ -824,8 +834,13 @@ def main():
             "frac": qside / dd / 1e12 / PEAKS["f16x3"][1],
             "algorithmic_gflop_per_frame": qside / FRAMES_PER_GPU / 1e9, "launches_per_step": len(dec_prof) // PROFILE_STEPS,
             "us_per_step": dd * 1e6, "share_of_step_time": dd * 1e3 / (elapsed / args.steps * 1e3),
-            "by_kernel_us_per_step": {k_: {"launches": v_[0] // PROFILE_STEPS, "us": v_[1] * 1e3 / PROFILE_STEPS}
+            "by_kernel_us_per_step": {k_: dict({"launches": v_[0] // PROFILE_STEPS, "us": v_[1] * 1e3 / PROFILE_STEPS},
+                                           **pipe_busy(k_, v_[1] * 1e3 / max(v_[0], 1)))
                                       for k_, v_ in sorted(kinds.items())},
+            "pipe_busy_note": "mfma_cycles_per_wave = the launch's MFMA instructions per wave (static count, csrc) x their pipe cycles (32 "
+                              "for 32x32x16, 16 for 16x16x32); matrix_pipe_busy = that over the launch's duration at the nominal 2.4 GHz "
+                              "(a LOWER bound of the busy fraction of a SIMD that holds a wave: the chip clocks at or below 2.4 GHz); "
+                              "cus_with_work = one-per-CU workgroups of the launch / 256.  The chip fraction of a launch is the product",
             "note": "the six composite decoder layers' Q-side nn.Linear products (44.25 GFLOP per frame at 100 queries) over the "
                     "summed HIP-event time of EVERY launch that performs one of them -- the fused self-attention blocks "
                     "(csrc/dec_attn.hip) are counted whole, attention cores and LayerNorms included; MSDA sampling, the sine "
