@@ -7,6 +7,7 @@
 // generic element strides so the seq-first / batch-swapped views of the reference need no copies.
 // One workgroup = QT query rows x all keys; the score rows live in LDS (no HBM round trip).
 #include "common.h"
+#include "tracker_tasks.h"
 
 namespace {
 
@@ -194,53 +195,18 @@ __global__ __launch_bounds__(512) void mha_rows_kernel(const float* __restrict__
     }
 }
 
-// Wave-per-query-row form for the matcher transformers' TINY problems (head_dim 128, at most 64 keys: the long-term match of
-// a frame sees 9-53 detections in its window, roi_heads/transformer.py:208,287).  The tile kernel above runs such a problem as
-// `heads` workgroups with five barriers and three staged phases: 25 us of latency for microseconds of work.  Here one wave
-// owns one (batch, head, query row): lane j scores key j (sequential fmaf over the 128 channels, q pre-scaled -- the tile
-// kernel's chain), max / sum are 64-lane butterflies, and the output row is accumulated over the keys in ascending order with
-// p_j read from lane j as a scalar: the same arithmetic, value for value, as mha_core_kernel, without LDS or barriers.
+// Wave-per-query-row form for the matcher transformers' TINY problems (head_dim 128, at most 64 keys): one wave owns one
+// (batch, head, query row) -- gom_tasks::mha_tiny128_task (tracker_tasks.h; the fused match kernel runs the same tasks).
 __global__ __launch_bounds__(256) void mha_tiny128_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                           const float* __restrict__ v, float* __restrict__ o, int Lq, int Lk,
                                                           int inner, int heads, long q_bo, long q_bi, long q_ss, long k_bo,
                                                           long k_bi, long k_ss, long v_bo, long v_bi, long v_ss, long o_bo,
                                                           long o_bi, long o_ss, float scale, long total) {
-    constexpr int HD = 128;
     const int lane = threadIdx.x & 63;
     const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= total) return;
-    const int i = (int)(w % Lq), h = (int)((w / Lq) % heads);
-    const long b = w / ((long)Lq * heads), bo = b / inner, bi = b % inner;
-    const float* qr = q + bo * q_bo + bi * q_bi + (long)i * q_ss + h * HD;
-    const float* kb = k + bo * k_bo + bi * k_bi + h * HD;
-    const float* vb = v + bo * v_bo + bi * v_bi + h * HD;
-    const int j = lane < Lk ? lane : Lk - 1;                 // idle lanes recompute the last key (discarded)
-    const float* kr = kb + (long)j * k_ss;
-    float s = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < HD; d += 4) {
-        const f32x4 qv = *reinterpret_cast<const f32x4*>(qr + d) * scale;
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + d);
-        s = fmaf(qv[0], kv[0], s);
-        s = fmaf(qv[1], kv[1], s);
-        s = fmaf(qv[2], kv[2], s);
-        s = fmaf(qv[3], kv[3], s);
-    }
-    if (lane >= Lk) s = -INFINITY;
-    const float mx = wave_max(s);
-    const float e = lane < Lk ? expf(s - mx) : 0.f;
-    const float inv = 1.f / wave_sum(e);
-    const float p = e * inv;
-    float o0 = 0.f, o1 = 0.f;
-    for (int jj = 0; jj < Lk; ++jj) {
-        const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), jj));
-        const float* vr = vb + (long)jj * v_ss;
-        o0 = fmaf(pj, vr[lane], o0);
-        o1 = fmaf(pj, vr[lane + 64], o1);
-    }
-    float* orow = o + bo * o_bo + bi * o_bi + (long)i * o_ss + h * HD;
-    orow[lane] = o0;
-    orow[lane + 64] = o1;
+    gom_tasks::mha_tiny128_task(q, k, v, o, Lq, Lk, inner, heads, q_bo, q_bi, q_ss, k_bo, k_bi, k_ss, v_bo, v_bi, v_ss, o_bo, o_bi,
+                                o_ss, scale, w, lane);
 }
 
 template <int HD, int QT>

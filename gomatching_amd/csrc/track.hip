@@ -4,6 +4,7 @@
 //   lstmatcher.py:373-381            _activate_asso (per-frame softmax with a zero background logit)
 //   gom_lstmatcher.py:429-445,510-547 trajectory score, last-box IoU, time decay, centre-distance gate
 #include "common.h"
+#include "tracker_tasks.h"
 
 namespace {
 
@@ -23,20 +24,7 @@ __global__ __launch_bounds__(256) void gather_match_kernel(const float* __restri
                                                            float* __restrict__ src, float* __restrict__ qkv,
                                                            float* __restrict__ qdec) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long n_src = (long)N * d4, n_qkv = (long)N * 3 * d4, n_q = (long)n_k * d4;
-    if (i < n_src) {
-        const int r = (int)(i / d4), c = (int)(i % d4);
-        *reinterpret_cast<f32x4*>(src + i * 4) = *reinterpret_cast<const f32x4*>(pool + (size_t)rows[r] * ld_pool + c * 4);
-    } else if (i < n_src + n_qkv) {
-        const long k = i - n_src;
-        const int r = (int)(k / (3 * d4)), c = (int)(k % (3 * d4));
-        *reinterpret_cast<f32x4*>(qkv + k * 4) = *reinterpret_cast<const f32x4*>(proj + (size_t)rows[r] * ld_proj + c * 4);
-    } else if (i < n_src + n_qkv + n_q) {
-        const long k = i - n_src - n_qkv;
-        const int r = (int)(k / d4), c = (int)(k % d4);
-        *reinterpret_cast<f32x4*>(qdec + k * 4) =
-            *reinterpret_cast<const f32x4*>(proj + (size_t)rows[lo + r] * ld_proj + (3 * d4 + c) * 4);
-    }
+    gom_tasks::gather_match_item(pool, ld_pool, proj, ld_proj, rows, N, lo, n_k, d4, src, qkv, qdec, i);
 }
 
 // one wave per (query row, frame segment)
@@ -58,48 +46,8 @@ __global__ __launch_bounds__(256) void asso_activate_kernel(const float* __restr
     for (int j = lo + lane; j < hi; j += 64) out[(size_t)i * ld_out + j] = expf(row[j] - mx) / sum;
 }
 
-// meta layout (int32): nonk[Np] | col_of[Np] | last_idx[M] | k_inds[n_k]
-// Trajectory score of (current detection i, track m) from the activation row of i (global memory or LDS: generic pointer).
-// NOT inlined on purpose: the two-launch and the one-launch form call the same machine code, so they agree bit for bit
-// whatever the compiler would hoist, contract or reassociate in either caller.
-__device__ __noinline__ float track_score_one(const float* act_row, const int* __restrict__ meta, const float* __restrict__ decay,
-                                               const float* __restrict__ boxes, float img_w, float img_h, int i, int m, int Np,
-                                               int M, int with_iou, float max_center_dist) {
-    const int* nonk = meta;
-    const int* col_of = meta + Np;
-    const int* last_idx = meta + 2 * Np;
-    const int* k_inds = meta + 2 * Np + M;
-    const float* kb = boxes + (size_t)k_inds[i] * 4;
-    const float kx0 = kb[0] / img_w, ky0 = kb[1] / img_h, kx1 = kb[2] / img_w, ky1 = kb[3] / img_h;
-    float s = 0.f;
-    bool any_valid = false;
-    const float kcx = (kx0 + kx1) / 2.f, kcy = (ky0 + ky1) / 2.f;
-    const float ks = (kx1 - kx0) * (kx1 - kx0) + (ky1 - ky0) * (ky1 - ky0);
-    for (int j = 0; j < Np; ++j) {
-        if (col_of[j] != m) continue;
-        float a = act_row[nonk[j]];
-        if (decay) a *= decay[j];
-        s += a;
-        if (max_center_dist > 0.f) {
-            const float* nb = boxes + (size_t)nonk[j] * 4;
-            const float nx0 = nb[0] / img_w, ny0 = nb[1] / img_h, nx1 = nb[2] / img_w, ny1 = nb[3] / img_h;
-            const float dx = kcx - (nx0 + nx1) / 2.f, dy = kcy - (ny0 + ny1) / 2.f;
-            if ((dx * dx + dy * dy) / (ks + 1e-8f) < max_center_dist) any_valid = true;
-        }
-    }
-    if (with_iou) {
-        const float* lb = boxes + (size_t)nonk[last_idx[m]] * 4;
-        const float lx0 = lb[0] / img_w, ly0 = lb[1] / img_h, lx1 = lb[2] / img_w, ly1 = lb[3] / img_h;
-        const float w = fmaxf(fminf(kx1, lx1) - fmaxf(kx0, lx0), 0.f);
-        const float h = fmaxf(fminf(ky1, ly1) - fmaxf(ky0, ly0), 0.f);
-        const float inter = w * h;
-        const float a1 = (kx1 - kx0) * (ky1 - ky0), a2 = (lx1 - lx0) * (ly1 - ly0);
-        const float iou = inter > 0.f ? inter / (a1 + a2 - inter) : 0.f;
-        s = fmaxf(s, iou);
-    }
-    if (max_center_dist > 0.f && !any_valid) s = 0.f;
-    return s;
-}
+// meta layout (int32): nonk[Np] | col_of[Np] | last_idx[M] | k_inds[n_k]; the score itself: gom_tasks::track_score_one (tracker_tasks.h)
+using gom_tasks::track_score_one;
 
 __global__ __launch_bounds__(256) void track_score_kernel(const float* __restrict__ act, int ld,
                                                           const int* __restrict__ meta, const float* __restrict__ decay,
@@ -122,21 +70,8 @@ __global__ __launch_bounds__(256) void asso_score_kernel(const float* __restrict
                                                          float img_w, float img_h, int n_k, int Np, int M, int with_iou,
                                                          float max_center_dist, float* __restrict__ traj) {
     extern __shared__ float act[];                           // [N] activations of detection i
-    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* row = logits + (size_t)i * ld;
-    for (int t = wave; t < T; t += 4) {
-        const int lo = offs[t], hi = offs[t + 1];
-        float mx = 0.f;                                      // the appended background logit
-        for (int j = lo + lane; j < hi; j += 64) mx = fmaxf(mx, row[j]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int j = lo + lane; j < hi; j += 64) sum += expf(row[j] - mx);
-        sum = wave_sum(sum) + expf(0.f - mx);
-        for (int j = lo + lane; j < hi; j += 64) act[j] = expf(row[j] - mx) / sum;
-    }
-    __syncthreads();
-    for (int m = threadIdx.x; m < M; m += 256)
-        traj[(size_t)i * M + m] = track_score_one(act, meta, decay, boxes, img_w, img_h, i, m, Np, M, with_iou, max_center_dist);
+    gom_tasks::asso_score_block(logits, ld, offs, T, meta, decay, boxes, img_w, img_h, Np, M, with_iou, max_center_dist, traj,
+                                (int)blockIdx.x, act, (int)threadIdx.x, 256);
 }
 
 // Short-term matching, all (previous, current) frame pairs of a clip in one launch (gom_lstmatcher.py:405-445 with the

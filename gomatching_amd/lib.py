@@ -150,6 +150,10 @@ SIGNATURES = {
     "gom_gather_match_f32": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P]),
     "gom_match_scores_proj_f32": (I, [P, I, P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
     "gom_tracker_set_projections": (I, [P, P, I]),
+    "gom_match_fused_serves": (I, [I, I, I, I, I, I, I, I]),
+    "gom_match_fused_set_grid": (I, [I]),
+    "gom_match_fused_f32": (I, [P, I, P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P, P, P, P, L, P]),
+    "gom_tracker_set_fused": (I, [I]),
     "gom_match_scores_f32": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
     "gom_tracker_create": (P, [I, F, I, I, I, F, P, I, P, I, I, I, I]),
     "gom_tracker_destroy": (None, [P]),

@@ -1734,6 +1734,35 @@ def match_scores(pool, rows, frame_offsets, meta, boxes, decay, N, T, lo, hi, nu
     return traj
 
 
+def match_scores_proj(pool, proj, rows, frame_offsets, meta, boxes, decay, N, T, lo, hi, num_tracks, enc, n_enc, dec, n_dec, d,
+                      heads, ffn, img_w, img_h, with_iou, max_center_dist, fused=False, desc=None):
+    """The match with hoisted projections (proj [pool rows, >= 4 d]: encoder-layer-0 in-projection | decoder-layer-0 query
+    projection of every pool row): `fused=False` the chain of 13 launches (gom_match_scores_proj_f32), `fused=True` the one-launch
+    form (gom_match_fused_f32, csrc/match_fused.hip) -- same bits.  `desc` = (pinned host int32 tensor, device int32 tensor): the
+    fused kernel first uploads the descriptor block the index arguments point into.  Returns traj [hi - lo, num_tracks]."""
+    n_k = hi - lo
+    nws = _L().gom_match_workspace_floats(N, n_k, d, ffn)
+    ws = torch.empty((nws,), dtype=_f32, device=pool.device)
+    traj = torch.empty((n_k, num_tracks), dtype=_f32, device=pool.device)
+    if not fused:
+        check(_L().gom_match_scores_proj_f32(_p(pool), pool.stride(0), _p(proj), proj.stride(0), _p(rows), _p(frame_offsets),
+                                             _p(meta), _p(boxes), _p(decay), N, T, lo, hi, num_tracks, enc, n_enc, dec, n_dec, d,
+                                             heads, ffn, float(img_w), float(img_h), 1 if with_iou else 0, float(max_center_dist),
+                                             _p(ws), nws, _p(traj), _stream()), "gom_match_scores_proj_f32")
+        return traj
+    sync = torch.zeros((2,), dtype=torch.int32, device=pool.device)
+    status = torch.zeros((1,), dtype=torch.int32, device=pool.device)
+    dh, dd, dw = (desc[0].data_ptr(), desc[1].data_ptr(), desc[0].numel()) if desc is not None else (None, None, 0)
+    check(_L().gom_match_fused_f32(_p(pool), pool.stride(0), _p(proj), proj.stride(0), _p(rows), _p(frame_offsets), _p(meta),
+                                   _p(boxes), _p(decay), N, T, lo, hi, num_tracks, enc, n_enc, dec, n_dec, d, heads, ffn,
+                                   float(img_w), float(img_h), 1 if with_iou else 0, float(max_center_dist), _p(ws), nws,
+                                   _p(traj), _p(sync), _p(status), dh, dd, dw, _stream()), "gom_match_fused_f32")
+    if int(status.item()) != 0:
+        raise _lib_mod.GomError("gom_match_fused_f32: the grid barrier timed out (more workgroups than resident slots)")
+    assert int(sync[0].item()) == 0                           # the arrival count is back at zero
+    return traj
+
+
 def linear_sum_assignment(cost):
     """Host LSA with SciPy-compatible tie-breaking; cost: 2-D numpy array."""
     cost = np.ascontiguousarray(cost, dtype=np.float64)
