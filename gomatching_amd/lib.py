@@ -72,6 +72,7 @@ SIGNATURES = {
     "gom_gemm_k256_image": (I, [P, L, I, P, P, I, I, P, L, P]),
     "gom_gemm_k256_f32": (I, [P, P, I, P, P, I, I, I, P, I, I, I, I, I, P, P]),
     "gom_gemm_k256_rp_f32": (I, [P, P, I, P, P, I, I, I, I, P, I, I, I, I, I, P, P]),
+    "gom_gemm_k256_rs_f32": (I, [P, P, I, P, P, I, I, I, P, I, I, P, I, I, I, I, I, P, P]),
     "gom_gemm_k256_set_lines": (None, [I]),
     "gom_gemm_k256_set_interleave": (None, [I]),
     "gom_stem_conv_pool_f32": (I, [P, P, L, I, P, P, P, P, I, I, I, P, P]),

@@ -287,6 +287,15 @@ int gom_gemm_k256_f32(const float* A, const float* A2, int lda, const void* imag
 int gom_gemm_k256_rp_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr, int r_cols,
                          int r_period, int relu, float* C, int ldc, int M, int N, int K, int col_groups, int* flag,
                          void* stream);
+/* ... the periodic residual in SEPARABLE form (round 5): row m is pixel q = m % r_period of a pyramid of num_levels (<= 4) maps,
+ * levels_hw [host, num_levels x 2] = (H_l, W_l) in raster order with sum H_l W_l = r_period; R [sum H_l + sum W_l, ldr] holds one
+ * row per map ROW of every level, then one row per map COLUMN of every level, and row m adds R[its map row] + R[its map column]
+ * to its first r_cols columns.  For the encoder's position term: PositionalEncoding2D (pos_encoding.py:62-82) puts a function of y
+ * alone in channels [0, 128) and of x alone in [128, 256), so pos W^T = Ty[y] + Tx[x]: 1 MB of tables that stay in L2 instead of a
+ * 57 MB table re-read once per frame of the batch (deformable_transformer.py:235-248).  Whole-line-store form only. */
+int gom_gemm_k256_rs_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr, int r_cols,
+                         int r_period, const int* levels_hw, int num_levels, int relu, float* C, int ldc, int M, int N, int K,
+                         int col_groups, int* flag, void* stream);
 void gom_gemm_k256_set_lines(int mode);
 /* Periodic residual, several periods (frames), long problem: workgroups take the row tiles frame-interleaved per XCD, so that the
  * table rows of a position are fetched into an XCD's L2 once for all frames (1 = on, 0 = index order = default: the interleave
