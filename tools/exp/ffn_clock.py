@@ -19,11 +19,11 @@ def build():
     def once(s, a, b):
         assert s.count(a) == 1, a
         return s.replace(a, b)
-    src = once(src, 'template <bool PLAIN>\n__global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {',
+    src = once(src, 'template <bool PLAIN, int RG = 2>\n__global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {',
                '__device__ unsigned long long g_stamp[4096 * 8];\n'
                '#define STAMP(i) if (blockIdx.x < 4096 && threadIdx.x == 0) { g_stamp[blockIdx.x * 8 + 2 * (i)] = __builtin_amdgcn_s_memtime(); '
                'g_stamp[blockIdx.x * 8 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); }\n'
-               'template <bool PLAIN>\n__global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {\n    STAMP(0)')
+               'template <bool PLAIN, int RG = 2>\n__global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {\n    STAMP(0)')
     src = once(src, '    constexpr unsigned OOB = 0x7FFF0000u;', '    STAMP(1)\n    constexpr unsigned OOB = 0x7FFF0000u;')
     src = once(src, '    // ---- epilogue: Y^T (row of X on the lane', '    STAMP(2)\n    // ---- epilogue: Y^T (row of X on the lane')
     src = once(src, '    if (bad && p.flag) atomicOr(p.flag, 1);', '    STAMP(3)\n    if (bad && p.flag) atomicOr(p.flag, 1);')
