@@ -1,7 +1,8 @@
 """Diagnostic build of the decoder attention kernels (csrc/dec_attn.hip): in-kernel cycles of a workgroup's prologue, of the
 weight-stage products, of the end-of-stage waits and barriers, and of everything between (attention, conversions, epilogue).
 Generated from the product source (s_memtime stamps); the product kernel carries none.
-    python tools/exp/dec_attn_clock.py --build   (here)        python tools/exp/dec_attn_clock.py   (GPU box)"""
+    python tools/exp/dec_attn_clock.py --build   (here)        python tools/exp/dec_attn_clock.py   (GPU box)
+STALE: the text anchors below match the kernel source before the RAW form's template and row loader (round 5); --build asserts until they are updated."""
 import ctypes
 import os
 import subprocess

@@ -1,7 +1,8 @@
 """Diagnostic build of the LDS-window MSDA kernel (csrc/msda.hip msda_window_kernel, single-buffer form): in-kernel cycles of a
 workgroup's window geometry, owner part, and per level the fill issue, the wait + barriers and the samples.  Generated from the
 product source (s_memtime stamps); the product kernel carries none.
-    python tools/exp/msda_window_clock.py --build   (here)        python tools/exp/msda_window_clock.py   (GPU box)"""
+    python tools/exp/msda_window_clock.py --build   (here)        python tools/exp/msda_window_clock.py   (GPU box)
+STALE: the text anchors below match the kernel source before the ADDR template parameter (round 4); --build asserts until they are updated."""
 import ctypes
 import os
 import subprocess
