@@ -118,9 +118,14 @@ def cpu_baseline(cfg, sd, shift, re_shift, frames_chw, orig_hw, gpu_res, gpu_id_
     sd[k] = sd[k] + shift
     if re_shift is not None:
         sd["roi_heads.rescoring_head.bias"] = sd["roi_heads.rescoring_head.bias"] + re_shift
+    # MatchLog: how close the clip's discrete tracker decisions sit to a flip -- smallest gap between the chosen assignment's total
+    # score and the best assignment with another outcome, smallest |score - threshold| over the chosen pairs
+    # (gom_lstmatcher.py:434-452, 521-554), in the oracle's traj.  Its ~n extra assignment solves per match are not the reference's
+    # work: the log times itself and that time is taken out of the baseline's
+    mlog = O.MatchLog()
     t0 = time.time()
-    ref, ref_idc = O.run_clip(sd, cfg, frames_chw, orig_hw=orig_hw)
-    dt = time.time() - t0
+    ref, ref_idc = O.run_clip(sd, cfg, frames_chw, orig_hw=orig_hw, log=mlog)
+    dt = time.time() - t0 - mlog.seconds
     parity = {"frames": len(ref), "id_count_cpu": int(ref_idc), "id_count_gpu": int(gpu_id_count),
               "detections_cpu": [len(r["instances"]) for r in ref],
               "detections_gpu": [len(r["instances"]) for r in gpu_res]}
@@ -138,7 +143,7 @@ def cpu_baseline(cfg, sd, shift, re_shift, frames_chw, orig_hw, gpu_res, gpu_id_
             mx["bd_px"] = max(mx["bd_px"], float((g.bd.cpu() - r["bd"]).abs().max()))
             mx["ctrl_px"] = max(mx["ctrl_px"], float((g.ctrl_points.cpu() - r["ctrl_points"]).abs().max()))
     parity.update({"track_ids_identical": ids_same, "recs_identical": recs_same, "max_abs_score": mx["score"],
-                   "max_abs_bd_px": mx["bd_px"], "max_abs_ctrl_px": mx["ctrl_px"]})
+                   "max_abs_bd_px": mx["bd_px"], "max_abs_ctrl_px": mx["ctrl_px"], "tracker_margins": mlog.summary()})
     n = len(frames_chw)
     return {"value": n / dt, "unit": "frames/sec", "cores": cores, "kind": "port",
             "sample": "the whole %d-frame clip of one step (1280x720 -> %dx%d) through oracle/gom_oracle.py run_clip: detector, "

@@ -535,7 +535,102 @@ def _lsa(cost):
     return linear_sum_assignment(cost.numpy())
 
 
-def run_short_term_match(sd, cfg, instances, id_count=None):
+class MatchLog:
+    """Margins of the tracker's DISCRETE decisions, and a way to let a near-tie fall the other way (test infrastructure).
+
+    A match (gom_lstmatcher.py:434-452 / :521-554) makes two kinds of decisions on its `traj` matrix: the linear-sum
+    assignment on -traj, and `traj[i, j] > thr_j` for every assigned pair.  For every match `decide` records
+      * `assign_gap`: total score of the optimal assignment minus that of the best assignment with a DIFFERENT outcome (found by
+        forbidding each optimal pair in turn and solving again: the second-best assignment lacks at least one of them);
+      * `thr_margin`: the smallest |traj[i, j] - thr_j| over the optimal pairs.
+    With `eps` > 0 the alternatives whose gap / margin is below eps are enumerated (`n_alt`), and `script` = {call index: k} makes
+    call number `index` take its k-th alternative (k >= 1) instead of the optimum: tests replay the clip with the HIP path's
+    decision forced at a near-tie and require every later id to follow (tests/helpers.py track_clip_tie_aware)."""
+
+    def __init__(self, eps=0.0, script=None):
+        self.eps = float(eps)
+        self.script = dict(script or {})
+        self.calls = []
+        self.seconds = 0.0                                             # time spent in here (bench.py takes it out of the CPU baseline)
+
+    @staticmethod
+    def _outcome(traj, thr, mi, mj, flip=None):
+        out = [-1] * traj.shape[0]
+        for i, j in zip(mi, mj):
+            ok = bool(traj[i, j] > thr[j])
+            if flip is not None and (int(i), int(j)) == flip:
+                ok = not ok
+            if ok:
+                out[int(i)] = int(j)
+        return tuple(out)
+
+    def decide(self, kind, frame, traj, thr, mi, mj):
+        """-> (mi, mj, flip): the assignment to use and the one pair whose threshold test is inverted (or None)."""
+        import time
+        t0 = time.time()
+        try:
+            return self._decide(kind, frame, traj, thr, mi, mj)
+        finally:
+            self.seconds += time.time() - t0
+
+    def _decide(self, kind, frame, traj, thr, mi, mj):
+        best = self._outcome(traj, thr, mi, mj)
+        total = float(traj[mi, mj].sum()) if len(mi) else 0.0
+        alts = {}                                                      # outcome -> (gap, kind, payload)
+        gap_min = float("inf")
+        for i, j in zip(mi, mj):
+            if float(traj[i, j]) == 0.0 and float(thr[j]) >= 0.0:
+                continue                                               # a zero pair is never accepted: swapping it changes nothing
+            t2 = traj.clone()
+            t2[i, j] = -1e6
+            ai, aj = _lsa(-t2)
+            if any(int(a) == int(i) and int(b) == int(j) for a, b in zip(ai, aj)):
+                continue                                               # (forced back onto the pair: no alternative without it)
+            out = self._outcome(traj, thr, ai, aj)
+            if out == best:
+                continue
+            gap = total - float(traj[ai, aj].sum())
+            gap_min = min(gap_min, gap)
+            if gap < self.eps and (out not in alts or gap < alts[out][0]):
+                alts[out] = (gap, "assign", (ai, aj))
+        thr_min = float("inf")
+        for i, j in zip(mi, mj):
+            m = abs(float(traj[i, j]) - float(thr[j]))
+            thr_min = min(thr_min, m)
+            if m < self.eps:
+                out = self._outcome(traj, thr, mi, mj, flip=(int(i), int(j)))
+                if out not in alts or m < alts[out][0]:
+                    alts[out] = (m, "flip", (int(i), int(j)))
+        ordered = sorted(alts.values(), key=lambda a: a[0])
+        idx = len(self.calls)
+        pick = int(self.script.get(idx, 0))
+        if pick > len(ordered):
+            pick = 0
+        self.calls.append({"frame": frame, "kind": kind, "rows": int(traj.shape[0]), "cols": int(traj.shape[1]),
+                           "assign_gap": gap_min, "thr_margin": thr_min, "n_alt": len(ordered), "picked": pick,
+                           "picked_gap": ordered[pick - 1][0] if pick else 0.0})
+        if pick == 0:
+            return mi, mj, None
+        _, what, payload = ordered[pick - 1]
+        if what == "assign":
+            return payload[0], payload[1], None
+        return mi, mj, payload
+
+    def summary(self):
+        """Smallest margins over the clip (what a reader needs to judge how close the ids sit to a flip)."""
+        fin = lambda v: None if v == float("inf") else v
+        return {"matches": len(self.calls),
+                "min_assign_gap": fin(min([c["assign_gap"] for c in self.calls], default=float("inf"))),
+                "min_thr_margin": fin(min([c["thr_margin"] for c in self.calls], default=float("inf")))}
+
+
+def _thr_vector(V, id_inds):
+    if V.NOT_MULT_THRESH:
+        return torch.full((id_inds.shape[1],), float(V.OVERLAP_THRESH))
+    return V.OVERLAP_THRESH * id_inds.sum(dim=0)
+
+
+def run_short_term_match(sd, cfg, instances, id_count=None, log=None, frame=None):
     """gom_lstmatcher.py:405-465.  instances = [prev, cur]; sets cur['track_ids']."""
     V = cfg.VIDEO_TEST
     n_t = [len(x) for x in instances]
@@ -561,10 +656,13 @@ def run_short_term_match(sd, cfg, instances, id_count=None):
     if V.WITH_IOU:
         traj = torch.max(traj, ious)
     mi, mj = _lsa(-traj)
+    flip = None
+    if log is not None:
+        mi, mj, flip = log.decide("short", frame, traj, _thr_vector(V, id_inds), mi, mj)
     track_ids = ids.new_full((n_k,), -1)
     for i, j in zip(mi, mj):
         thr = V.OVERLAP_THRESH * id_inds[:, j].sum() if not V.NOT_MULT_THRESH else V.OVERLAP_THRESH
-        if traj[i, j] > thr:
+        if bool(traj[i, j] > thr) != (flip == (int(i), int(j))):
             track_ids[i] = uniq[j]
     if id_count:
         for i in range(n_k):
@@ -577,7 +675,7 @@ def run_short_term_match(sd, cfg, instances, id_count=None):
     return instances, torch.unique(track_ids)
 
 
-def run_long_term_match(sd, cfg, full, k, id_count, cur_id):
+def run_long_term_match(sd, cfg, full, k, id_count, cur_id, log=None, frame=None):
     """gom_lstmatcher.py:467-564."""
     V = cfg.VIDEO_TEST
     cur = set(int(c) for c in cur_id)
@@ -627,10 +725,13 @@ def run_long_term_match(sd, cfg, full, k, id_count, cur_id):
         valid_assn = torch.mm(valid.float(), id_inds).clamp_(max=1.0).long().bool()
         traj[~valid_assn] = 0
     mi, mj = _lsa(-traj)
+    flip = None
+    if log is not None:
+        mi, mj, flip = log.decide("long", frame, traj, _thr_vector(V, id_inds), mi, mj)
     track_ids = ids.new_full((n_k,), -1)
     for i, j in zip(mi, mj):
         thr = V.OVERLAP_THRESH * id_inds[:, j].sum() if not V.NOT_MULT_THRESH else V.OVERLAP_THRESH
-        if traj[i, j] > thr:
+        if bool(traj[i, j] > thr) != (flip == (int(i), int(j))):
             track_ids[i] = uniq[j]
     for i in range(n_k):
         if track_ids[i] < 0:
@@ -640,9 +741,9 @@ def run_long_term_match(sd, cfg, full, k, id_count, cur_id):
     return full, id_count
 
 
-def track_clip(sd, cfg, per_frame, batch_id=0, id_count=0, instances=None):
+def track_clip(sd, cfg, per_frame, batch_id=0, id_count=0, instances=None, log=None):
     """The control flow of gom_lstmatcher.py:366-403 over already-detected frames
-    (`per_frame` = output of roi_heads_forward, one Inst per frame)."""
+    (`per_frame` = output of roi_heads_forward, one Inst per frame).  `log`: a MatchLog (margins / forced near-ties)."""
     test_len = cfg.INPUT.VIDEO.TEST_LEN
     instances = [] if instances is None else instances
     start = batch_id * 100
@@ -653,15 +754,15 @@ def track_clip(sd, cfg, per_frame, batch_id=0, id_count=0, instances=None):
             instances[0]["track_ids"] = torch.arange(1, len(instances[0]) + 1)
             id_count = len(instances[0]) + 1
         elif rf == 1:
-            pair, id_count = run_short_term_match(sd, cfg, instances[rf - 1: rf + 1], id_count=id_count)
+            pair, id_count = run_short_term_match(sd, cfg, instances[rf - 1: rf + 1], id_count=id_count, log=log, frame=rf)
             instances[rf - 1: rf + 1] = pair
         else:
-            pair, cur_id = run_short_term_match(sd, cfg, instances[rf - 1: rf + 1])
+            pair, cur_id = run_short_term_match(sd, cfg, instances[rf - 1: rf + 1], log=log, frame=rf)
             instances[rf - 1: rf + 1] = pair
             if -1 in cur_id:
                 st, ed = max(0, rf + 1 - test_len), rf + 1
                 win, id_count = run_long_term_match(sd, cfg, instances[st:ed], min(test_len - 1, rf),
-                                                    id_count, cur_id)
+                                                    id_count, cur_id, log=log, frame=rf)
                 instances[st:ed] = win
         assert len(instances[-1]["track_ids"]) == len(torch.unique(instances[-1]["track_ids"]))
         if rf - test_len >= 0:
@@ -740,13 +841,13 @@ def detect_frames(sd, cfg, images, taps=None, topk_override=None):
     return roi_heads_forward(sd, cfg, props)
 
 
-def run_clip(sd, cfg, images, orig_hw=None):
+def run_clip(sd, cfg, images, orig_hw=None, log=None):
     """Whole path for one clip (GoMBatchPredictor.__call__ window, text_track_visualizer.py:325-334)."""
     with torch.no_grad():
         per_frame = []
         for im in images:                                   # one frame at a time, as the reference does
             per_frame.extend(detect_frames(sd, cfg, [im]))
-        instances, id_count = track_clip(sd, cfg, per_frame)
+        instances, id_count = track_clip(sd, cfg, per_frame, log=log)
         if cfg.VIDEO_TEST.MIN_TRACK_LEN > 0:
             instances = remove_short_track(cfg, instances)
         if orig_hw is None:

@@ -15,10 +15,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.mark.parametrize("frac", [0.12, 0.3])
 @pytest.mark.parametrize("builtin", sorted(BUILTIN))
-def test_every_shipped_config_tracked_clip_vs_oracle(builtin):
+def test_every_shipped_config_tracked_clip_vs_oracle(builtin, frac):
     """As tests/test_clips_fullsize_gpu.py does at full size: the oracle's DETECTOR on one frame (tie-robust against near-tied
-    proposal winners), the oracle's TRACKER + short-track removal + rescaling over the HIP path's detections of all eight frames."""
+    proposal winners), the oracle's TRACKER + short-track removal + rescaling over the HIP path's detections of all eight frames.
+    Two densities: ~12 and ~30 detections per 160 x 224 frame.  At the crowded one the random-weight association scores sit close
+    together (round 5 met a near-tie there); the ids are compared under helpers.track_clip_tie_aware: identical, or parting only at
+    decisions whose gap in the ORACLE's traj matrix is below 1e-4, with every later id following once that decision is forced."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from oracle import gom_oracle as O
@@ -27,6 +31,7 @@ def test_every_shipped_config_tracked_clip_vs_oracle(builtin):
     from gomatching_amd.synth import make_clip
     from test_fullsize_gpu import _calibrated_sd
     from test_clips_fullsize_gpu import _oracle_insts, _rank_swaps, _same_detections
+    from helpers import track_clip_tie_aware
     cfg = setup_cfg(builtin=builtin)
     cfg.MODEL.DEVICE = DEV
     ocfg = setup_cfg(builtin=builtin)
@@ -34,11 +39,7 @@ def test_every_shipped_config_tracked_clip_vs_oracle(builtin):
     hw = (160, 224)
     frames = make_clip(8, hw[0], hw[1], clip_id=11, num_rects=6)
     images = [torch.as_tensor(f.astype("float32").transpose(2, 0, 1).copy()) for f in frames]
-    # ~12 detections per 160 x 224 frame: this test is about every config's heads / thresholds / matcher running end to end; at ~30 per
-    # frame (frac 0.3) the random-weight association scores crowd together, and an fp32 rounding anywhere upstream (round 5: the
-    # position term as two partial sums, ops.POS_SEPARABLE) moved one id of one config through a near-tie between the HIP tracker and
-    # the oracle's.  Crowded scenes are the full-size clip tests' job (70-79 detections, tests/test_clips_fullsize_gpu.py)
-    sd = _calibrated_sd(cfg, seed=2, image=images[0], frac=0.12)
+    sd = _calibrated_sd(cfg, seed=2, image=images[0], frac=frac)
     model = GoMatching(cfg, sd, device=DEV, frames_per_step=8)
     inputs = [{"image": im, "height": hw[0], "width": hw[1]} for im in images]
     model.begin_batch([], len(inputs))
@@ -56,9 +57,9 @@ def test_every_shipped_config_tracked_clip_vs_oracle(builtin):
             ref = O.detect_frames(sd, ocfg, [images[3]], topk_override=order)[0]
         _same_detections(raw[3], ref, 1e-3)
         # the tracker with this config's matcher head and thresholds over all frames
-        o_inst, o_count = O.track_clip(sd, ocfg, raw)
-        for f, x in enumerate(o_inst):
-            assert x["track_ids"].tolist() == raw_ids[f], ("ids before removal", f)
+        o_inst, o_count, rep = track_clip_tie_aware(sd, ocfg, raw, raw_ids)
+        print("TRACKER %s frac %.2f: detections/frame %s, forced near-ties %s, margins %s"
+              % (builtin, frac, [len(x) for x in raw_ids], rep["forced"], rep["margins"]))
         if ocfg.VIDEO_TEST.MIN_TRACK_LEN > 0:
             o_inst = O.remove_short_track(ocfg, o_inst)
         o_res = O.batch_postprocess(o_inst, [hw] * len(o_inst))

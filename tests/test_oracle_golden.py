@@ -118,6 +118,45 @@ def test_tracker_trace(builtin, tag):
 
 
 @pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
+def test_match_log_leaves_the_trace_alone_and_the_tie_rule_is_strict(builtin, tag):
+    """oracle.MatchLog (margins of the tracker's discrete decisions) must not change a single id of the reference's trace, and
+    tests/helpers.track_clip_tie_aware -- the rule the GPU clip tests compare ids under -- must (i) accept identical ids with
+    nothing forced, (ii) accept ids that part from the oracle's at ONE decision only when that decision's gap is below eps, then
+    requiring every later id to follow, (iii) reject the same ids at an eps below the gap."""
+    from helpers import track_clip_tie_aware
+    g = golden("tracker_%s.npz" % tag)
+    cfg = mini_cfg(builtin)
+    sd = synth_state_dict(cfg, seed=7)
+    insts, frames = _tracker_inputs(g)
+    want = [g["ids_%d" % f].tolist() for f in range(frames)]
+    res, id_count, rep = track_clip_tie_aware(sd, cfg, insts, want)
+    assert int(id_count) == int(g["id_count"][0]) and rep["forced"] == [] and rep["replays"] == 1
+    assert rep["margins"]["matches"] >= frames - 2 and rep["margins"]["min_thr_margin"] > 0
+    # the widest-margin-first alternative of some match as "another implementation's" ids: gap known, far above 1e-4
+    import copy
+    probe = O.MatchLog(eps=10.0)
+    with torch.no_grad():
+        O.track_clip(sd, cfg, copy.deepcopy(insts), log=probe)
+    other_ids, gap = None, None
+    for idx, c in enumerate(probe.calls):                               # (a forced short-term alternative is often undone by the
+        for k in range(1, c["n_alt"] + 1):                              #  long-term match of the same frame: take one that shows)
+            forced = O.MatchLog(eps=10.0, script={idx: k})
+            with torch.no_grad():
+                other, _ = O.track_clip(sd, cfg, copy.deepcopy(insts), log=forced)
+            ids = [x["track_ids"].tolist() for x in other]
+            if ids != want and forced.calls[idx]["picked_gap"] > 1e-3:
+                other_ids, gap = ids, forced.calls[idx]["picked_gap"]
+                break
+        if other_ids is not None:
+            break
+    assert other_ids is not None
+    _, _, rep = track_clip_tie_aware(sd, cfg, insts, other_ids, eps=gap * 1.01, max_runs=64)
+    assert len(rep["forced"]) >= 1 and all(c["picked_gap"] < gap * 1.01 for c in rep["forced"])
+    with pytest.raises(AssertionError):
+        track_clip_tie_aware(sd, cfg, insts, other_ids, eps=min(gap * 0.5, 1e-4))
+
+
+@pytest.mark.parametrize("builtin,tag", [("icdar15", "lst"), ("pp_dstext", "pp")])
 def test_end_to_end_mini_clip(builtin, tag):
     """Whole path on 8 tiny frames: Bezier/boundary points within 1e-3 px-scaled, identical recs and ids."""
     g = golden("e2e_%s.npz" % tag)
