@@ -1,4 +1,5 @@
-"""The row-local tail of a composite decoder layer as one launch (csrc/dec_tail.hip) against a float64 statement of
+"""The row-local tail of a composite decoder layer as one launch -- form 2: the CU-cooperative kernel of csrc/dec_tail2.hip (80 rows
+per workgroup, the waves split the output columns; round 6, the default), form 1: csrc/dec_tail.hip -- against a float64 statement of
 deformable_transformer.py:352-369 (FFN + norm3), :484-488 (ctrl_point_coord + reference refinement) and :470-473 +
 adet/modeling/model/utils.py:24-37 (the next layer's ref_point_head over the sine embedding), and against the four-launch path
 it replaces (fused FFN, two-layer perceptron, ref_update, two-layer perceptron)."""
@@ -46,13 +47,18 @@ def _ref64(x, ffn, coord, qpos, ref, dim_t):
     return y, new_ref, q
 
 
+@pytest.mark.parametrize("form", [2, 1])
 @pytest.mark.parametrize("M,F,want", [(1, 1024, True), (33, 1024, True), (128, 64, False), (129, 1024, True), (2500, 1024, False),
-                                       (20000, 1024, True), (4097, 96, True)])
-def test_dec_tail_vs_fp64_and_four_launches(M, F, want):
+                                       (20000, 1024, True), (4097, 96, True), (79, 128, True), (80, 256, False), (161, 1024, True)])
+def test_dec_tail_vs_fp64_and_four_launches(M, F, want, form):
     from gomatching_amd import ops
+    if form == 2 and F % 128:
+        pytest.skip("form 2 takes the hidden layer in chunks of 128 (ops.DecTail falls back to form 1)")
     x, ffn, coord, qpos, ref, dim_t = _case(M, F, seed=M + F)
     dv = lambda t: t.to(DEV)
-    blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t))
+    blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
+                      form=form)
+    assert blk.form == form
     y, nref, qp = ops.dec_tail(dv(x), blk, dv(ref), want_qpos=want)
     torch.cuda.synchronize()
     ops.check_range_flag(DEV)
@@ -74,33 +80,46 @@ def test_dec_tail_vs_fp64_and_four_launches(M, F, want):
         assert float((qp - ops.mlp2_fused(emb4, q)).abs().max()) <= 3e-5
 
 
-def test_dec_tail_rows_are_independent_of_the_launch():
-    """Batch invariance: a row's bits do not depend on what shares its launch (tile position, tail tile, launch length)."""
+@pytest.mark.parametrize("proj", [False, True])
+@pytest.mark.parametrize("form", [2, 1])
+def test_dec_tail_rows_are_independent_of_the_launch(form, proj):
+    """Batch invariance: a row's bits do not depend on what shares its launch (tile position, tail tile, launch length) -- with and
+    without the out_proj block in front (whose residual the form-1 kernel parks in Y: ADVICE r5)."""
     from gomatching_amd import ops
     M = 1000
     x, ffn, coord, qpos, ref, dim_t = _case(M, 1024, seed=7)
+    g = torch.Generator().manual_seed(5)
+    samp = torch.randn((M, 256), generator=g)
+    pw = (torch.randn((256, 256), generator=g) / 16, torch.randn((256,), generator=g) * 0.1, 1.0 + 0.2 * torch.randn((256,), generator=g),
+          0.1 * torch.randn((256,), generator=g))
     dv = lambda t: t.to(DEV)
-    blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t))
-    full = ops.dec_tail(dv(x), blk, dv(ref))
-    for a, b in ((0, 1), (17, 300), (511, 1000), (900, 901)):
-        part = ops.dec_tail(dv(x[a:b]).contiguous(), blk, dv(ref[a:b]).contiguous())
+    blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
+                      proj_w=tuple(dv(v) for v in pw) if proj else None, form=form)
+    run = (lambda a, b: ops.dec_tail(dv(samp[a:b]).contiguous(), blk, dv(ref[a:b]).contiguous(), residual=dv(x[a:b]).contiguous())) if proj \
+        else (lambda a, b: ops.dec_tail(dv(x[a:b]).contiguous(), blk, dv(ref[a:b]).contiguous()))
+    full = run(0, M)
+    for a, b in ((0, 1), (17, 300), (511, 1000), (900, 901), (80, 160), (79, 241)):
+        part = run(a, b)
         for u, v in zip(full, part):
             assert torch.equal(u[a:b], v)
 
 
-def test_dec_tail_flags_an_activation_beyond_fp16():
+@pytest.mark.parametrize("form", [2, 1])
+def test_dec_tail_flags_an_activation_beyond_fp16(form):
     from gomatching_amd import lib, ops
     x, ffn, coord, qpos, ref, dim_t = _case(64, 1024, seed=1, xscale=1e5)
     dv = lambda t: t.to(DEV)
-    blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t))
+    blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
+                      form=form)
     ops.dec_tail(dv(x), blk, dv(ref))
     torch.cuda.synchronize()
     with pytest.raises(lib.GomError):
         ops.check_range_flag(DEV)
 
 
+@pytest.mark.parametrize("form", [2, 1])
 @pytest.mark.parametrize("M,want", [(1, True), (130, False), (2500, True), (20000, True)])
-def test_dec_tail_with_out_proj_in_front(M, want):
+def test_dec_tail_with_out_proj_in_front(M, want, form):
     """The launch that also takes the cross attention's out_proj + residual + norm_cross (deformable_transformer.py:406-422):
     float64 reference and the proj_ln launch + the plain tail launch it replaces."""
     from gomatching_amd import ops
@@ -111,7 +130,7 @@ def test_dec_tail_with_out_proj_in_front(M, want):
     pg, pb = 1.0 + 0.2 * torch.randn((256,), generator=g), 0.1 * torch.randn((256,), generator=g)
     dv = lambda t: t.to(DEV)
     blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
-                      proj_w=(dv(wo), dv(bo), dv(pg), dv(pb)))
+                      proj_w=(dv(wo), dv(bo), dv(pg), dv(pb)), form=form)
     y, nref, qp = ops.dec_tail(dv(samp), blk, dv(ref), want_qpos=want, residual=dv(x))
     torch.cuda.synchronize()
     ops.check_range_flag(DEV)
@@ -122,7 +141,8 @@ def test_dec_tail_with_out_proj_in_front(M, want):
     assert float((nref.cpu().double() - rref).abs().max()) <= 2e-6
     if want:
         assert float((qp.cpu().double() - rq).abs().max()) <= 3e-5
-    plain = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t))
+    plain = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
+                        form=1)
     pl = ops.proj_ln_block((ops.prep_weight(dv(wo)), dv(bo)), (dv(pg), dv(pb)))
     t3g = ops.proj_ln(dv(samp), pl, dv(x))
     y2, nref2, qp2 = ops.dec_tail(t3g, plain, dv(ref), want_qpos=want)

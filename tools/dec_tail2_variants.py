@@ -1,0 +1,94 @@
+"""Schedule variants of csrc/dec_tail2.hip, built as stand-alone libraries from the same source with -D knobs and timed against
+each other (and against form 1) in alternating bursts on one GPU at the decoder's shape.
+    python tools/dec_tail2_variants.py --build [name=flags ...]   (here: cross-compiles tools/exp/libdt2_<name>.so)
+    python tools/dec_tail2_variants.py [M]                        (GPU box)"""
+import ctypes
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXP = os.path.join(ROOT, "tools", "exp")
+SRC = os.path.join(ROOT, "gomatching_amd", "csrc", "dec_tail2.hip")
+DEFAULT = {"s1_3_s2_2": "", "s1_3_s2_7": "-DT2_SPREAD2=7", "s1_2_s2_2": "-DT2_SPREAD1=2", "s1_1_s2_1": "-DT2_SPREAD1=1 -DT2_SPREAD2=1"}
+
+
+def build(variants):
+    for name, flags in variants.items():
+        out = os.path.join(EXP, "libdt2_%s.so" % name)
+        cmd = ["hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
+               "-shared", "-x", "hip", SRC, "-o", out] + flags.split()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stderr)
+            raise SystemExit(1)
+        print("built", out, flags)
+
+
+def main():
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gomatching_amd import ops
+    from gomatching_amd.lib import SIGNATURES
+    from test_dec_tail_gpu import _case
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+    x, ffn, coord, qpos, ref, dim_t = _case(M, 1024, seed=3)
+    dv = lambda t: t.to("cuda")
+    g = torch.Generator().manual_seed(1)
+    samp = dv(torch.randn((M, 256), generator=g))
+    pw = (dv(torch.randn((256, 256), generator=g) / 16), dv(torch.randn((256,), generator=g) * 0.1), dv(1.0 + 0.2 * torch.randn((256,), generator=g)),
+          dv(0.1 * torch.randn((256,), generator=g)))
+    mk = lambda form, proj: ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos],
+                                        dv(dim_t), proj_w=pw if proj else None, form=form)
+    b1, b2 = mk(1, True), mk(2, True)
+    X, R = dv(x), dv(ref)
+    want = ops.dec_tail(samp, b1, R, want_qpos=True, residual=X)
+    libs = {}
+    for path in sorted(glob.glob(os.path.join(EXP, "libdt2_*.so"))):
+        lib = ctypes.CDLL(path)
+        res, args = SIGNATURES["gom_dec_tail2_f32"]
+        lib.gom_dec_tail2_f32.restype, lib.gom_dec_tail2_f32.argtypes = res, args
+        libs[os.path.basename(path)[7:-3]] = lib
+    out, nref, qp = torch.empty((M, 256), device="cuda"), torch.empty((M, 2), device="cuda"), torch.empty((M, 256), device="cuda")
+    flag = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    p = ops._p
+
+    def run(lib, blk=b2):
+        pi, pb, pg, pbe = blk.proj
+        rc = lib.gom_dec_tail2_f32(p(samp), 256, p(X), 256, p(blk.image), blk.wave_bytes[1], blk.F, p(pi), p(pb), p(pg), p(pbe), blk.eps,
+                                   p(blk.inv1), p(blk.b1), p(blk.inv2), p(blk.b2), p(blk.gamma), p(blk.beta), blk.eps, p(blk.c_inv1),
+                                   p(blk.c_b1), p(blk.c_inv2), p(blk.c_b2), p(blk.W3), p(blk.b3), p(R), p(blk.dim_t), p(blk.q_inv1),
+                                   p(blk.q_b1), p(blk.q_inv2), p(blk.q_b2), p(out), 256, p(nref), p(qp), 256, M, p(flag), ops._stream())
+        assert rc == 0, rc
+
+    def burst(fn, n=20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
+    for name, lib in libs.items():
+        out.zero_()
+        run(lib)
+        torch.cuda.synchronize()
+        print("%-14s max |d| vs form 1: tgt %.2e ref %.2e qpos %.2e, flag %d" % (name, float((out - want[0]).abs().max()),
+              float((nref - want[1]).abs().max()), float((qp - want[2]).abs().max()), int(flag.item())))
+    for rnd in range(3):
+        line = "round %d  M = %d with out_proj: form 1 %.1f us" % (rnd, M, burst(lambda: ops.dec_tail(samp, b1, R, want_qpos=True, residual=X)))
+        for name, lib in libs.items():
+            line += " | %s %.1f" % (name, burst(lambda: run(lib)))
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    if "--build" in sys.argv:
+        extra = dict(a.split("=", 1) for a in sys.argv[2:])
+        build(extra or DEFAULT)
+    else:
+        main()
