@@ -297,9 +297,6 @@ def main():
                     help="compute units reserved for the tracker's per-frame recurrence (CU-masked streams); -1 = 32 when the tracker "
                          "handles the frames of 8 or more GPUs (world size x --emulate-world), else 0: measured 48.6 -> 42.2 ms "
                          "per step at 8 GPUs' load, 37.4 -> 39.6 at 4 (the detector pays 5 %% for the lost CUs)")
-    ap.add_argument("--match-fused", action="store_true",
-                    help="A/B: the long-term match as ONE launch (csrc/match_fused.hip; same bits, measured slower) instead of its "
-                         "chain of 13 launches (gom_match_scores_proj_f32)")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="N=1 diagnostic: run the replicated tracker over W copies of this GPU's records per step, i.e. "
                          "the tracker load of a W-GPU run, beside one GPU's detection (value still counts 8 frames/step)")
@@ -377,7 +374,6 @@ def main():
         """Model + pipeline of one contraction back-end; every rank (and every back-end) calibrates on frame 0 of the
         clip, the default back-end's shifts being reused so that all of them hold identical weights."""
         ops.GEMM_MODE = mode
-        ops._L().gom_tracker_set_fused(1 if args.match_fused else 0)
         model, sd = build_model(cfg, device)
         if args.h2d:
             model.h2d_mode = args.h2d
@@ -611,7 +607,7 @@ def main():
                    "short_term_scores": ("replicated on every rank" if args.replicate_short_term else
                                          "sharded: a rank scores the frame pairs it detected, second all-gather of the [F, 2 + nq^2] blocks")
                    if world * args.emulate_world > 1 else "single rank",
-                   "long_term_match": "one launch (match_fused.hip)" if args.match_fused else "chain of 13 launches",
+                   "long_term_match": "chain of 13 launches",
                    "tracker_cus": args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world >= 8 else 0),
                    "pipelining": "upload(step i+1) and detector(step i+1) overlap tracker(step i)",
                    "detector_hipgraph": graphed, "detector_lanes": args.detector_lanes,

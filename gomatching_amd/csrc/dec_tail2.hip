@@ -40,6 +40,22 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// Range bookkeeping on what is SPLIT (gemm_f16x3.hip contract: an operand must stay within fp16's range, and a NaN must not pass):
+// the main plane of a split value is fp16(x) -- infinite or NaN exactly when |x| >= 65520 or x is not finite -- so the running
+// maximum of the planes' 15-bit magnitudes (v_and + v_pk_max_u16 per TWO values; non-negative values: the maximum alone) replaces a
+// float maximum and a NaN detector per value.  Raised when a half reaches the exponent 0x1f.
+__device__ __forceinline__ void t2_track(u16x2& m, const half8 plane0) {
+    const u32x4 w = __builtin_bit_cast(u32x4, plane0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, w[i] & 0x7fff7fffu));
+}
+__device__ __forceinline__ void t2_track_nonneg(u16x2& m, const half8 plane0) {
+    const u32x4 w = __builtin_bit_cast(u32x4, plane0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, w[i]));
+}
 
 __device__ __forceinline__ f32x4 mfma16(const half8 a, const half8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -112,6 +128,26 @@ __device__ __forceinline__ float groups_sum(float v) {
 #define T2_SPREAD2 2
 #endif
 
+// -DT2_STAMPS (tools/dec_tail2_variants.py only): s_memtime at the phase boundaries of every wave into a buffer set by
+// gom_dec_tail2_set_stamps -- [workgroup][wave][16] cycles since the wave's start; slots 10..12 = sums over the FFN's chunks
+#ifdef T2_STAMPS
+__device__ unsigned long long* g_t2_stamps = nullptr;
+__device__ __forceinline__ unsigned long long t2_clock() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define T2_STAMP(i)                                                                                        \
+    if (g_t2_stamps && lane == 0) g_t2_stamps[((size_t)blockIdx.x * 4 + wave) * 16 + (i)] = t2_clock() - t2_t0;
+#define T2_STAMP_ADD(i, since)                                                                             \
+    if (g_t2_stamps && lane == 0) g_t2_stamps[((size_t)blockIdx.x * 4 + wave) * 16 + (i)] += t2_clock() - (since);
+#define T2_NOW(var) const unsigned long long var = t2_clock();
+#else
+#define T2_STAMP(i)
+#define T2_STAMP_ADD(i, since)
+#define T2_NOW(var)
+#endif
+
 #define T2_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory")
 #define T2_BARRIER() asm volatile("s_barrier" ::: "memory")
 
@@ -122,20 +158,38 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fn = lane & 15, fg = lane >> 4;
     const long tile0 = (long)blockIdx.x * RB;
+#ifdef T2_STAMPS
+    const unsigned long long t2_t0 = t2_clock();
+#endif
 
     // ---- the wave's weight stream ----
     const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, (int)p.img_bytes, 0x00020000);
     const int voff = lane * 16;
     int so = (int)(wave * p.wave_stride);                    // byte offset of the current block / chunk in the stream (uniform)
     half8 a0[8], a1[8], b0[10], b1[10];
-#define T2_LOADA(dst, grp)                                                                                                  \
+#define T2_LOADA_(dst, grp)                                                                                                 \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                                        \
         dst[i_] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_img, voff, so + (grp) * GROUP + i_ * FRAG, 0));
+#ifdef T2_EXP_NO_A                                       /* timing experiment (wrong results): the weight stream is not read */
+#define T2_LOADA(dst, grp)
+#else
+#define T2_LOADA(dst, grp) T2_LOADA_(dst, grp)
+#endif
     const unsigned char* xp_lane = smem + lane * 16;
     const unsigned char* hp_lane = smem + HP_OFF + lane * 16;
-#define T2_LOADB(dst, base, s)                                                                                              \
+#define T2_LOADB_(dst, base, s)                                                                                             \
     _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) dst[i_] = *reinterpret_cast<const half8*>((base) + ((s) * 10 + i_) * FRAG);
-    T2_LOADA(a0, 0)
+#ifdef T2_EXP_NO_B                                       /* timing experiment (wrong results): the row fragments are read once */
+#define T2_LOADB(dst, base, s)
+#else
+#define T2_LOADB(dst, base, s) T2_LOADB_(dst, base, s)
+#endif
+    T2_LOADA_(a0, 0)
+#if defined(T2_EXP_NO_A) || defined(T2_EXP_NO_B)
+    T2_LOADA_(a1, 1)
+    T2_LOADB_(b0, xp_lane, 0)
+    T2_LOADB_(b1, xp_lane, 1)
+#endif
 
     // this lane's rows in the accumulator layout (row group rg: tile0 + 16 rg + fn), clamped for loads; tail rows are never stored
     long mrow[NRG];
@@ -147,7 +201,8 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         mrow[rg] = live[rg] ? m : p.M - 1;
     }
 
-    float amax = 0.f, chk = 0.f, hmax = 0.f;                 // range bookkeeping (gemm_f16x3.hip contract), as dec_tail.hip
+    float amax = 0.f, chk = 0.f;                             // range bookkeeping (gemm_f16x3.hip contract): the input rows, unsplit results
+    u16x2 pmax = {0, 0};                                     // ... and every value split inside the kernel (t2_track)
 
     // ---- prologue: the 80 input rows -> XP.  80 units of (8 rows x 32 floats = one k-step) over the four waves; a unit is ONE load
     //      instruction of eight whole 128-byte lines (lane: row l & 7, 16-byte piece l >> 3) and two 8-byte LDS stores per lane ----
@@ -176,6 +231,7 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         asm volatile("" : "+v"(amax));
     }
     T2_BARRIER_LDS();
+    T2_STAMP(0)
 
     f32x4 acc2[4][NRG];                                      // [column group of the wave][row group]
 #define T2_ZERO_ACC2()                                                                                                      \
@@ -219,6 +275,7 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         T2_LOADB(b0, xp_lane, 0)                                                                                            \
         for (int c = 0; c < (nch); ++c) {                                                                                   \
             const bool more = c + 1 < (nch);                                                                                \
+            T2_NOW(tc0_)                                                                                                    \
             f32x4 acc1[2][NRG];                                                                                             \
             _Pragma("unroll") for (int hg = 0; hg < 2; ++hg)                                                                \
                 _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg) acc1[hg][rg] = f32x4{0.f, 0.f, 0.f, 0.f};                \
@@ -237,21 +294,24 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
             T2_LOADB(b1, xp_lane, 7) T2_LOADA(a0, 4) T2_MM1(a1, 0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD1) T2_PIN_M(30 - 8 * T2_SPREAD1)                  \
             T2_MM1(a1, 1, b1) T2_PIN_M(30)                                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                              \
+            T2_STAMP_ADD(10, tc0_)                                                                                          \
+            T2_NOW(tc1_)                                                                                                    \
             T2_BARRIER();                                            /* every wave is done with the previous chunk's HP */ \
             _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg) {                                                            \
                 f32x4 v[2];                                                                                                 \
                 _Pragma("unroll") for (int hg = 0; hg < 2; ++hg)                                                            \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                         \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                           \
                         v[hg][e] = fmaxf(fmaf(acc1[hg][rg][e], sc[hg][e], bi[hg][e]), 0.f);                                 \
-                        hmax = fmaxf(hmax, v[hg][e]);                                                                       \
-                    }                                                                                                       \
                 half8 h0, h1;                                                                                               \
                 gom_split8_f16(v[0], v[1], h0, h1);                                                                         \
+                t2_track_nonneg(pmax, h0);                                                                                  \
                 unsigned char* dst = smem + HP_OFF + ((wave * NRG + rg) * 2) * FRAG + lane * 16;                            \
                 *reinterpret_cast<half8*>(dst) = h0;                                                                        \
                 *reinterpret_cast<half8*>(dst + FRAG) = h1;                                                                 \
             }                                                                                                               \
             T2_BARRIER_LDS();                                                                                               \
+            T2_STAMP_ADD(11, tc1_)                                                                                          \
+            T2_NOW(tc2_)                                                                                                    \
             T2_LOADB(b0, hp_lane, 0)                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                              \
             T2_LOADB(b1, hp_lane, 1) T2_LOADA(a1, 5) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)                     \
@@ -263,6 +323,7 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
             }                                                                                                               \
             T2_LOADA(a0, 8) T2_MM2(a1, b1) T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                              \
+            T2_STAMP_ADD(12, tc2_)                                                                                          \
             so += CHUNK_FRAGS * FRAG;                                                                                       \
         }                                                                                                                   \
     }
@@ -312,13 +373,15 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
             for (int rg = 0; rg < NRG; ++rg) {
                 half8 h0, h1;
                 gom_split8_f16(o[2 * sh][rg], o[2 * sh + 1][rg], h0, h1);
+                t2_track(pmax, h0);
                 unsigned char* dst = smem + (((2 * wave + sh) * NRG + rg) * 2) * FRAG + lane * 16;
                 *reinterpret_cast<half8*>(dst) = h0;
                 *reinterpret_cast<half8*>(dst + FRAG) = h1;
             }
     };
 
-    f32x4 res[4][NRG];                                       // the FFN's residual in the accumulator layout
+    // the FFN's residual in the accumulator layout: norm_cross's output (proj) or the input rows
+    f32x4 res[4][NRG];
 
     // ================================ block 0: out_proj of the cross attention + norm_cross ================================
     if constexpr (WITH_PROJ) {
@@ -334,6 +397,7 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         T2_LOADA(a0, 8) T2_MM2(a1, b1) T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)
         __builtin_amdgcn_sched_barrier(0);
         so += LIN_FRAGS * FRAG;
+        T2_STAMP(1)
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) {
             const int col = 64 * wave + 16 * cg + 4 * fg;
@@ -341,6 +405,10 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
             const f32x4 bi = *reinterpret_cast<const f32x4*>(p.p_b + col);
 #pragma unroll
             for (int rg = 0; rg < NRG; ++rg) {
+                // norm_cross's residual: tgt in front of the cross attention.  (Sixteen half-lines per instruction in this layout:
+                // ~4.6k cycles of the CU's texture-address unit whenever it is issued -- requested under the loop's last step the
+                // loop grew by what the epilogue saved, requested before the loop the in-order vector-memory counter held the
+                // weight stream behind it: 9.4k -> 27k cycles.)
                 const f32x4 xr = *reinterpret_cast<const f32x4*>(p.R + (size_t)mrow[rg] * p.ldr + col);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc2[cg][rg][e] = fmaf(acc2[cg][rg][e], sc[e], bi[e]) + xr[e];
@@ -356,26 +424,16 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
 #pragma unroll
             for (int rg = 0; rg < NRG; ++rg)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float o = (acc2[cg][rg][e] - mean[rg]) * rstd[rg] * ga[e] + be[e];
-                    res[cg][rg][e] = o;
-                    chk = fmaf(o, 0.f, chk);
-                    amax = fmaxf(amax, fabsf(o));
-                }
+                for (int e = 0; e < 4; ++e) res[cg][rg][e] = (acc2[cg][rg][e] - mean[rg]) * rstd[rg] * ga[e] + be[e];
         }
-        asm volatile("" : "+v"(amax), "+v"(chk));
         to_xp(res);
         T2_BARRIER_LDS();
-    } else {
-#pragma unroll
-        for (int cg = 0; cg < 4; ++cg)
-#pragma unroll
-            for (int rg = 0; rg < NRG; ++rg)
-                res[cg][rg] = *reinterpret_cast<const f32x4*>(p.X + (size_t)mrow[rg] * p.ldx + 64 * wave + 16 * cg + 4 * fg);
+        T2_STAMP(2)
     }
 
     // ================================ block 1: the FFN + norm3 ================================
     T2_MLP(p.ffn_chunks, p.s1, p.b1)
+    T2_STAMP(3)
     {
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) {
@@ -383,9 +441,11 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(p.s2 + col);
             const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b2 + col);
 #pragma unroll
-            for (int rg = 0; rg < NRG; ++rg)
+            for (int rg = 0; rg < NRG; ++rg) {
+                if constexpr (!WITH_PROJ) res[cg][rg] = *reinterpret_cast<const f32x4*>(p.X + (size_t)mrow[rg] * p.ldx + col);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc2[cg][rg][e] = fmaf(acc2[cg][rg][e], sc[e], bi[e]) + res[cg][rg][e];
+            }
         }
         float mean[NRG], rstd[NRG];
         row_stats(1, p.eps, mean, rstd);
@@ -397,22 +457,18 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
 #pragma unroll
             for (int rg = 0; rg < NRG; ++rg) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float o = (acc2[cg][rg][e] - mean[rg]) * rstd[rg] * ga[e] + be[e];
-                    res[cg][rg][e] = o;
-                    chk = fmaf(o, 0.f, chk);
-                    amax = fmaxf(amax, fabsf(o));
-                }
+                for (int e = 0; e < 4; ++e) res[cg][rg][e] = (acc2[cg][rg][e] - mean[rg]) * rstd[rg] * ga[e] + be[e];
                 if (live[rg]) *reinterpret_cast<f32x4*>(p.Y + (size_t)mrow[rg] * p.ldy + col) = res[cg][rg];
             }
         }
-        asm volatile("" : "+v"(amax), "+v"(chk));
         to_xp(res);
         T2_BARRIER_LDS();
+        T2_STAMP(4)
     }
 
     // ================================ block 2: ctrl_point_coord + the reference refinement ================================
     T2_MLP(2, p.c_s1, p.c_b1)
+    T2_STAMP(5)
     float nref[NRG][2];
     {
         float2* red = reinterpret_cast<float2*>(smem + RED_OFF);     // buffer 0 (its last readers passed the FFN's barriers)
@@ -466,13 +522,21 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
 #pragma unroll
             for (int cg = 0; cg < 4; ++cg) {
                 const f32x4 dt = *reinterpret_cast<const f32x4*>(p.dim_t + ((64 * wave + 16 * cg + 4 * fg) & 127));
+                // pos = pts * 2 pi / dim_t (utils.py:24-37) with the quotient as a product by 1 / dim_t refined to fp32 accuracy (one
+                // Newton step on v_rcp_f32): two reciprocals per column group instead of ten divisions (~10 instructions each)
+                float rdt[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float r0 = __builtin_amdgcn_rcpf(dt[2 * k]);
+                    rdt[k] = fmaf(r0, fmaf(-dt[2 * k], r0, 1.f), r0);
+                }
 #pragma unroll
                 for (int rg = 0; rg < NRG; ++rg) {
                     const float e = nref[rg][wave >> 1] * 6.283185307179586f;
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {            // channels (4 g + 2 k, 4 g + 2 k + 1) of the quad: one angle
                         float sn, cs;
-                        sincos_0_2pi(e / dt[2 * k], sn, cs);
+                        sincos_0_2pi(e * rdt[k], sn, cs);
                         o[cg][rg][2 * k] = sn;
                         o[cg][rg][2 * k + 1] = cs;
                     }
@@ -480,9 +544,11 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
             }
             to_xp(o);
             T2_BARRIER_LDS();
+            T2_STAMP(6)
         }
         // ================================ block 3: ref_point_head ================================
         T2_MLP(2, p.q_s1, p.q_b1)
+        T2_STAMP(7)
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) {
             const int col = 64 * wave + 16 * cg + 4 * fg;
@@ -501,8 +567,9 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         }
         asm volatile("" : "+v"(chk));
     }
+    T2_STAMP(8)
     // an operand left fp16's range, or a result is not finite (gemm_f16x3.hip contract; fmaxf drops a NaN, `chk` catches it)
-    if ((!(amax <= 65504.f) || !(hmax <= 65504.f) || !(chk == 0.f)) && p.flag) atomicOr(p.flag, 1);
+    if ((!(amax <= 65504.f) || pmax[0] >= 0x7c00 || pmax[1] >= 0x7c00 || !(chk == 0.f)) && p.flag) atomicOr(p.flag, 1);
 #undef T2_LOADA
 #undef T2_LOADB
 #undef T2_ZERO_ACC2
@@ -577,6 +644,12 @@ extern "C" int gom_dec_tail2_image_mlp(const void* w1_planes, long w1_plane_stri
                        d_hidden, (unsigned short*)((unsigned char*)image + offset_bytes), wave_bytes / 2);
     return gom_launch_status();
 }
+
+#ifdef T2_STAMPS
+extern "C" int gom_dec_tail2_set_stamps(void* device_buffer) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_t2_stamps), &device_buffer, sizeof(void*));
+}
+#endif
 
 #define GOM_ALIGNED16(ptr) (((uintptr_t)(ptr) % 16) == 0)
 

@@ -42,11 +42,6 @@ struct RowArgs {
     int* flag;
     int lda, ldr, ldc, M, chunks, cpg, r_chunks, relu, r_period;
     int tiles, frames, tpf;                                  // frame-interleaved tile order (periodic residual): see tile_of()
-    // SEPARABLE periodic residual (LINES form): row m is pixel q = m % r_period of a pyramid of `sep_levels` maps (level l: pixels
-    // [sep_start[l], sep_start[l + 1]) in raster order, sep_w[l] wide) and adds R[sep_y[l] + y] + R[sep_x[l] + x] -- two small
-    // tables (one row per map ROW and per map COLUMN) instead of one row per pixel.  sep_levels = 0: off.
-    int sep_levels, sep_rows;
-    int sep_start[5], sep_w[4], sep_y[4], sep_x[4];
 };
 
 // Which 128-row tile a workgroup takes.  Plain launches: its index.  With a PERIODIC residual (the encoder's position table
@@ -111,26 +106,6 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
     if (tile < 0) return;                                    // padding of the interleaved id space (whole workgroup)
     long row = tile * BM + wave * 32 + fr;
     if (row > p.M - 1) row = p.M - 1;                        // tail rows recompute AND re-store the last row (same bits)
-    __shared__ unsigned sep_off[LINES ? 2 * BM : 2];          // byte offsets of every tile row's two residual rows (read in the epilogue,
-    if constexpr (LINES) {                                    //  behind the chunk loop's first barrier)
-        if (p.sep_levels > 0 && tid < BM) {
-            long m = tile * BM + tid;
-            if (m > p.M - 1) m = p.M - 1;
-            const int q = (int)(m % p.r_period);
-            int l = 0;
-#pragma unroll
-            for (int i = 1; i < 4; ++i)
-                if (i < p.sep_levels && q >= p.sep_start[i]) l = i;
-            const int start = l == 0 ? p.sep_start[0] : l == 1 ? p.sep_start[1] : l == 2 ? p.sep_start[2] : p.sep_start[3];
-            const int w = l == 0 ? p.sep_w[0] : l == 1 ? p.sep_w[1] : l == 2 ? p.sep_w[2] : p.sep_w[3];
-            const int yb = l == 0 ? p.sep_y[0] : l == 1 ? p.sep_y[1] : l == 2 ? p.sep_y[2] : p.sep_y[3];
-            const int xb = l == 0 ? p.sep_x[0] : l == 1 ? p.sep_x[1] : l == 2 ? p.sep_x[2] : p.sep_x[3];
-            const int y = (q - start) / w, x = (q - start) - y * w;
-            sep_off[2 * tid] = (unsigned)(yb + y) * (unsigned)p.ldr * 4u;
-            sep_off[2 * tid + 1] = (unsigned)(xb + x) * (unsigned)p.ldr * 4u;
-        }
-    }
-
     const __amdgpu_buffer_rsrc_t rs_img =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, p.chunks * CHUNK_BYTES, 0x00020000);
     auto dma_stage = [&](int c, int stage) {                 // 33 fragments, dealt to the four waves
@@ -234,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
         const bool periodic = p.r_period > 0;
         const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(!p.R ? p.C : periodic ? p.R : p.R + (size_t)tile0 * p.ldr), 0,
-            !p.R ? 0 : (int)((p.sep_levels > 0 ? (unsigned)p.sep_rows : periodic ? (unsigned)p.r_period : rows_here) * r_row), 0x00020000);
+            !p.R ? 0 : (int)((periodic ? (unsigned)p.r_period : rows_here) * r_row), 0x00020000);
         const unsigned c_lane = (unsigned)(wave * 32 + 4 * fh) * c_row;
         const unsigned r_first = periodic ? (unsigned)((tile0 + wave * 32 + 4 * fh) % p.r_period) : (unsigned)(wave * 32 + 4 * fh);
         auto r_offset = [&](int k) {                         // byte offset of residual row (first + k), wrapped once (period >= 32)
@@ -282,29 +257,10 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const RowArgs p) {
                 // (the residual is read HERE, not in front of the MFMAs: sixteen more live registers there spill -- two
                 // workgroups per CU leave 256 -- and the other workgroup's MFMAs run under this latency)
                 float rv[16];
-                if (p.sep_levels > 0) {                       // two small tables: row-of-the-map term + column-of-the-map term
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {    // (eight rows at a time: sixteen loads in flight, as below)
-                        float ry[8], rx[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int r = 8 * half + u;
-                            const int tr = wave * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
-                            ry[u] = rx[u] = 0.f;
-                            if (use_r) {
-                                ry[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)(voff + sep_off[2 * tr]), 0, 0));
-                                rx[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)(voff + sep_off[2 * tr + 1]), 0, 0));
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) rv[8 * half + u] = ry[u] + rx[u];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        rv[r] = 0.f;
-                        if (use_r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)(voff + r_offset((r & 3) + 8 * (r >> 2))), 0, 0));
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    rv[r] = 0.f;
+                    if (use_r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)(voff + r_offset((r & 3) + 8 * (r >> 2))), 0, 0));
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -372,8 +328,7 @@ extern "C" void gom_gemm_k256_set_lines(int mode) { g_k256_lines = mode; }
 extern "C" void gom_gemm_k256_set_interleave(int on) { g_k256_interleave = on; }
 
 static int launch_rows(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr, int r_cols, int r_period,
-                       const int* levels_hw, int num_levels, int relu, float* C, int ldc, int M, int N, int K, int col_groups,
-                       int* flag, void* stream) {
+                       int relu, float* C, int ldc, int M, int N, int K, int col_groups, int* flag, void* stream) {
     GOM_CHECK_ARG(A && image && C && M >= 0 && K == KD && N > 0 && (N % CW) == 0);
     GOM_CHECK_ARG(lda >= KD && (lda % 4) == 0 && ldc >= N && (ldc % 4) == 0 && (!R || (ldr >= r_cols && (ldr % 4) == 0)));
     GOM_CHECK_ARG(((uintptr_t)A % 16) == 0 && (!A2 || ((uintptr_t)A2 % 16) == 0) && ((uintptr_t)C % 16) == 0 &&
@@ -381,7 +336,6 @@ static int launch_rows(const float* A, const float* A2, int lda, const void* ima
     GOM_CHECK_ARG(!R || (r_cols > 0 && r_cols <= N && (r_cols % CW) == 0));
     // a periodic residual: at least one wave's rows per period (one wrap per wave), the table below 4 GB (buffer descriptor)
     GOM_CHECK_ARG(r_period == 0 || (R && r_period >= 32 && (long)r_period * ldr * 4 < (1L << 32)));
-    GOM_CHECK_ARG(num_levels == 0 || (levels_hw && R && r_period > 0 && num_levels >= 1 && num_levels <= 4));
     if (M == 0) return GOM_OK;
     const int chunks = N / CW, tiles = cdiv(M, BM);
     int groups = col_groups;
@@ -396,25 +350,8 @@ static int launch_rows(const float* A, const float* A2, int lda, const void* ima
     a.lda = lda; a.ldr = ldr; a.ldc = ldc; a.M = M; a.chunks = chunks; a.cpg = cdiv(chunks, groups);
     a.r_chunks = R ? r_cols / CW : 0; a.relu = relu ? 1 : 0; a.r_period = r_period;
     a.tiles = tiles; a.frames = 1; a.tpf = tiles;
-    if (num_levels > 0) {                                    // separable table: y rows of every level, then x rows of every level
-        int pixels = 0, ys = 0, xs = 0;
-        for (int l = 0; l < num_levels; ++l) {
-            GOM_CHECK_ARG(levels_hw[2 * l] > 0 && levels_hw[2 * l + 1] > 0);
-            ys += levels_hw[2 * l];
-        }
-        for (int l = 0; l < num_levels; ++l) {
-            a.sep_start[l] = pixels; a.sep_w[l] = levels_hw[2 * l + 1];
-            a.sep_y[l] = l == 0 ? 0 : a.sep_y[l - 1] + levels_hw[2 * (l - 1)];
-            a.sep_x[l] = ys + xs;
-            xs += levels_hw[2 * l + 1];
-            pixels += levels_hw[2 * l] * levels_hw[2 * l + 1];
-        }
-        a.sep_start[num_levels] = pixels;
-        GOM_CHECK_ARG(pixels == r_period);
-        a.sep_levels = num_levels; a.sep_rows = ys + xs;
-    }
     unsigned ids = (unsigned)tiles;
-    if (g_k256_interleave && num_levels == 0 && R && r_period > 0 && M % r_period == 0 && M / r_period > 1 && tiles >= 512 && cdiv(chunks, a.cpg) == 1) {
+    if (g_k256_interleave && R && r_period > 0 && M % r_period == 0 && M / r_period > 1 && tiles >= 512 && cdiv(chunks, a.cpg) == 1) {
         a.frames = M / r_period;
         a.tpf = cdiv(tiles, a.frames);
         ids = (unsigned)(cdiv(a.tpf, 8) * 8 * a.frames);
@@ -426,7 +363,7 @@ static int launch_rows(const float* A, const float* A2, int lda, const void* ima
         e = hipFuncSetAttribute((const void*)gemm_k256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
     // whole-line stores for long problems (>= one round of two workgroups per CU), see the kernel's header
-    const bool lines = num_levels > 0 || (g_k256_lines < 0 ? tiles >= 512 : g_k256_lines != 0);   // (the separable form exists as LINES only)
+    const bool lines = g_k256_lines < 0 ? tiles >= 512 : g_k256_lines != 0;
     if (lines) hipLaunchKernelGGL(gemm_k256_kernel<true>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(gemm_k256_kernel<false>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return gom_launch_status();
@@ -435,21 +372,7 @@ static int launch_rows(const float* A, const float* A2, int lda, const void* ima
 extern "C" int gom_gemm_k256_rp_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr,
                                     int r_cols, int r_period, int relu, float* C, int ldc, int M, int N, int K, int col_groups,
                                     int* flag, void* stream) {
-    return launch_rows(A, A2, lda, image, R, ldr, r_cols, r_period, nullptr, 0, relu, C, ldc, M, N, K, col_groups, flag, stream);
-}
-
-/* The periodic residual in SEPARABLE form: row m is pixel q = m % r_period of a pyramid of `num_levels` (<= 4) maps, levels_hw
- * [host] = (H_l, W_l) per level in raster order, r_period = sum H_l W_l; R [sum H_l + sum W_l, ldr]: first one row per map ROW of
- * every level, then one row per map COLUMN of every level; the row adds R[row-of-the-map] + R[column-of-the-map] to its first
- * r_cols columns.  What it is for: the encoder's position term (src + pos) W^T = src W^T + pos W^T, where the sine embedding of
- * pos_encoding.py:62-82 puts a function of y alone in channels [0, 128) and of x alone in [128, 256): pos W^T = Ty[y] + Tx[x],
- * 1 MB of tables instead of a 57 MB one that every frame of the batch re-reads through the fabric. */
-extern "C" int gom_gemm_k256_rs_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr,
-                                    int r_cols, int r_period, const int* levels_hw, int num_levels, int relu, float* C, int ldc,
-                                    int M, int N, int K, int col_groups, int* flag, void* stream) {
-    GOM_CHECK_ARG(levels_hw && num_levels >= 1 && num_levels <= 4);
-    return launch_rows(A, A2, lda, image, R, ldr, r_cols, r_period, levels_hw, num_levels, relu, C, ldc, M, N, K, col_groups, flag,
-                       stream);
+    return launch_rows(A, A2, lda, image, R, ldr, r_cols, r_period, relu, C, ldc, M, N, K, col_groups, flag, stream);
 }
 
 extern "C" int gom_gemm_k256_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr,

@@ -31,8 +31,6 @@ struct Tracker {
     int* desc_pin = nullptr;     long desc_pin_cap = 0;
     float* ws_dev = nullptr;     long ws_cap = 0;          // floats
     float* traj_pin = nullptr;   long traj_pin_cap = 0;
-    unsigned* sync_dev = nullptr;                           // the fused match kernel's grid barrier (match_fused.hip): 2 words
-    int* status_pin = nullptr;                              // ... and its status word
     const float* proj = nullptr; int ld_proj = 0;          // hoisted projections for the next run (gom_tracker_set_projections)
 };
 
@@ -90,7 +88,6 @@ std::vector<long> sorted_unique(std::vector<long> v) {
     return v;
 }
 
-int g_fused = 0;                     // gom_tracker_set_fused (off by default: measured slower, see match_fused.hip)
 int g_sizes = -1;                    // GOM_TRACKER_SIZES=1: one stderr line per long-term match (sizes of the problem)
 int g_double_check = -1;             // GOM_TRACKER_DOUBLE_CHECK=1: run every long-term chain twice and compare (diagnostic)
 
@@ -108,24 +105,7 @@ extern "C" void* gom_tracker_create(int test_len, float overlap_thresh, int not_
     t->ffn = ffn;
     for (int i = 0; i < n_enc; ++i) t->enc[i] = enc[i];
     for (int i = 0; i < n_dec; ++i) t->dec[i] = dec[i];
-    // (allocated here, not on first use: a first use may happen while another stream of the process is capturing a graph)
-    if (hipMalloc((void**)&t->sync_dev, 2 * sizeof(unsigned)) != hipSuccess ||
-        hipMemset(t->sync_dev, 0, 2 * sizeof(unsigned)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess ||
-        hipHostMalloc((void**)&t->status_pin, sizeof(int), hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        if (t->sync_dev) (void)hipFree(t->sync_dev);
-        t->sync_dev = nullptr;                               // the tracker then always runs the chain
-        t->status_pin = nullptr;
-    }
     return t;
-}
-
-/* [host] 1: a long-term match that fits runs as ONE launch (gom_match_fused_f32, match_fused.hip: same bits as the chain);
- * 0 (default): always the chain of gom_match_scores_proj_f32.  The one-launch form is correct but measured SLOWER (the numbers
- * are at the top of match_fused.hip); it stays for A/B runs and its parity tests. */
-extern "C" int gom_tracker_set_fused(int on) {
-    g_fused = on ? 1 : 0;
-    return GOM_OK;
 }
 
 /* Hoisted projections for the NEXT gom_tracker_run call (gom_match_scores_proj_f32): device [pool rows, ld_proj >= 4d], valid
@@ -145,8 +125,6 @@ extern "C" void gom_tracker_destroy(void* h) {
     if (t->ws_dev) (void)hipFree(t->ws_dev);
     if (t->desc_pin) (void)hipHostFree(t->desc_pin);
     if (t->traj_pin) (void)hipHostFree(t->traj_pin);
-    if (t->sync_dev) (void)hipFree(t->sync_dev);
-    if (t->status_pin) (void)hipHostFree(t->status_pin);
     delete t;
 }
 
@@ -302,19 +280,11 @@ static int tracker_run_impl(void* handle, int F, const int* n, const float* boxe
             const float* d_boxes = (const float*)(d_meta + (2L * Np + M + n_k));
             const float* d_decay = t->use_decay ? d_boxes + 4L * N : nullptr;
             const int lo = p_offs[k];
-            // one launch (descriptor upload included) when the match fits the fused kernel, else the descriptor copy + the chain of
-            // 13; either way the last phase writes the n_k x M trajectory scores STRAIGHT into pinned host memory (device-visible,
-            // posted PCIe writes, complete at the stream sync below)
-            const bool fused = g_fused && t->sync_dev && t->proj &&
-                               gom_match_fused_serves(N, n_k, t->n_enc, t->n_dec, t->d, t->heads, t->ffn, 1);
+            // the descriptor copy + the chain of 13 launches; its last phase writes the n_k x M trajectory scores STRAIGHT into pinned
+            // host memory (device-visible, posted PCIe writes, complete at the stream sync below).  (The same chain as ONE
+            // persistent launch with grid barriers was bit-identical and slower -- 324 vs 132 us per match; tools/exp/match_fused/,
+            // docs/LAB_NOTES.md round 5.)
             auto run_match = [&]() -> int {
-                if (fused) {
-                    *t->status_pin = 0;
-                    return gom_match_fused_f32(pool_dev, ld_pool, t->proj, t->ld_proj, d_rows, d_offs, d_meta, d_boxes, d_decay, N, T, lo,
-                                               lo + n_k, M, t->enc, t->n_enc, t->dec, t->n_dec, t->d, t->heads, t->ffn, mw, mh,
-                                               t->with_iou, t->max_center_dist, t->ws_dev, nws, t->traj_pin, t->sync_dev,
-                                               t->status_pin, t->desc_pin, t->desc_dev, words, stream);
-                }
                 const int rc_ = gom_copy_words(t->desc_pin, t->desc_dev, words, stream);
                 if (rc_ != GOM_OK) return rc_;
                 return gom_match_scores_proj_f32(pool_dev, ld_pool, t->proj, t->ld_proj, d_rows, d_offs, d_meta, d_boxes, d_decay, N, T,
@@ -325,12 +295,6 @@ static int tracker_run_impl(void* handle, int F, const int* n, const float* boxe
             if (rc != GOM_OK) return rc;
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-            if (fused && *t->status_pin != 0) {
-                // a workgroup of the fused kernel never became resident (more workgroups than the stream has CUs): loud, not wrong
-                fprintf(stderr, "gom_tracker_run: the fused match kernel's grid barrier timed out (gom_match_fused_set_grid)\n");
-                (void)hipMemsetAsync(t->sync_dev, 0, 2 * sizeof(unsigned), st);
-                return GOM_ERR_UNSUPPORTED;
-            }
             if (g_double_check) {                                // diagnostic: the same match again must give the same bits
                 std::vector<float> first(t->traj_pin, t->traj_pin + (size_t)n_k * M);
                 rc = run_match();

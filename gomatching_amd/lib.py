@@ -72,7 +72,6 @@ SIGNATURES = {
     "gom_gemm_k256_image": (I, [P, L, I, P, P, I, I, P, L, P]),
     "gom_gemm_k256_f32": (I, [P, P, I, P, P, I, I, I, P, I, I, I, I, I, P, P]),
     "gom_gemm_k256_rp_f32": (I, [P, P, I, P, P, I, I, I, I, P, I, I, I, I, I, P, P]),
-    "gom_gemm_k256_rs_f32": (I, [P, P, I, P, P, I, I, I, P, I, I, P, I, I, I, I, I, P, P]),
     "gom_gemm_k256_set_lines": (None, [I]),
     "gom_gemm_k256_set_interleave": (None, [I]),
     "gom_stem_conv_pool_f32": (I, [P, P, L, I, P, P, P, P, I, I, I, P, P]),
@@ -156,10 +155,6 @@ SIGNATURES = {
     "gom_gather_match_f32": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P]),
     "gom_match_scores_proj_f32": (I, [P, I, P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
     "gom_tracker_set_projections": (I, [P, P, I]),
-    "gom_match_fused_serves": (I, [I, I, I, I, I, I, I, I]),
-    "gom_match_fused_set_grid": (I, [I]),
-    "gom_match_fused_f32": (I, [P, I, P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P, P, P, P, L, P]),
-    "gom_tracker_set_fused": (I, [I]),
     "gom_match_scores_f32": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, I, P, I, I, I, I, F, F, I, F, P, L, P, P]),
     "gom_tracker_create": (P, [I, F, I, I, I, F, P, I, P, I, I, I, I]),
     "gom_tracker_destroy": (None, [P]),

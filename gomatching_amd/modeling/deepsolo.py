@@ -238,34 +238,16 @@ class DeepSolo:
         # (src + pos) W^T = src W^T + (pos W^T): the second term is a [S, 384] table per layer.  The f16x3 kernel reads it
         # periodically (row m -> table row m % S: 57 MB per call instead of a 457 MB broadcast copy at 8 x 37 171 tokens)
         self._pos_periodic = ops.GEMM_MODE == "f16x3" and ops.POS_PERIODIC
-        # ... and SEPARABLY (round 5): the sine embedding (pos_encoding.py:62-82) puts a function of y alone (+ level_embed) in
-        # channels [0, 128) and of x alone in [128, 256), so pos W^T = Ty[y] + Tx[x]: one table row per map row and per map column
-        # (655 rows = 1 MB at 1000 x 1778) that stays in L2, instead of 57 MB per layer that every frame re-reads through the fabric
-        # (PMC: 1.31 x the algorithmic bytes of the projection -> 1.0 x).  Same GEMM kernel on the half-zero rows; the two partial
-        # sums differ from the one-table sum by fp32 rounding only.  Padded batches keep the per-pixel table.
-        pos_sep = self._pos_periodic and ops.POS_SEPARABLE and vshapes is None and len(shapes) <= 4 and \
-            all(isinstance(L["attn"]["raw_value"], ops.K256Linear) for L in self.enc)
-        if pos_sep:
-            rows_y, rows_x = [], []
-            for l, (H, W) in enumerate(shapes):
-                a = int(lsi[l])
-                y = torch.zeros((H, 256), dtype=_f32, device=dev)
-                y[:, :128] = lvl_pos[a:a + H * W:W, :128]         # pixel (r, 0) of the level: the y half of row r
-                x = torch.zeros((W, 256), dtype=_f32, device=dev)
-                x[:, 128:] = lvl_pos[a:a + W, 128:]                # pixel (0, c): the x half of column c
-                rows_y.append(y)
-                rows_x.append(x)
-            halves = torch.cat(rows_y + rows_x)
-            pos_w = [ops.gemm(halves, L["attn"]["raw"][0]) for L in self.enc]
-        else:
-            pos_w = [ops.gemm(lvl_pos, L["attn"]["raw"][0]) for L in self.enc]
+        # (the same term as Ty[map row] + Tx[map column] -- the sine embedding puts a function of y alone in channels [0, 128) and of
+        # x alone in [128, 256), 1 MB of tables -- removed the projection's surplus traffic and none of its time: the re-reads are
+        # Infinity Cache hits; docs/LAB_NOTES.md round 5, profiles/r05_k256_separable_*)
+        pos_w = [ops.gemm(lvl_pos, L["attn"]["raw"][0]) for L in self.enc]
         if not self._pos_periodic:
             pos_w = [ops.broadcast_rows(t_, B).view(B * S, 384) for t_ in pos_w]
         geo = {
             "S": S, "shapes": ss_d, "lsi": lsi_d, "lsi_host": [int(v) for v in lsi], "pos_w": pos_w,
             "hw0": (int(shapes[0][0]), int(shapes[0][1])),
             "pos_periodic": self._pos_periodic,
-            "pos_levels": [(int(h), int(w)) for h, w in shapes] if pos_sep else None,
             "lvl_pos": ops.broadcast_rows(lvl_pos, B).view(B * S, 256),
             "enc_ref": ops.broadcast_rows(ops.encoder_reference_points(ss_d, lsi_d, S, vs_d), B).view(B * S, 1, 2),
             "valid": ops.proposal_valid(ss_d, lsi_d, S, vs_d),
@@ -312,7 +294,7 @@ class DeepSolo:
         S = geo["S"]
         for li, L in enumerate(self.enc):
             rv = ops.linear(src, L["attn"]["raw_value"], R=geo["pos_w"][li], r_cols=384,
-                            r_period=S if geo["pos_periodic"] else 0, r_levels=geo["pos_levels"])   # [B*S, 384 | 256]
+                            r_period=S if geo["pos_periodic"] else 0)   # [B*S, 384 | 256]
             if geo["vr"] is not None:                      # padded batch: value.masked_fill(padding_mask, 0)
                 ops.zero_padded_tokens_(rv, 384, 256, geo["shapes"], geo["lsi"], geo["vshapes"], B, S)
             samp = ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, geo["vr"],

@@ -868,7 +868,6 @@ class GoMatching:
         torch.cuda.synchronize(self.device)
         self._lane_stream = self._det_stream = None              # (the queues stay cached per mask in ops.masked_stream)
         ops._L().gom_ffn_set_stream_cus(0)
-        ops._L().gom_match_fused_set_grid(32)
         if n_cus <= 0:
             return
         total = torch.cuda.get_device_properties(self.device).multi_processor_count
@@ -883,8 +882,6 @@ class GoMatching:
         self._lane_stream = ops.masked_stream(trk, self.device)
         self._det_stream = ops.masked_stream(det, self.device)
         ops._L().gom_ffn_set_stream_cus(total - n_cus)           # the fused FFN's tail-round rule counts the detector's CUs
-        # the one-launch match (csrc/match_fused.hip) needs all its workgroups resident at once: never more than the lane has CUs
-        ops._L().gom_match_fused_set_grid(min(32, n_cus))
 
     def begin_batch(self, instances, num_new_frames):
         """Keep the carried-over window's embeddings addressable, drop everything older, size the pool."""

@@ -502,18 +502,16 @@ def k256_linear(w, bias=None):
     return (w, bias)
 
 
-def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0, r_period=0, r_levels=None):
+def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0, r_period=0):
     """act((x [+ A2]) @ W^T + b [+ R]) for `lin` = K256Linear or a (weight, bias) pair; r_period > 0: row m adds
-    R[m % r_period] (ops.gemm); `r_levels` = [(H_l, W_l), ...]: the periodic residual in separable form, R = one row per map row
-    of every level then one per map column, row m adds R[its map row] + R[its map column] (gom_gemm_k256_rs_f32).  `groups`: column groups of the row-resident kernel's launch; the product always launches ONE
+    R[m % r_period] (ops.gemm).  `groups`: column groups of the row-resident kernel's launch; the product always launches ONE
     (every workgroup splits its rows once and walks all columns): splitting the columns over more workgroups re-splits the
     rows per group and measured slower in the step (the decoder's 30 launches: 689 -> 878 us, bench.py same box)."""
     if not isinstance(lin, K256Linear):
-        assert r_levels is None, "the separable periodic residual is served by the row-resident kernel only"
         return gemm(x, lin[0], bias=lin[1], A2=A2, R=R, relu=relu, r_cols=r_cols, out=out, r_period=r_period)
     M = x.shape[0]
-    # an explicit `groups` forces the kernel (tests, tools); so does the separable residual (no other kernel reads that table)
-    if M == 0 or not (groups or r_levels is not None or k256_wins(M, lin.N, A2 is not None)):
+    # an explicit `groups` forces the kernel (tests, tools)
+    if M == 0 or not (groups or k256_wins(M, lin.N, A2 is not None)):
         return gemm(x, lin.W, bias=lin.bias, A2=A2, R=R, relu=relu, r_cols=r_cols, out=out, r_period=r_period)
     assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == lin.K and x.dtype == _f32
     lda = x.stride(0) if M > 1 else lin.K
@@ -533,21 +531,13 @@ def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0,
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if r_levels is not None:                                 # separable periodic residual: R = (map-row rows | map-column rows)
-        flat = [int(v) for hw in r_levels for v in hw]
-        assert R is not None and r_period == sum(h * w for h, w in r_levels) and R.shape[0] == sum(h + w for h, w in r_levels)
-        lv = (ctypes.c_int * len(flat))(*flat)
-        check(_L().gom_gemm_k256_rs_f32(_p(x), _p(A2), lda, _p(lin.image), _p(R), ldr, rc, int(r_period), lv, len(r_levels),
-                                        1 if relu else 0, _p(out), out.stride(0) if out.shape[0] > 1 else N, M, N, lin.K,
-                                        groups or 1, _p(range_flag(x.device)), _stream()), "gom_gemm_k256_rs_f32")
-    else:
-        check(_L().gom_gemm_k256_rp_f32(_p(x), _p(A2), lda, _p(lin.image), _p(R), ldr, rc, int(r_period), 1 if relu else 0, _p(out),
-                                        out.stride(0) if out.shape[0] > 1 else N, M, N, lin.K, groups or 1,
-                                        _p(range_flag(x.device)), _stream()), "gom_gemm_k256_rp_f32")
+    check(_L().gom_gemm_k256_rp_f32(_p(x), _p(A2), lda, _p(lin.image), _p(R), ldr, rc, int(r_period), 1 if relu else 0, _p(out),
+                                    out.stride(0) if out.shape[0] > 1 else N, M, N, lin.K, groups or 1,
+                                    _p(range_flag(x.device)), _stream()), "gom_gemm_k256_rp_f32")
     if prof is not None:
         e1.record()
         nbytes = 4.0 * M * lin.K * (2 if A2 is not None else 1) + lin.image.numel() + 4.0 * M * N \
-            + 4.0 * (R.shape[0] if r_levels is not None else (r_period or M)) * rc
+            + 4.0 * (r_period or M) * rc
         prof.append((e0, e1, 2.0 * M * N * lin.K, nbytes, "k256:%dx%dx%d" % (M, N, lin.K), _profile_scope))
     return out
 
@@ -555,10 +545,6 @@ def linear(x, lin, A2=None, R=None, relu=False, r_cols=None, out=None, groups=0,
 HOIST_MATCH_PROJECTIONS = _switch("HOIST_MATCH_PROJECTIONS")   # native tracker: per-row matcher projections computed once per detection
 PROJ_LN = _switch("PROJ_LN")         # f16x3 back-end: out_proj + residual + LayerNorm of every attention block as one launch
 POS_PERIODIC = _switch("POS_PERIODIC")   # f16x3 back-end: the encoder's position table read as row m % S (no broadcast copy)
-# ... and as Ty[map row] + Tx[map column]: 1 MB of tables instead of 57 MB per layer (gom_gemm_k256_rs_f32).  OFF by default: the
-# projection's fabric traffic drops to its algorithmic bytes but its time does not move (273.3 vs 273.3 frames/s, three alternating
-# pairs: the re-reads are Infinity Cache hits), and the two partial sums move the detector's numerics by an fp32 rounding
-POS_SEPARABLE = _switch("POS_SEPARABLE", False)
 
 
 PROJ_LN_V2 = _switch("PROJ_LN_V2")   # out_proj + LayerNorm launches on 64-row tiles at two workgroups per CU (round 5); 0: the 128-row form
@@ -1811,31 +1797,17 @@ def match_scores(pool, rows, frame_offsets, meta, boxes, decay, N, T, lo, hi, nu
 
 
 def match_scores_proj(pool, proj, rows, frame_offsets, meta, boxes, decay, N, T, lo, hi, num_tracks, enc, n_enc, dec, n_dec, d,
-                      heads, ffn, img_w, img_h, with_iou, max_center_dist, fused=False, desc=None):
+                      heads, ffn, img_w, img_h, with_iou, max_center_dist):
     """The match with hoisted projections (proj [pool rows, >= 4 d]: encoder-layer-0 in-projection | decoder-layer-0 query
-    projection of every pool row): `fused=False` the chain of 13 launches (gom_match_scores_proj_f32), `fused=True` the one-launch
-    form (gom_match_fused_f32, csrc/match_fused.hip) -- same bits.  `desc` = (pinned host int32 tensor, device int32 tensor): the
-    fused kernel first uploads the descriptor block the index arguments point into.  Returns traj [hi - lo, num_tracks]."""
+    projection of every pool row): the chain of 13 launches (gom_match_scores_proj_f32).  Returns traj [hi - lo, num_tracks]."""
     n_k = hi - lo
     nws = _L().gom_match_workspace_floats(N, n_k, d, ffn)
     ws = torch.empty((nws,), dtype=_f32, device=pool.device)
     traj = torch.empty((n_k, num_tracks), dtype=_f32, device=pool.device)
-    if not fused:
-        check(_L().gom_match_scores_proj_f32(_p(pool), pool.stride(0), _p(proj), proj.stride(0), _p(rows), _p(frame_offsets),
-                                             _p(meta), _p(boxes), _p(decay), N, T, lo, hi, num_tracks, enc, n_enc, dec, n_dec, d,
-                                             heads, ffn, float(img_w), float(img_h), 1 if with_iou else 0, float(max_center_dist),
-                                             _p(ws), nws, _p(traj), _stream()), "gom_match_scores_proj_f32")
-        return traj
-    sync = torch.zeros((2,), dtype=torch.int32, device=pool.device)
-    status = torch.zeros((1,), dtype=torch.int32, device=pool.device)
-    dh, dd, dw = (desc[0].data_ptr(), desc[1].data_ptr(), desc[0].numel()) if desc is not None else (None, None, 0)
-    check(_L().gom_match_fused_f32(_p(pool), pool.stride(0), _p(proj), proj.stride(0), _p(rows), _p(frame_offsets), _p(meta),
-                                   _p(boxes), _p(decay), N, T, lo, hi, num_tracks, enc, n_enc, dec, n_dec, d, heads, ffn,
-                                   float(img_w), float(img_h), 1 if with_iou else 0, float(max_center_dist), _p(ws), nws,
-                                   _p(traj), _p(sync), _p(status), dh, dd, dw, _stream()), "gom_match_fused_f32")
-    if int(status.item()) != 0:
-        raise _lib_mod.GomError("gom_match_fused_f32: the grid barrier timed out (more workgroups than resident slots)")
-    assert int(sync[0].item()) == 0                           # the arrival count is back at zero
+    check(_L().gom_match_scores_proj_f32(_p(pool), pool.stride(0), _p(proj), proj.stride(0), _p(rows), _p(frame_offsets),
+                                         _p(meta), _p(boxes), _p(decay), N, T, lo, hi, num_tracks, enc, n_enc, dec, n_dec, d,
+                                         heads, ffn, float(img_w), float(img_h), 1 if with_iou else 0, float(max_center_dist),
+                                         _p(ws), nws, _p(traj), _stream()), "gom_match_scores_proj_f32")
     return traj
 
 

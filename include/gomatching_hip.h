@@ -287,15 +287,6 @@ int gom_gemm_k256_f32(const float* A, const float* A2, int lda, const void* imag
 int gom_gemm_k256_rp_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr, int r_cols,
                          int r_period, int relu, float* C, int ldc, int M, int N, int K, int col_groups, int* flag,
                          void* stream);
-/* ... the periodic residual in SEPARABLE form (round 5): row m is pixel q = m % r_period of a pyramid of num_levels (<= 4) maps,
- * levels_hw [host, num_levels x 2] = (H_l, W_l) in raster order with sum H_l W_l = r_period; R [sum H_l + sum W_l, ldr] holds one
- * row per map ROW of every level, then one row per map COLUMN of every level, and row m adds R[its map row] + R[its map column]
- * to its first r_cols columns.  For the encoder's position term: PositionalEncoding2D (pos_encoding.py:62-82) puts a function of y
- * alone in channels [0, 128) and of x alone in [128, 256), so pos W^T = Ty[y] + Tx[x]: 1 MB of tables that stay in L2 instead of a
- * 57 MB table re-read once per frame of the batch (deformable_transformer.py:235-248).  Whole-line-store form only. */
-int gom_gemm_k256_rs_f32(const float* A, const float* A2, int lda, const void* image, const float* R, int ldr, int r_cols,
-                         int r_period, const int* levels_hw, int num_levels, int relu, float* C, int ldc, int M, int N, int K,
-                         int col_groups, int* flag, void* stream);
 void gom_gemm_k256_set_lines(int mode);
 /* Periodic residual, several periods (frames), long problem: workgroups take the row tiles frame-interleaved per XCD, so that the
  * table rows of a position are fetched into an XCD's L2 once for all frames (1 = on, 0 = index order = default: the interleave
@@ -613,30 +604,6 @@ int gom_match_scores_f32(const float* pool, int ld_pool, const int* rows, const 
                          const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec, int n_dec, int d,
                          int heads, int ffn, float img_w, float img_h, int with_iou, float max_center_dist,
                          float* workspace, long workspace_floats, float* traj, void* stream);
-/* ---- the same chain as ONE launch (csrc/match_fused.hip) -------------------------------------------------------------------
- * Replaces, for a match that fits, the 13 dependent launches of gom_match_scores_proj_f32 (lstmatcher.py:333-381,
- * transformer.py:60-96, gom_lstmatcher.py:429-445/510-547) by a small persistent grid that walks the chain's phases with grid
- * barriers between them; every phase runs the chain kernels' own wave tasks (csrc/tracker_tasks.h), so the trajectory scores
- * are the chain's bit for bit.  Serves: hoisted projections, 1 <= N <= 64 window rows, head_dim 128.
- * [host] gom_match_fused_serves: 1 if gom_match_fused_f32 takes the problem, 0 if it needs the chain.
- * [host] gom_match_fused_set_grid: workgroups of the launch (default 32); every one must be resident at once, so never more than
- *        the CUs of the stream the match runs on.
- * [device] gom_match_fused_f32: arguments as gom_match_scores_proj_f32, plus `sync` [device, 2 words, zero when first used; the
- *        barrier's state, owned by one match at a time], `status` [device-visible int, e.g. pinned host memory: the caller clears
- *        it; 1 after the stream is done = a barrier gave up after ~2 s, results invalid] and an optional descriptor upload
- *        (desc_host != NULL: `desc_words` 32-bit words are first copied from device-visible host memory to desc_dev, the block
- *        rows / frame_offsets / meta / boxes / decay point into).  GOM_ERR_UNSUPPORTED when the problem does not fit. */
-int gom_match_fused_serves(int N, int n_k, int n_enc, int n_dec, int d, int heads, int ffn, int has_proj);
-int gom_match_fused_set_grid(int workgroups);
-int gom_match_fused_f32(const float* pool, int ld_pool, const float* proj, int ld_proj, const int* rows,
-                        const int* frame_offsets, const int* meta, const float* boxes, const float* decay, int N, int T, int lo,
-                        int hi, int num_tracks, const gom_matcher_layer* enc, int n_enc, const gom_matcher_layer* dec, int n_dec,
-                        int d, int heads, int ffn, float img_w, float img_h, int with_iou, float max_center_dist, float* workspace,
-                        long workspace_floats, float* traj, unsigned int* sync, int* status, const void* desc_host, void* desc_dev,
-                        long desc_words, void* stream);
-/* [host] 1: gom_tracker_run* hands a long-term match that fits to gom_match_fused_f32; 0 (default): always the chain
- * (the one-launch form is bit-identical but measured slower: csrc/match_fused.hip). */
-int gom_tracker_set_fused(int on);
 /* [host + device] The per-frame id recurrence of GoMatching.track_frames for all frames of a call behind ONE crossing
  * (tracker_rt.hip; gom_lstmatcher.py:366-564): short-term assignment from precomputed score matrices, long-term match
  * (selection, descriptors, gom_match_scores_f32, LSA, thresholds, id allocation).  Host arrays in, ids out; see the

@@ -68,21 +68,10 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.gom_copy_words(None, p, 4, None) == INVALID
     assert L.gom_tracker_create(0, 0.2, 1, 1, 1, 1.0, None, 0, None, 0, 1024, 8, 1024) is None           # test_len < 1
     assert L.gom_tracker_create(6, 0.2, 1, 1, 1, 1.0, None, 1, None, 0, 1024, 8, 1024) is None           # layers without weights
-    # round 5: the one-launch long-term match and the separable periodic residual of the row-resident K = 256 GEMM
-    UNSUPPORTED = 2
-    assert [L.gom_match_fused_serves(*a) for a in ((64, 9, 1, 1, 1024, 8, 1024, 1), (65, 9, 1, 1, 1024, 8, 1024, 1),
-                                                    (40, 9, 1, 1, 1024, 8, 1024, 0), (40, 9, 1, 1, 256, 8, 1024, 1),
-                                                    (40, 0, 1, 1, 1024, 8, 1024, 1), (40, 41, 1, 1, 1024, 8, 1024, 1),
-                                                    (40, 9, 5, 1, 1024, 8, 1024, 1))] == [1, 0, 0, 0, 0, 0, 0]
-    assert L.gom_match_fused_set_grid(0) == INVALID and L.gom_match_fused_set_grid(257) == INVALID and L.gom_match_fused_set_grid(32) == 0
-    lay = (ctypes.c_void_p * 8)(*([0x1000] * 8))
-    common = (p, 1024, p, 4096, p, p, p, p, None, 70, 7, 60, 70, 5, lay, 1, lay, 1, 1024, 8, 1024, 1.0, 1.0, 1, 50.0, p, 1 << 30, p)
-    assert L.gom_match_fused_f32(*common, p, p, None, None, 0, None) == UNSUPPORTED                      # 70 window rows: the chain's case
-    assert L.gom_match_fused_f32(*common, None, p, None, None, 0, None) == INVALID                       # no barrier state
-    lv = (ctypes.c_int * 4)(5, 7, 3, 4)                                                                  # 35 + 12 = 47 pixels
-    k256 = lambda period, levels, n: L.gom_gemm_k256_rs_f32(p, None, 256, p, p, 64, 64, period, levels, n, 0, p, 64, 94, 64, 256, 1, None, None)
-    assert k256(48, lv, 2) == INVALID                                                                    # the maps do not add up to the period
-    assert k256(47, None, 2) == INVALID and k256(47, lv, 5) == INVALID and k256(47, lv, 0) == INVALID
+    # round 6: the CU-cooperative decoder tail
+    assert L.gom_dec_tail2_wave_bytes(256, 1024, 1, 1) == (64 + 12 * 64) * 1024 and L.gom_dec_tail2_wave_bytes(256, 1000, 1, 1) == -1
+    assert L.gom_dec_tail2_image_lin(p, 1, 128, p, 1 << 20, 0, None) == INVALID                          # ld < 256
+    assert L.gom_dec_tail2_image_mlp(p, 1, 256, p, 1, 256, 192, p, 1 << 20, 0, None) == INVALID           # hidden % 128 != 0
 
 
 def test_library_has_no_packed_fp32_instructions():

@@ -77,43 +77,6 @@ def test_k256_store_forms_and_periodic_residual(lines, M, N, period):
     ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
 
 
-@pytest.mark.parametrize("levels,frames,N", [([(125, 223), (63, 112), (32, 56), (16, 28)], 2, 640), ([(5, 7), (3, 4), (2, 2), (1, 1)], 9, 96),
-                                             ([(9, 300)], 3, 128), ([(40, 3), (1, 50)], 4, 64), ([(1, 33)], 5, 64)])
-def test_k256_separable_periodic_residual(levels, frames, N):
-    """gom_gemm_k256_rs_f32: row m = pixel q of a pyramid adds Ty[map row] + Tx[map column] -- bit-equal to the per-pixel periodic
-    table T[q] = Ty[y] + Tx[x] (the encoder's position term, deepsolo.py geometry): levels narrower than a wave's 32 rows (several
-    map rows per wave), single-row and single-column maps, a ragged last tile, relu, column groups, an `out` view."""
-    ops = _ops()
-    S = sum(h * w for h, w in levels)
-    M = frames * S - 3                                            # the last frame is cut: tail tile + clamped rows
-    g = torch.Generator().manual_seed(S + N)
-    A = torch.randn((M, 256), generator=g).to(DEV) * 1.3
-    W = (torch.randn((N, 256), generator=g) * torch.logspace(-2, 1, N).view(-1, 1)).to(DEV)
-    b = torch.randn((N,), generator=g).to(DEV)
-    lin = ops.K256Linear(ops.split_weight(W, kind="f16x3"), b)
-    rc = max(32, (N * 3 // 5) // 32 * 32)
-    ty = [torch.randn((h, rc), generator=g) for h, w in levels]
-    tx = [torch.randn((w, rc), generator=g) for h, w in levels]
-    full = torch.cat([(ty[l][:, None, :] + tx[l][None, :, :]).reshape(-1, rc) for l in range(len(levels))]).to(DEV)   # [S, rc]
-    sep = torch.cat(ty + tx).to(DEV)
-    assert S >= 32
-    from gomatching_amd import lib
-    try:
-        lib.load().gom_gemm_k256_set_lines(1)
-        for groups in (1, 2):
-            for relu in (False, True):
-                ref = ops.linear(A, lin, groups=groups, R=full, r_cols=rc, r_period=S, relu=relu)
-                got = ops.linear(A, lin, groups=groups, R=sep, r_cols=rc, r_period=S, r_levels=levels, relu=relu)
-                assert torch.equal(got, ref), (groups, relu, float((got - ref).abs().max()))
-        wide = torch.full((M, N + 64), 7.0, device=DEV)
-        ops.linear(A, lin, out=wide[:, 32:32 + N], R=sep, r_cols=rc, r_period=S, r_levels=levels)
-        assert torch.equal(wide[:, 32:32 + N], ops.linear(A, lin, groups=1, R=full, r_cols=rc, r_period=S))
-        assert float((wide[:, :32] - 7.0).abs().max()) == 0.0 and float((wide[:, 32 + N:] - 7.0).abs().max()) == 0.0
-    finally:
-        lib.load().gom_gemm_k256_set_lines(-1)
-    ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
-
-
 def test_k256_views_slices_and_range_flag():
     """Row-strided operands (column slices of wider buffers), a weight ROW slice (the fused in_proj's q|k and v parts), no bias,
     an `out` view -- and the fp16 range contract: an activation beyond 65504 raises at the next check."""

@@ -75,37 +75,6 @@ def test_deepsolo_mini_golden(builtin, tag, voc, gemm_mode):
         _close(out[k].view(*shape), g[k], 2e-4, k)
 
 
-def test_deepsolo_mini_golden_with_the_separable_position_table():
-    """ops.POS_SEPARABLE (off by default): the encoder's position term as Ty[map row] + Tx[map column] (gom_gemm_k256_rs_f32, 1 MB
-    of tables instead of one row per pixel) -- against the reference's own outputs with the default run's tolerances, the top-k
-    proposals identical, and the path really taken."""
-    from gomatching_amd import ops
-    from gomatching_amd.weights import synth_state_dict
-    from gomatching_amd.modeling import DeepSolo
-    g = golden("deepsolo_ic15.npz")
-    cfg = mini_cfg("icdar15")
-    sd = synth_state_dict(cfg, seed=7)
-    old = ops.POS_SEPARABLE
-    try:
-        ops.POS_SEPARABLE = True
-        with ops.gemm_mode("f16x3"):
-            net = DeepSolo(cfg, sd, DEV)
-            feats = [t(g["feat%d" % i]).permute(0, 2, 3, 1).contiguous().to(DEV) for i in range(3)]
-            taps = {}
-            out = net.forward(feats, taps=taps)
-            assert any(geo["pos_levels"] is not None for geo in net._geom.values()), "the separable table was not used"
-            assert all(geo["pos_w"][0].shape[0] == sum(h + w for h, w in geo["pos_levels"]) for geo in net._geom.values())
-    finally:
-        ops.POS_SEPARABLE = old
-    B, nq, P = 2, cfg.MODEL.TRANSFORMER.NUM_QUERIES, 25
-    _close(taps["memory"].view(B, -1, 256), g["tap_memory"], 1e-4, "memory")
-    assert torch.equal(taps["topk"].cpu().long(), t(g["tap_topk"])), "top-k proposals differ"
-    _close(taps["init_ref"].view(B, nq, P, 2), g["tap_init_ref"], 1e-5, "init_ref")
-    for k, shape in (("pred_logits", (B, nq, P, 1)), ("pred_ctrl_points", (B, nq, P, 2)), ("pred_bd_points", (B, nq, P, 4)),
-                     ("query_features", (B, nq, P, 256))):
-        _close(out[k].view(*shape), g[k], 2e-4, k)
-
-
 def test_deepsolo_padded_batch_golden(gemm_mode):
     """Padded batch (41x70 images inside 64x96): the mask-aware kernels against the reference's own outputs."""
     from gomatching_amd.weights import synth_state_dict

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXP = os.path.join(ROOT, "tools", "exp")
 SRC = os.path.join(ROOT, "gomatching_amd", "csrc", "dec_tail2.hip")
-DEFAULT = {"s1_3_s2_2": "", "s1_3_s2_7": "-DT2_SPREAD2=7", "s1_2_s2_2": "-DT2_SPREAD1=2", "s1_1_s2_1": "-DT2_SPREAD1=1 -DT2_SPREAD2=1"}
+DEFAULT = {"base": "", "stamps": "-DT2_STAMPS"}
 
 
 def build(variants):
@@ -79,6 +79,33 @@ def main():
         torch.cuda.synchronize()
         print("%-14s max |d| vs form 1: tgt %.2e ref %.2e qpos %.2e, flag %d" % (name, float((out - want[0]).abs().max()),
               float((nref - want[1]).abs().max()), float((qp - want[2]).abs().max()), int(flag.item())))
+    for name, lib in libs.items():
+        if not hasattr(lib, "gom_dec_tail2_set_stamps"):
+            continue
+        try:
+            lib.gom_dec_tail2_set_stamps
+        except AttributeError:
+            continue
+        nwg = (M + 79) // 80
+        st = torch.zeros((nwg, 4, 16), dtype=torch.int64, device="cuda")
+        lib.gom_dec_tail2_set_stamps.argtypes = [ctypes.c_void_p]
+        run(lib)
+        torch.cuda.synchronize()
+        assert lib.gom_dec_tail2_set_stamps(ctypes.c_void_p(st.data_ptr())) == 0
+        run(lib)
+        torch.cuda.synchronize()
+        lib.gom_dec_tail2_set_stamps(None)
+        t = st.double()
+        names = ["prologue", "proj loop", "proj epilogue", "FFN loop", "FFN epilogue", "coord loop", "coord epilogue + sine", "qpos loop", "end"]
+        med = t[:, :, :9].median(dim=0).values            # [wave][slot]
+        print("%s: cycles since the wave's start (median over workgroups), per wave" % name)
+        prev = torch.zeros(4, dtype=torch.float64, device="cuda")
+        for i, nm in enumerate(names):
+            print("  %-24s %s   (+%s)" % (nm, ["%7.0f" % v for v in med[:, i].tolist()], ["%6.0f" % v for v in (med[:, i] - prev).tolist()]))
+            prev = med[:, i]
+        for i, nm in ((10, "GEMM1 (all 12 chunks)"), (11, "barrier + act + barrier"), (12, "GEMM2")):
+            print("  %-24s %s" % (nm, ["%7.0f" % v for v in t[:, :, i].median(dim=0).values.tolist()]))
+        print("  slowest workgroup's end: %.0f, fastest: %.0f" % (float(t[:, :, 8].max()), float(t[:, :, 8].min())))
     for rnd in range(3):
         line = "round %d  M = %d with out_proj: form 1 %.1f us" % (rnd, M, burst(lambda: ops.dec_tail(samp, b1, R, want_qpos=True, residual=X)))
         for name, lib in libs.items():
