@@ -745,12 +745,16 @@ def main():
         n0 = 0
         for geo_ in (hw0 or {}).values():
             n0 = geo_["hw0"][0] * geo_["hw0"][1]
+            if len(geo_["hw0"]) >= 4 and getattr(ops, "MSDA_WINDOW_L1", False):
+                n0 += geo_["hw0"][2] * geo_["hw0"][3]
         tail_grid = ((FRAMES_PER_GPU * (n_tok - n0) + 3) // 4) * 256
+        # (pmc_traffic sums the per-call bytes of every window launch of an encoder call: the level-0 and the level-1 grids)
         t_win, t_tail = pmc_traffic("msda_window_kernel"), pmc_traffic("msda_fused_lanes_kernel<false> [grid %d]" % tail_grid)
         enc_traffic = (t_win + t_tail) if (win_on and t_win is not None and t_tail is not None) else None
         line["roofline_msda"] = {
-            "bound": "hbm", "kernel": ("msda_window_kernel<8,16,5,576,0,4> + msda_fused_lanes_kernel<false> (an encoder call = the two "
-                                       "launches, one after the other; a decoder call = the lane kernel)") if win_on else "msda_fused_lanes_kernel<false>",
+            "bound": "hbm", "kernel": ("msda_window_kernel<8,16,5,576,4> (level-0 queries) + <4,8,5,576,1> (level-1 queries) + "
+                                       "msda_fused_lanes_kernel<false> (an encoder call = the three launches, one after the other; a "
+                                       "decoder call = the lane kernel)") if win_on else "msda_fused_lanes_kernel<false>",
             "achieved": mb / (md * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
             "frac": mb / (md * 1e-3) / 1e12 / 8.0,
             "traffic": enc_traffic if win_on else pmc_traffic("msda_fused_lanes_kernel<false>"),
@@ -760,6 +764,11 @@ def main():
             "share_of_step_time": (md / PROFILE_STEPS) / (elapsed / args.steps * 1e3),
             # the two populations apart: the blended figure flatters the encoder launches
             "encoder_launches": msda_pop(enc_p) if enc_p else None,
+            # ops.MSDA_WINDOW_POLICY: share of the window launches' octet groups that left their windows, measured once per layer on
+            # its first eager call; a layer above ops.MSDA_WINDOW_MAX_FALLBACK runs on the gather kernel
+            "window_fallback_share_per_encoder_layer": [model.detection_transformer.msda_window_fallback.get(i_)
+                                                        for i_ in range(model.detection_transformer.n_enc)],
+            "window_layers": [bool(L_.get("msda_window", True)) for L_ in model.detection_transformer.enc],
             "decoder_launches": dict(msda_pop(dec_p), note="algorithmic bytes here = the value map once + raw + output; for "
                                      "%d sparse queries per frame (512 corner lines each: %.0f MB of line reads per launch against a "
                                      "%.0f MB map) 'the map once' is an upper bound of the distinct lines touched, not a minimum -- "
@@ -817,10 +826,16 @@ def main():
         dd = sum(p_[0].elapsed_time(p_[1]) for p_ in dec_prof) / PROFILE_STEPS * 1e-3
         def pipe_busy(kind, us_per_launch):
             """Static MFMA work of the decoder's launches per wave (see csrc/dec_attn.hip, dec_tail.hip) against their duration."""
+            # the tail launch by the form in effect (ops.DEC_TAIL2, ops.DEC_TAIL_PROJ): form 2 = 80-row workgroups, a wave issues 480
+            # MFMAs per 128-unit chunk and per plain 256 -> 256 layer; form 1 = 128-row workgroups, 192 per 32-unit stage
+            tail2 = bool(getattr(ops, "DEC_TAIL2", False)) and F_ % 128 == 0
+            with_proj = 1 if getattr(ops, "DEC_TAIL_PROJ", False) else 0
+            tail_cyc = (with_proj + F_ // 128 + 2 + 2 * (L_ - 1) / L_) * 480 * 16 if tail2 else \
+                (4 * with_proj + F_ // 32 + 8 + 8 * (L_ - 1) / L_) * 192 * 16         # (the last layer's launch has no ref_point_head block)
             wgs = {"decattn intra": (rows // T_.NUM_POINTS + 3) // 4, "decattn inter": FRAMES_PER_GPU * T_.NUM_POINTS,
-                   "decattn inter+raw": FRAMES_PER_GPU * T_.NUM_POINTS, "dectail": (rows + 127) // 128}
+                   "decattn inter+raw": FRAMES_PER_GPU * T_.NUM_POINTS, "dectail": (rows + 79) // 80 if tail2 else (rows + 127) // 128}
             cyc = {"decattn intra": (32 * 48 + 8 * 12) * 32, "decattn inter": (32 * 48 + 8 * 48) * 32,
-                   "decattn inter+raw": (44 * 48 + 8 * 48) * 32, "dectail": (4 + F_ // 32 + 8 + 8 * (L_ - 1) / L_) * 192 * 16}     # (the last layer's launch has no ref_point_head block)
+                   "decattn inter+raw": (44 * 48 + 8 * 48) * 32, "dectail": tail_cyc}
             if kind not in cyc or us_per_launch <= 0:
                 return {}
             return {"mfma_cycles_per_wave": cyc[kind], "matrix_pipe_busy": cyc[kind] / (us_per_launch * 2400.0),
@@ -870,6 +885,17 @@ def main():
     # for like across rounds; `roofline_top` is the largest-share view of THIS run, whichever kernel that is.
     pinned = "roofline_fused_ffn" if "roofline_fused_ffn" in shares else top
     line["roofline"] = dict(contract_view(pinned), pinned=True)
+    # the other two figures a reader of the contract object asks for first (VERDICT r5 "small" 8): north_star's decoder figure
+    # and the MSDA call that holds the largest share; the full objects are `roofline_decoder_qside` / `roofline_msda`
+    dq, ms_ = line.get("roofline_decoder_qside") or {}, line.get("roofline_msda") or {}
+    line["roofline"]["also"] = {
+        "decoder_qside_frac_of_mfma_peak": dq.get("frac"), "decoder_qside_us_per_step": dq.get("us_per_step"),
+        "decoder_qside_launch_us": {k_: (v_["us"] / v_["launches"]) for k_, v_ in (dq.get("by_kernel_us_per_step") or {}).items()
+                                    if v_.get("launches")},
+        "msda_encoder_call": ms_.get("encoder_launches"), "msda_share_of_step_time": ms_.get("share_of_step_time"),
+        "msda_window_fallback_share_per_encoder_layer": ms_.get("window_fallback_share_per_encoder_layer"),
+        "in_kernel_clock_note": "fractions are against peaks at 2.4 GHz; under its MFMA-dense kernels the chip holds 1.4-2.1 GHz "
+                                "(profiles/r05_clock_stamps.log, profiles/r06_lds_rate.log: 1.76-1.88 GHz in bare MFMA + LDS loops)"}
     line["roofline_top"] = contract_view(top)
     solo = rank == 0 and world == 1 and args.backbone == "r50" and args.emulate_world == 1
     line["fallback_steps"] = int(model.fallback_steps)          # steps of this run re-done on the bf16x6 twin (range flag tripped)

@@ -234,33 +234,6 @@ __device__ __forceinline__ float group8_read(float v, int owner) {      // value
     }
 }
 
-// The same broadcast on the VALU: two DPP moves -- quad_perm spreads lane (owner & 3) of every quad, a row shift by 4 with a bank
-// mask then copies the owner's quad over the other quad of each group of eight.  ds_swizzle goes through the LDS pipe (~12 of its
-// cycles per wave-instruction, measured in the window kernel below, where 8 waves per CU issue 6 per corner-quartet); the VALU
-// has four pipes per CU and nothing else to do there.  Pure data movement: the same bits.
-template <int OWNER>
-__device__ __forceinline__ float group8_bcast(float v) {
-    constexpr int q = OWNER & 3;
-    constexpr int perm = q | (q << 2) | (q << 4) | (q << 6);
-    const int x = __builtin_bit_cast(int, v);
-    const int t = __builtin_amdgcn_update_dpp(x, x, perm, 0xF, 0xF, false);
-    // OWNER < 4: lanes 4..7 / 12..15 take lanes 0..3 / 8..11 (row_shr:4, banks 1 and 3); else the other way (row_shl:4, banks 0, 2)
-    const int r = OWNER < 4 ? __builtin_amdgcn_update_dpp(t, t, 0x114, 0xF, 0xA, false)
-                            : __builtin_amdgcn_update_dpp(t, t, 0x104, 0xF, 0x5, false);
-    return __builtin_bit_cast(float, r);
-}
-__device__ __forceinline__ float group8_bcast_rt(float v, int owner) {     // owner: a literal after unrolling
-    switch (owner) {
-        case 0: return group8_bcast<0>(v);
-        case 1: return group8_bcast<1>(v);
-        case 2: return group8_bcast<2>(v);
-        case 3: return group8_bcast<3>(v);
-        case 4: return group8_bcast<4>(v);
-        case 5: return group8_bcast<5>(v);
-        case 6: return group8_bcast<6>(v);
-        default: return group8_bcast<7>(v);
-    }
-}
 
 template <bool HAS_VR>
 __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __restrict__ value,
@@ -385,13 +358,14 @@ __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __re
 //   * workgroup id = tile * 8 + head: workgroups go round-robin to the 8 XCDs, so XCD m sees exactly head m's lines (1/8 of the
 //     value map per L2) and consecutive tiles, which share their halos, meet in the same L2.
 // Queries of the coarser levels (25 % of the tokens) keep the lane-distributed kernel (q_begin / q_count above).
-template <int TY, int TX, int R, int CAP, int CAPB, int NB, bool DPP = false, int ADDR = 0>
-__global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const float* __restrict__ value,
+template <int TY, int TX, int R, int CAP, int NB>
+__global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __restrict__ value,
                                                              const int64_t* __restrict__ shapes,
                                                              const int64_t* __restrict__ lsi,
                                                              const float* __restrict__ raw, int ld_raw,
                                                              const float* __restrict__ ref, float* __restrict__ out,
-                                                             int Lq, long v_bs, int v_rs, int tiles_y, int tiles_x) {
+                                                             int Lq, long v_bs, int v_rs, int tiles_y, int tiles_x, int ql,
+                                                             unsigned* __restrict__ slow_groups) {
     constexpr int POINTS = 4, LP = LEVELS * POINTS, ITERS = (TY * TX) / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char win[];          // CAP lines of 128 bytes
     const int tid = threadIdx.x, lane = tid & 63;
@@ -413,10 +387,15 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
         Ws[i] = (int)shapes[2 * i + 1];
         lv[i] = (unsigned)lsi[i];
     }
+    // the tile's queries are pixels of level `ql` (0: the finest map; 1: round 6, smaller tiles -- the same windows cover twice the
+    // pixels per query on the finer levels)
+    const int Hq = ql == 0 ? Hs[0] : ql == 1 ? Hs[1] : ql == 2 ? Hs[2] : Hs[3];
+    const int Wq = ql == 0 ? Ws[0] : ql == 1 ? Ws[1] : ql == 2 ? Ws[2] : Ws[3];
+    const long q0 = (long)b * Lq + (long)(ql == 0 ? lv[0] : ql == 1 ? lv[1] : ql == 2 ? lv[2] : lv[3]);
     const int y0t = ty * TY, x0t = tx * TX;
-    const int y1t = min(y0t + TY, Hs[0]) - 1, x1t = min(x0t + TX, Ws[0]) - 1;
+    const int y1t = min(y0t + TY, Hq) - 1, x1t = min(x0t + TX, Wq) - 1;
     // windows: the projection of the tile's first and last query on every level, R pixels of halo + the second bilinear corner
-    const long qa = (long)b * Lq + (long)y0t * Ws[0] + x0t, qz = (long)b * Lq + (long)y1t * Ws[0] + x1t;
+    const long qa = q0 + (long)y0t * Wq + x0t, qz = q0 + (long)y1t * Wq + x1t;
     const float rxa = ref[qa * 2], rya = ref[qa * 2 + 1], rxz = ref[qz * 2], ryz = ref[qz * 2 + 1];
     int wx0[LEVELS], wy0[LEVELS], wx1[LEVELS], wy1[LEVELS], wwd[LEVELS];
 #pragma unroll
@@ -427,9 +406,8 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
         if (zx < ax) zx = ax;
         if (zy < ay) zy = ay;
         int w_ = zx - ax + 1, h_ = zy - ay + 1;
-        const int cap = (CAPB && (i & 1)) ? CAPB : CAP;      // levels 1, 3 live in the second buffer when there is one
-        if (w_ > cap) { w_ = cap; zx = ax + w_ - 1; }
-        if (w_ * h_ > cap) { h_ = cap / w_; zy = ay + h_ - 1; }   // whatever does not fit is served by the global path
+        if (w_ > CAP) { w_ = CAP; zx = ax + w_ - 1; }
+        if (w_ * h_ > CAP) { h_ = CAP / w_; zy = ay + h_ - 1; }   // whatever does not fit is served by the global path
         wx0[i] = ax; wy0[i] = ay; wx1[i] = zx; wy1[i] = zy; wwd[i] = w_;
     }
     // this lane's level (runtime index l): select with compares, not an indexed array (registers)
@@ -449,28 +427,11 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
     const unsigned mine = (unsigned)k * 16u;                 // this lane's 4 channels inside a 128-byte line
     const unsigned head = (unsigned)(m * CH) * 4u;
 
-    // (the fill lambdas are defined below; level 0 of the double-buffered form is requested here, in front of the owner part)
-    if constexpr (CAPB != 0) {
-        const int ww_ = wwd[0], n_lines = ww_ * (wy1[0] - wy0[0] + 1);
-        const float inv_w = 1.f / (float)ww_;
-        for (int base = wave * 8; base < n_lines; base += 32) {
-            int line = base + g;
-            if (line > n_lines - 1) line = n_lines - 1;
-            int yy = (int)(((float)line + 0.5f) * inv_w);
-            int xx = line - yy * ww_;
-            if (xx < 0) { --yy; xx += ww_; }
-            if (xx >= ww_) { ++yy; xx -= ww_; }
-            const unsigned src = (lv[0] + (unsigned)((wy0[0] + yy) * Ws[0] + wx0[0] + xx)) * (unsigned)v_rs * 4u + head + mine;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(win + (size_t)base * 128), 16,
-                                                     (int)src, 0, 0, 0);
-        }
-    }
     // ---- owner part of every octet group: the lane-distributed kernel's, plus the window test and the LDS address ----
     // (straight-line code over the ITERS groups: no branch in here or in the level loops, so that the scheduler can overlap the
     // groups' loads, swizzles and LDS reads -- a wave has at most one partner on its SIMD to hide latency behind)
     float sw1[ITERS][2], sw2[ITERS][2], sw3[ITERS][2], sw4[ITERS][2], sww[ITERS][2];
     unsigned pk[ITERS][2];                                   // LDS byte address of corner (yc0, xc0) | dx << 20 | dy << 21
-    unsigned pk2[ITERS][2], pk3[ITERS][2], pk4[ITERS][2];    // ADDR4: the other three corners' addresses, computed at the owner
     f32x4 acc[ITERS];
     long qrow[ITERS];
     bool fast[ITERS], live[ITERS];
@@ -482,7 +443,7 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
         const int jy = j / TX, jx = j - jy * TX;
         const int qy = y0t + jy, qx = x0t + jx;
         live[it] = qy <= y1t && qx <= x1t;
-        const long q_global = (long)b * Lq + (long)(live[it] ? qy : y0t) * Ws[0] + (live[it] ? qx : x0t);
+        const long q_global = q0 + (long)(live[it] ? qy : y0t) * Wq + (live[it] ? qx : x0t);
         qrow[it] = q_global;
         const float* op = raw + (size_t)q_global * ld_raw + m * (LP * 2) + 4 * k;
         const float* lp = raw + (size_t)q_global * ld_raw + HEADS * LP * 2 + m * LP + 2 * k;
@@ -526,19 +487,7 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
         const bool use = inside && OK; /* (an address inside the buffer in every case) */                         \
         const int ly0 = use ? yc0 - my0 : 0, lx0 = use ? xc0 - mx0 : 0;                                           \
         const unsigned la_ = (unsigned)((ly0 * mww + lx0) * 128);                                                 \
-        if constexpr (ADDR == 4) {                                                                                \
-            const unsigned ldx_ = (use && xc1 != xc0) ? 128u : 0u, ldy_ = (use && yc1 != yc0) ? (unsigned)mww * 128u : 0u; \
-            pk[IT][T] = la_;                                                                                      \
-            pk2[IT][T] = la_ + ldx_;                                                                              \
-            pk3[IT][T] = la_ + ldy_;                                                                              \
-            pk4[IT][T] = la_ + ldy_ + ldx_;                                                                       \
-        } else if constexpr (ADDR == 2) {                                                                         \
-            /* two words: corner (yc0, xc0) with the x step in bit 27 (-> 128 after a shift by 20), and corner (yc1, xc0) */ \
-            pk[IT][T] = la_ | ((use && xc1 != xc0) ? (1u << 27) : 0u);                                            \
-            pk3[IT][T] = la_ + ((use && yc1 != yc0) ? (unsigned)mww * 128u : 0u);                                 \
-        } else {                                                                                                  \
-            pk[IT][T] = la_ | ((use && xc1 != xc0) ? (1u << 20) : 0u) | ((use && yc1 != yc0) ? (1u << 21) : 0u);  \
-        }                                                                                                         \
+        pk[IT][T] = la_ | ((use && xc1 != xc0) ? (1u << 20) : 0u) | ((use && yc1 != yc0) ? (1u << 21) : 0u);      \
     }
     unsigned any_slow = 0;
 #pragma unroll
@@ -568,8 +517,9 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
 
     // ---- level by level: fill the window, then the level's four samples of every octet group ----
     // Fill = LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction moves 8 lines (1 KB) into 8 consecutive window lines,
-    // every lane from its own source address; all requests of a level are in flight together.  CAPB > 0: two buffers (levels
-    // 0, 2 in the first, 1, 3 in the second), the next level's fill is requested before this level's samples are read.
+    // every lane from its own source address; all requests of a level are in flight together.  (Rounds 4-5 also carried a double-
+    // buffered form -- the next level's fill under this level's samples, one workgroup per CU -- and forms with two / four corner
+    // addresses computed at the owner, a DPP broadcast: none faster, tools/exp + docs/LAB_NOTES.md; removed in round 6.)
     // (the level is a compile-time constant of every call: as a run-time loop the compiler keeps `lev` in a register, indexes the
     // windows' arrays in scratch and turns every literal owner of a broadcast into an eight-way branch)
     auto fill = [&](auto LEVC, unsigned char* buf) {
@@ -588,7 +538,7 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
                                                      (int)src, 0, 0, 0);
         }
     };
-    auto bcast = [](float v, int owner) { return DPP ? group8_bcast_rt(v, owner) : group8_read(v, owner); };
+    auto bcast = [](float v, int owner) { return group8_read(v, owner); };
     auto level_samples = [&](auto LEVC, const unsigned char* buf) {
         constexpr int lev = decltype(LEVC)::value;
         const unsigned row_bytes = (unsigned)wwd[lev] * 128u;
@@ -603,7 +553,7 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
 #pragma unroll
                 for (int u = 0; u < NB; ++u) any_fast = any_fast || fast[half + u];
                 if (!any_fast) continue;
-                unsigned word[NB], wa2[NB], wa3[NB], wa4[NB];
+                unsigned word[NB];
                 float w1[NB], w2[NB], w3[NB], w4[NB], ww[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
@@ -611,15 +561,7 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
                     // (opaque: a ds_swizzle is not a memory operation, and without this the compiler computes the swizzles of ALL
                     // levels in front of the first barrier -- 1500 live values, 3.6 KB of scratch per lane)
                     asm volatile("" : "+v"(pk[it][t]), "+v"(sw1[it][t]), "+v"(sw2[it][t]), "+v"(sw3[it][t]), "+v"(sw4[it][t]), "+v"(sww[it][t]));
-                    if constexpr (ADDR == 4) asm volatile("" : "+v"(pk2[it][t]), "+v"(pk3[it][t]), "+v"(pk4[it][t]));
-                    if constexpr (ADDR == 2) asm volatile("" : "+v"(pk3[it][t]));
                     word[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk[it][t]), o));
-                    if constexpr (ADDR == 4) {
-                        wa2[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk2[it][t]), o));
-                        wa3[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk3[it][t]), o));
-                        wa4[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk4[it][t]), o));
-                    }
-                    if constexpr (ADDR == 2) wa3[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk3[it][t]), o));
                     w1[u] = bcast(sw1[it][t], o);
                     w2[u] = bcast(sw2[it][t], o);
                     w3[u] = bcast(sw3[it][t], o);
@@ -629,23 +571,9 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
                 f32x4 v1[NB], v2[NB], v3[NB], v4[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    unsigned a1, a2, a3, a4;
-                    if constexpr (ADDR == 4) {
-                        a1 = word[u] + mine; a2 = wa2[u] + mine; a3 = wa3[u] + mine; a4 = wa4[u] + mine;
-                    } else if constexpr (ADDR == 2) {
-                        // VALU and the LDS pipe are both near their limit in this phase (per (group, sample): 38 vector
-                        // instructions x 4 cycles x 2 waves per SIMD against 6 swizzles + 4 reads = 28 LDS cycles x 8 waves):
-                        // one more broadcast (the second row's corner) buys seven fewer address instructions
-                        const unsigned dxb = (word[u] >> 20) & 0x80u;
-                        a1 = (word[u] & 0xFFFFFu) + mine;
-                        a2 = a1 + dxb;
-                        a3 = wa3[u] + mine;
-                        a4 = a3 + dxb;
-                    } else {
-                        a1 = (word[u] & 0xFFFFFu) + mine;
-                        const unsigned dx = (word[u] >> 20) & 1u, dy = (word[u] >> 21) & 1u;
-                        a2 = a1 + dx * 128u; a3 = a1 + dy * row_bytes; a4 = a3 + dx * 128u;
-                    }
+                    const unsigned a1 = (word[u] & 0xFFFFFu) + mine;
+                    const unsigned dx = (word[u] >> 20) & 1u, dy = (word[u] >> 21) & 1u;
+                    unsigned a2 = a1 + dx * 128u, a3 = a1 + dy * row_bytes, a4 = a3 + dx * 128u;
                     // opaque: otherwise the compiler branches around the reads whose address may equal another one's (dx = 0 or
                     // dy = 0 at the map's edge) -- 600 branches in this kernel, exec-masked paths per lane group
                     asm volatile("" : "+v"(a2), "+v"(a3), "+v"(a4));
@@ -671,23 +599,15 @@ __global__ __launch_bounds__(256, CAPB ? 1 : 2) void msda_window_kernel(const fl
         __syncthreads();                                                                                          \
         level_samples(std::integral_constant<int, L>{}, win);                                                     \
     }
-#define MSDA_LEVEL_DOUBLE(L)                                                                                      \
-    {                                                                                                             \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
-        __syncthreads(); /* level L has landed for everybody; the other buffer is free */                         \
-        if constexpr (L + 1 < LEVELS) fill(std::integral_constant<int, (L + 1 < LEVELS ? L + 1 : L)>{}, ((L + 1) & 1) ? bufb : win); \
-        level_samples(std::integral_constant<int, L>{}, (L & 1) ? bufb : win);                                    \
-    }
-    if constexpr (CAPB == 0) {
-        MSDA_LEVEL_SINGLE(0) MSDA_LEVEL_SINGLE(1) MSDA_LEVEL_SINGLE(2) MSDA_LEVEL_SINGLE(3)
-    } else {
-        unsigned char* bufb = win + (size_t)CAP * 128;
-        // (level 0's fill was requested in front of the owner part: see there)
-        MSDA_LEVEL_DOUBLE(0) MSDA_LEVEL_DOUBLE(1) MSDA_LEVEL_DOUBLE(2) MSDA_LEVEL_DOUBLE(3)
-    }
+    MSDA_LEVEL_SINGLE(0) MSDA_LEVEL_SINGLE(1) MSDA_LEVEL_SINGLE(2) MSDA_LEVEL_SINGLE(3)
 #undef MSDA_LEVEL_SINGLE
-#undef MSDA_LEVEL_DOUBLE
     if (any_slow) {
+        if (slow_groups && lane == 0) {                       // diagnostic count (gom_msda_window_count_fallbacks): octet groups on the global path
+            unsigned n_slow = 0;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) n_slow += fast[it] ? 0u : 1u;
+            atomicAdd(slow_groups, n_slow);
+        }
         // octet groups with a sample outside its window: the lane-distributed kernel's gather from global memory (rare: never on
         // the bench workload); the window result of such a group is discarded
 #pragma unroll                                                // (static indices: a run-time `it` would put the arrays in scratch)
@@ -771,123 +691,66 @@ extern "C" int gom_msda_fused_forward(const float* raw, int ld_raw, const float*
     return gom_launch_status();
 }
 
-// Side lanes for the A/B switch below: one side stream + fork / join event pair PER CALLER STREAM (two streams entering the encoder
-// entry concurrently -- two detector lanes, or the tracker lane beside the detector -- must not re-record each other's events),
-// created on first use.  A lane is never created while its caller's stream is capturing (stream / event creation is not a
-// capturable operation): the call then runs its two kernels one after the other, as with the switch off.
-struct SideLane {
-    int dev = -1;
-    hipStream_t caller = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-static std::mutex g_side_mu;
-static std::vector<SideLane*> g_side;
-static int g_msda_overlap = 0;                           // measured in the step: the fork / join costs the hipGraph more than the overlap buys
-static SideLane* side_lane(hipStream_t caller) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(g_side_mu);
-    for (SideLane* sl : g_side)
-        if (sl->dev == dev && sl->caller == caller) return sl;
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(caller, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    SideLane* sl = new SideLane();
-    sl->dev = dev;
-    sl->caller = caller;
-    if (hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&sl->fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&sl->join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        delete sl;
-        return nullptr;
-    }
-    g_side.push_back(sl);
-    return sl;
-}
-/* [host] 1: the encoder entry runs its two kernels side by side (fork / join on a library-owned stream); 0 (default): one after
- * the other on the caller's stream.  Same bits.  Alone the call gains 3 % from the overlap (801 vs 812 us); inside the detector's
- * hipGraph the step LOST 2 % (263.1 vs 268.4 frames/s with the window kernel off, same box), without the fork it gains 1.9 %. */
-extern "C" int gom_msda_set_overlap(int on) {
-    g_msda_overlap = on ? 1 : 0;
+static int g_msda_window = 3;
+static unsigned* g_msda_slow = nullptr;
+/* [host] which encoder queries the entry below serves from LDS windows: bit 0 = the level-0 pixels (8 x 16 tiles, round 4), bit 1 =
+ * the level-1 pixels (4 x 8 tiles, round 6); default 3 = both, 0 = everything on the lane-distributed kernel (A/B runs, tests).
+ * Same bits either way. */
+extern "C" int gom_msda_set_window(int mask) {
+    g_msda_window = mask < 0 ? 0 : (mask & 3);
     return GOM_OK;
 }
-
-static int g_msda_window = 1;
-/* [host] 1 (default): the encoder entry below serves the level-0 queries from LDS windows; 0: everything on the lane-distributed
- * kernel (A/B runs, tests).  Same bits either way. */
-extern "C" int gom_msda_set_window(int on) {
-    g_msda_window = on < 0 ? 0 : on;                         // 2: the double-buffered form (experiments)
+/* [host] diagnostic: a device word that every window workgroup adds its FALLBACK octet groups to (groups of 8 (query, head) pairs
+ * with a sample outside its window: they take the gather path); NULL (default) = no counting.  tools/msda_offset_scale.py. */
+extern "C" int gom_msda_window_count_fallbacks(unsigned int* device_counter) {
+    g_msda_slow = device_counter;
     return GOM_OK;
 }
 
 /* The fused op for an ENCODER call: num_query = the tokens of the pyramid (query q of a frame IS token q: level-0 pixels first,
- * `h0` x `w0` of them in raster order), reference points = the pixels' own positions.  Level-0 queries run on the LDS-window
- * kernel, the coarser levels' on the lane-distributed one; results are bit-identical to gom_msda_fused_forward. */
+ * `h0` x `w0` of them in raster order, then the coarser levels'), reference points = the pixels' own positions.  Level-0 and
+ * level-1 queries run on the LDS-window kernel, the coarser levels' on the lane-distributed one; results are bit-identical to
+ * gom_msda_fused_forward. */
 extern "C" int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, const float* ref, const float* value,
                                               long value_batch_stride, int value_row_stride, const int64_t* spatial_shapes,
                                               const int64_t* level_start_index, float* output, int batch, int num_query,
-                                              int h0, int w0, void* stream) {
+                                              int h0, int w0, int h1, int w1, void* stream) {
     GOM_CHECK_ARG(raw && ref && value && spatial_shapes && level_start_index && output);
     GOM_CHECK_ARG(batch > 0 && num_query > 0 && ld_raw >= HEADS * LEVELS * 4 * 3 && (ld_raw % 4) == 0);
     GOM_CHECK_ARG(value_row_stride >= HEADS * CH && (value_row_stride % 4) == 0 && (value_batch_stride % 4) == 0);
     GOM_CHECK_ARG(((uintptr_t)raw % 16) == 0 && ((uintptr_t)value % 16) == 0);
-    GOM_CHECK_ARG(h0 > 0 && w0 > 0 && (long)h0 * w0 <= num_query);
-    constexpr int TY = 8, TX = 16, R = 5, CAP = 576, CAPB = 384;   // 72 KB: two workgroups per CU; + 48 KB second buffer: one
-    const long n0 = (long)h0 * w0;
-    const int tiles_y = cdiv(h0, TY), tiles_x = cdiv(w0, TX);
-    const long wgs = (long)batch * tiles_y * tiles_x * 8;
-    if (!(g_msda_window && g_msda_lanes && value_batch_stride > 0 && value_batch_stride < (1L << 29) && wgs < (1L << 31)))
+    GOM_CHECK_ARG(h0 > 0 && w0 > 0 && h1 >= 0 && w1 >= 0 && (long)h0 * w0 + (long)h1 * w1 <= num_query);
+    constexpr int R = 5, CAP = 576;                          // 72 KB of window lines: two workgroups per CU
+    constexpr int TY0 = 8, TX0 = 16, TY1 = 4, TX1 = 8;
+    const long n0 = (long)h0 * w0, n1 = (long)h1 * w1;       // (host copies of spatial_shapes[0], [1]: the tile grids)
+    const long wgs0 = (long)batch * cdiv(h0, TY0) * cdiv(w0, TX0) * 8;
+    const long wgs1 = (long)batch * cdiv(h1, TY1) * cdiv(w1, TX1) * 8;
+    if (!((g_msda_window & 1) && g_msda_lanes && value_batch_stride > 0 && value_batch_stride < (1L << 29) && wgs0 < (1L << 31) &&
+          wgs1 < (1L << 31)))
         return gom_msda_fused_forward(raw, ld_raw, ref, value, value_batch_stride, value_row_stride, spatial_shapes,
                                       level_start_index, output, batch, num_query, stream);
-    // fork BEFORE the window kernel is queued: the side stream then depends on what precedes this call only (see below)
-    const long rest = num_query - n0;
-    hipStream_t s = (hipStream_t)stream, lane_stream = s;
-    SideLane* sl = (rest > 0 && g_msda_overlap) ? side_lane(s) : nullptr;
-    if (sl) {
-        if (hipEventRecord(sl->fork, s) == hipSuccess && hipStreamWaitEvent(sl->stream, sl->fork, 0) == hipSuccess) lane_stream = sl->stream;
-        else sl = nullptr;
-    }
-    if (g_msda_window == 2) {                                // double-buffered windows, one workgroup per CU
-        auto kern = msda_window_kernel<TY, TX, R, CAP, CAPB, 4>;
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (CAP + CAPB) * 128);
-        if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), (CAP + CAPB) * 128, (hipStream_t)stream, value, spatial_shapes,
-                           level_start_index, raw, ld_raw, ref, output, num_query, value_batch_stride, value_row_stride, tiles_y,
-                           tiles_x);
-    } else if (g_msda_window == 3) {                         // experiments: two corner addresses computed at the owner
-        auto kern = msda_window_kernel<TY, TX, R, CAP, 0, 4, false, 2>;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        auto kern = msda_window_kernel<TY0, TX0, R, CAP, 4>;
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CAP * 128);
         if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), CAP * 128, (hipStream_t)stream, value, spatial_shapes,
-                           level_start_index, raw, ld_raw, ref, output, num_query, value_batch_stride, value_row_stride, tiles_y,
-                           tiles_x);
-    } else {
-        auto kern = msda_window_kernel<TY, TX, R, CAP, 0, 4>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)wgs0), dim3(256), CAP * 128, s, value, spatial_shapes, level_start_index, raw, ld_raw,
+                           ref, output, num_query, value_batch_stride, value_row_stride, cdiv(h0, TY0), cdiv(w0, TX0), 0, g_msda_slow);
+    }
+    long done = n0;
+    if ((g_msda_window & 2) && n1 > 0) {
+        auto kern = msda_window_kernel<TY1, TX1, R, CAP, 1>;
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CAP * 128);
         if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), CAP * 128, (hipStream_t)stream, value, spatial_shapes,
-                           level_start_index, raw, ld_raw, ref, output, num_query, value_batch_stride, value_row_stride, tiles_y,
-                           tiles_x);
+        hipLaunchKernelGGL(kern, dim3((unsigned)wgs1), dim3(256), CAP * 128, s, value, spatial_shapes, level_start_index, raw, ld_raw,
+                           ref, output, num_query, value_batch_stride, value_row_stride, cdiv(h1, TY1), cdiv(w1, TX1), 1, g_msda_slow);
+        done += n1;
     }
-    if (rest > 0) {
-        // The coarser levels' queries run on the lane-distributed kernel -- on a SIDE stream, beside the window kernel: that one
-        // is bound by the vector ALU (2 waves per SIMD, 4 cycles per instruction) and leaves the texture-address path idle, this
-        // one is bound by the texture-address path and needs few registers and no LDS, so its waves fit beside the window
-        // kernel's two workgroups per CU.  The two kernels write disjoint rows.  Fork / join by events (legal under stream
-        // capture: the detector's hipGraph records both branches).
-        hipLaunchKernelGGL((msda_fused_lanes_kernel<false>), dim3((unsigned)cdiv((long)batch * rest, 4)), dim3(256), 0, lane_stream,
-                           value, spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query,
-                           value_batch_stride, value_row_stride, (const float*)nullptr, (int)n0, (int)rest);
-        if (sl) {
-            hipError_t e2 = hipEventRecord(sl->join, sl->stream);
-            if (e2 == hipSuccess) e2 = hipStreamWaitEvent(s, sl->join, 0);
-            if (e2 != hipSuccess) return GOM_ERR_HIP_BASE + (int)e2;
-        }
-    }
+    const long rest = num_query - done;
+    if (rest > 0)                                            // the coarser levels' queries: the lane-distributed kernel (disjoint rows)
+        hipLaunchKernelGGL((msda_fused_lanes_kernel<false>), dim3((unsigned)cdiv((long)batch * rest, 4)), dim3(256), 0, s, value,
+                           spatial_shapes, level_start_index, raw, ld_raw, ref, output, batch, num_query, value_batch_stride,
+                           value_row_stride, (const float*)nullptr, (int)done, (int)rest);
     return gom_launch_status();
 }
 

@@ -28,9 +28,9 @@ SIGNATURES = {
     "gom_ms_deform_attn_forward_strided": (I, [P, L, I, P, P, P, P, P, I, I, P]),
     "gom_msda_set_lane_distributed": (I, [I]),
     "gom_msda_fused_forward": (I, [P, I, P, P, L, I, P, P, P, I, I, P]),
-    "gom_msda_fused_forward_encoder": (I, [P, I, P, P, L, I, P, P, P, I, I, I, I, P]),
+    "gom_msda_fused_forward_encoder": (I, [P, I, P, P, L, I, P, P, P, I, I, I, I, I, I, P]),
     "gom_msda_set_window": (I, [I]),
-    "gom_msda_set_overlap": (I, [I]),
+    "gom_msda_window_count_fallbacks": (I, [P]),
     "gom_msda_prepare": (I, [P, I, P, I, P, P, P, L, P]),
     "gom_gemm_f32": (I, [P, P, P, I, P, I, P, P, P, I, I, P, I, I, I, I, P]),
     "gom_gemm_splitk_workspace_bytes": (L, [I, I, I]),

@@ -90,6 +90,8 @@ class DeepSolo:
                                   _dev(torch.cat([b, bv], 0), device))}
 
         self.enc = []
+        self._msda_counter = None                                # one int32 device word: fallback octet groups of a window launch
+        self.msda_window_fallback = {}                           # encoder layer -> measured share (ops.MSDA_WINDOW_POLICY)
         for i in range(self.n_enc):
             p = t + "encoder.layers.%d." % i
             attn, n1 = msda(p + "self_attn"), norm(p + "norm1")
@@ -246,7 +248,7 @@ class DeepSolo:
             pos_w = [ops.broadcast_rows(t_, B).view(B * S, 384) for t_ in pos_w]
         geo = {
             "S": S, "shapes": ss_d, "lsi": lsi_d, "lsi_host": [int(v) for v in lsi], "pos_w": pos_w,
-            "hw0": (int(shapes[0][0]), int(shapes[0][1])),
+            "hw0": tuple(int(v) for hw in shapes[:2] for v in hw),     # (H0, W0[, H1, W1]): the window kernels' tile grids
             "pos_periodic": self._pos_periodic,
             "lvl_pos": ops.broadcast_rows(lvl_pos, B).view(B * S, 256),
             "enc_ref": ops.broadcast_rows(ops.encoder_reference_points(ss_d, lsi_d, S, vs_d), B).view(B * S, 1, 2),
@@ -297,8 +299,19 @@ class DeepSolo:
                             r_period=S if geo["pos_periodic"] else 0)   # [B*S, 384 | 256]
             if geo["vr"] is not None:                      # padded batch: value.masked_fill(padding_mask, 0)
                 ops.zero_padded_tokens_(rv, 384, 256, geo["shapes"], geo["lsi"], geo["vshapes"], B, S)
+            # LDS windows for this layer's queries?  Decided once per layer, on its first eager call, from the measured share of octet
+            # groups whose samples leave the windows (ops.MSDA_WINDOW_POLICY); undecided calls (a capture in progress) use the windows
+            use_win = geo["vr"] is None and L.get("msda_window", True)
+            decide = use_win and "msda_window" not in L and ops.MSDA_WINDOW and ops.MSDA_LANES and ops.MSDA_WINDOW_POLICY and \
+                not torch.cuda.is_current_stream_capturing()
+            if decide and self._msda_counter is None:
+                self._msda_counter = torch.zeros((1,), dtype=torch.int32, device=src.device)
             samp = ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, geo["vr"],
-                                  encoder_hw0=geo["hw0"] if geo["vr"] is None else None)
+                                  encoder_hw0=geo["hw0"] if use_win else None, fallback_counter=self._msda_counter if decide else None)
+            if decide:
+                frac = float(self._msda_counter.item()) / max(1, ops.msda_window_groups(geo["hw0"], B))
+                L["msda_window"] = frac <= ops.MSDA_WINDOW_MAX_FALLBACK
+                self.msda_window_fallback[li] = frac
             if L["out_ln"] is not None:
                 src = ops.proj_ln(samp, L["out_ln"], src)
             else:

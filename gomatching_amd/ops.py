@@ -1164,14 +1164,38 @@ _msda_lanes_set = [None]
 
 
 MSDA_WINDOW = _switch("MSDA_WINDOW")   # encoder calls: level-0 queries served from LDS windows of the value map (same bits)
-MSDA_OVERLAP = _switch("MSDA_OVERLAP", default=False)   # ... and the coarser levels' launch on a forked side stream (A/B only)
-_msda_overlap_set = [None]
+# ... and the level-1 queries (4 x 8 tiles, round 6): bit-identical, SLOWER at the bench shape (958 vs 865 us per encoder call: a 4 x 8
+# tile's windows are 36 lines per (query, head) against 9 for an 8 x 16 level-0 tile, and an 8 x 16 level-1 tile's level-0 window is
+# 1 161 lines = 145 KB); off by default, kept for A/B runs and its parity test
+MSDA_WINDOW_L1 = _switch("MSDA_WINDOW_L1", False)
+_msda_window_set = [None]
 
 
-def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq, valid_ratios=None, encoder_hw0=None):
+# Encoder layers decide ONCE, on their first eager call, whether their level-0 queries are worth the LDS windows: the window kernel
+# assumes sampling offsets within its 5-pixel halo; an octet group (8 (query, head) pairs) with one sample outside takes the gather
+# path after paying for the windows.  Measured at the bench shape (profiles/r06_msda_level1_windows_and_offset_scale.log): 872 us per
+# call with no group falling back against 973 us for the gather kernel alone, 1131 us with 87 % falling back (the synthetic weights'
+# offsets x 2) -- break-even near 34 %.  A trained checkpoint's offsets are not known here (none ships); the policy makes the
+# choice a measurement instead of an assumption.  GOM_MSDA_WINDOW_POLICY=0: always the windows (round 4-5 behaviour).
+MSDA_WINDOW_POLICY = _switch("MSDA_WINDOW_POLICY")
+MSDA_WINDOW_MAX_FALLBACK = 0.30
+
+
+def msda_window_groups(encoder_hw0, B):
+    """Octet groups of one encoder call's window launches (8 heads x 8-query groups of every tile, padded tiles included)."""
+    h0, w0 = int(encoder_hw0[0]), int(encoder_hw0[1])
+    n = -(-h0 // 8) * -(-w0 // 16) * 16
+    if MSDA_WINDOW_L1 and len(encoder_hw0) >= 4:
+        n += -(-int(encoder_hw0[2]) // 4) * -(-int(encoder_hw0[3]) // 8) * 4
+    return B * 8 * n
+
+
+def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq, valid_ratios=None, encoder_hw0=None, fallback_counter=None):
     """raw [B*Lq, >=384] (offsets | logits, stride(1)==1), ref [B*Lq, 2], value2d [B*S, 256] column slice;
-    valid_ratios [4,2] fp32 (Wv/W, Hv/H) for padded batches.  encoder_hw0 = (H0, W0): an ENCODER call (query q = token q,
-    reference points = the tokens' own positions) -- the level-0 queries then run on the LDS-window kernel (csrc/msda.hip)."""
+    valid_ratios [4,2] fp32 (Wv/W, Hv/H) for padded batches.  encoder_hw0 = (H0, W0[, H1, W1]): an ENCODER call (query q = token
+    q, reference points = the tokens' own positions) -- the level-0 (and level-1) queries then run on the LDS-window kernel
+    (csrc/msda.hip).  fallback_counter: a one-word int32 device tensor the window launches of THIS call add their fallback octet
+    groups to (zeroed here)."""
     assert raw.stride(1) == 1 and value2d.stride(1) == 1
     _chk_f32(ref, valid_ratios)
     if _msda_lanes_set[0] != MSDA_LANES:                     # library-side switch follows ops.MSDA_LANES
@@ -1196,12 +1220,21 @@ def msda_fused(raw, ref, value2d, batch_stride, shapes, lsi, B, Lq, valid_ratios
         _after()
         return out
     if encoder_hw0 is not None and MSDA_WINDOW and MSDA_LANES:
-        if _msda_overlap_set[0] != MSDA_OVERLAP:
-            _L().gom_msda_set_overlap(1 if MSDA_OVERLAP else 0)
-            _msda_overlap_set[0] = MSDA_OVERLAP
-        check(_L().gom_msda_fused_forward_encoder(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride, value2d.stride(0),
-                                                  _p(shapes), _p(lsi), _p(out), B, Lq, int(encoder_hw0[0]), int(encoder_hw0[1]),
-                                                  _stream()), "gom_msda_fused_forward_encoder")
+        mask = 3 if MSDA_WINDOW_L1 else 1
+        if _msda_window_set[0] != mask:
+            _L().gom_msda_set_window(mask)
+            _msda_window_set[0] = mask
+        h1, w1 = (int(encoder_hw0[2]), int(encoder_hw0[3])) if len(encoder_hw0) >= 4 else (0, 0)
+        if fallback_counter is not None:
+            fallback_counter.zero_()
+            _L().gom_msda_window_count_fallbacks(_p(fallback_counter))
+        try:
+            check(_L().gom_msda_fused_forward_encoder(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride, value2d.stride(0),
+                                                      _p(shapes), _p(lsi), _p(out), B, Lq, int(encoder_hw0[0]), int(encoder_hw0[1]),
+                                                      h1, w1, _stream()), "gom_msda_fused_forward_encoder")
+        finally:
+            if fallback_counter is not None:
+                _L().gom_msda_window_count_fallbacks(None)
     else:
         check(_L().gom_msda_fused_forward(_p(raw), raw.stride(0), _p(ref), _p(value2d), batch_stride, value2d.stride(0),
                                           _p(shapes), _p(lsi), _p(out), B, Lq, _stream()), "gom_msda_fused_forward")

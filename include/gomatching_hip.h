@@ -86,17 +86,19 @@ int gom_msda_set_lane_distributed(int on);   /* [host] fused MSDA: 1 = per-sampl
 int gom_msda_fused_forward(const float* raw, int ld_raw, const float* ref, const float* value, long value_batch_stride,
                            int value_row_stride, const int64_t* spatial_shapes, const int64_t* level_start_index,
                            float* output, int batch, int num_query, void* stream);
-/* The same op for an ENCODER call (num_query = the pyramid's tokens, query q of a frame IS token q; the first h0 x w0 queries are
- * the level-0 pixels in raster order, reference points = the tokens' own positions: deformable_transformer.py:288-300).  The
- * level-0 queries are served from per-workgroup LDS windows of the value map (tile of 8 x 16 queries + 5 pixels of halo per
- * level, one head per workgroup; samples that leave the window fall back to global memory), the coarser levels' by the kernel
- * of gom_msda_fused_forward.  Bit-identical to gom_msda_fused_forward.  gom_msda_set_window(0) = always the latter (A/B, tests). */
-int gom_msda_set_window(int on);
-int gom_msda_set_overlap(int on);   /* [host] 1 = the two kernels of the encoder entry side by side on a forked stream (default 0:
-                                     * inside the detector's hipGraph the fork / join cost more than the overlap bought) */
+/* The same op for an ENCODER call (num_query = the pyramid's tokens, query q of a frame IS token q: the level-0 pixels in raster
+ * order, then the coarser levels'; reference points = the tokens' own positions: deformable_transformer.py:288-300).  h0 x w0 and
+ * h1 x w1 = host copies of spatial_shapes[0] and [1] (h1 = w1 = 0: no level-1 windows).  Level-0 queries (tiles of 8 x 16) and
+ * level-1 queries (tiles of 4 x 8, round 6) are served from per-workgroup LDS windows of the value map -- the tile's projection on
+ * every level + 5 pixels of halo, one head per workgroup; an octet group with a sample outside its window falls back to global
+ * memory -- the coarser levels' by the kernel of gom_msda_fused_forward.  Bit-identical to gom_msda_fused_forward.
+ * [host] gom_msda_set_window(mask): bit 0 = level-0 windows, bit 1 = level-1 windows (default 3), 0 = always the gather kernel.
+ * [host] gom_msda_window_count_fallbacks(ptr): diagnostic device word the window launches add their fallback octet groups to. */
+int gom_msda_set_window(int mask);
+int gom_msda_window_count_fallbacks(unsigned int* device_counter);
 int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, const float* ref, const float* value, long value_batch_stride,
                                    int value_row_stride, const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                   float* output, int batch, int num_query, int h0, int w0, void* stream);
+                                   float* output, int batch, int num_query, int h0, int w0, int h1, int w1, void* stream);
 
 /* Sampling-location + softmax arithmetic of MSDeformAttn.forward (ms_deform_attn.py:136-145).
  * raw [Q, ld_raw]: columns [0,256) = sampling_offsets output, [256,384) = attention_weights logits;

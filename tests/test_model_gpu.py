@@ -53,6 +53,45 @@ def test_backbone_vs_oracle(gemm_mode):
         _close(out[k].permute(0, 3, 1, 2), ref[k], 2e-5 * max(scale, 1.0), k)
 
 
+def test_msda_window_policy_follows_the_measured_offsets():
+    """ops.MSDA_WINDOW_POLICY: every encoder layer decides on its first eager call, from the counted share of octet groups whose
+    samples leave the 5-pixel windows, whether its level-0 queries run on the LDS-window kernel.  With the synthetic weights' offsets
+    nothing falls back and the windows stay; with the sampling offsets scaled x 8 (a stand-in for a trained checkpoint's larger
+    offsets) the layers switch to the gather kernel.  The two kernels are bit-identical, so the outputs do not depend on the
+    choice: checked against a run with the policy off."""
+    from gomatching_amd import ops
+    from gomatching_amd.weights import synth_state_dict
+    from gomatching_amd.modeling import DeepSolo
+    g = golden("deepsolo_ic15.npz")
+    cfg = mini_cfg("icdar15")
+    feats = [t(g["feat%d" % i]).permute(0, 2, 3, 1).contiguous().to(DEV) for i in range(3)]
+    old = ops.MSDA_WINDOW_POLICY
+    try:
+        with ops.gemm_mode("f16x3"):
+            for scale, want in ((1.0, True), (8.0, False)):
+                sd = dict(synth_state_dict(cfg, seed=7))
+                for k in list(sd):
+                    if ".encoder.layers." in k and "sampling_offsets" in k:
+                        sd[k] = sd[k] * scale
+                ops.MSDA_WINDOW_POLICY = True
+                net = DeepSolo(cfg, sd, DEV)
+                out = net.forward(feats)
+                assert sorted(net.msda_window_fallback) == list(range(net.n_enc))
+                assert all(L["msda_window"] is want for L in net.enc), (scale, net.msda_window_fallback)
+                if want:
+                    assert max(net.msda_window_fallback.values()) == 0.0
+                else:
+                    assert min(net.msda_window_fallback.values()) > ops.MSDA_WINDOW_MAX_FALLBACK
+                ops.MSDA_WINDOW_POLICY = False
+                net2 = DeepSolo(cfg, sd, DEV)
+                out2 = net2.forward(feats)
+                assert net2.msda_window_fallback == {}
+                for k in ("pred_logits", "pred_ctrl_points", "query_features"):
+                    assert torch.equal(out[k], out2[k]), (scale, k)
+    finally:
+        ops.MSDA_WINDOW_POLICY = old
+
+
 @pytest.mark.parametrize("builtin,tag,voc", [("icdar15", "ic15", None), ("bovtext", "voc96", 96)])
 def test_deepsolo_mini_golden(builtin, tag, voc, gemm_mode):
     """DeepSolo-without-backbone against the reference's own outputs (mini geometry, B=2)."""

@@ -3,6 +3,8 @@ statement of the same op, on seeded inputs.  Tolerances are fp32-accumulation-or
 import math
 
 import numpy as np
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -383,10 +385,10 @@ def test_msda_larger_vs_oracle_and_prepare():
                                             ([(17, 50), (9, 25), (5, 13), (3, 7)], 1, 9.0), ([(8, 16), (4, 8), (2, 4), (1, 2)], 2, 1.0),
                                             ([(125, 223), (63, 112), (32, 56), (16, 28)], 1, 2.5)])
 def test_msda_encoder_window_kernel_is_bit_identical(shapes, B, scale):
-    """The encoder form of the fused op (level-0 queries served from LDS windows of the value map, csrc/msda.hip) against the
-    lane-distributed kernel on the same inputs: the SAME BITS -- with offsets of a few pixels (everything inside the windows),
-    with offsets far beyond the halo (the octet groups' global-memory path), on maps that are not multiples of the 8 x 16 tile
-    and on the bench's pyramid."""
+    """The encoder form of the fused op (level-0 and level-1 queries served from LDS windows of the value map, csrc/msda.hip)
+    against the lane-distributed kernel on the same inputs: the SAME BITS -- with offsets of a few pixels (everything inside the
+    windows), with offsets far beyond the halo (the octet groups' global-memory path, counted), on maps that are not multiples of
+    the 8 x 16 / 4 x 8 tiles and on the bench's pyramid."""
     ops = _ops()
     from gomatching_amd import lib
     g = torch.Generator().manual_seed(int(scale * 10) + B)
@@ -399,16 +401,27 @@ def test_msda_encoder_window_kernel_is_bit_identical(shapes, B, scale):
     raw = raw.to(DEV)
     ref = ops.encoder_reference_points(ss.to(DEV), lsi.to(DEV), S).repeat(B, 1).contiguous()
     L = lib.load()
+    hw01 = tuple(shapes[0]) + tuple(shapes[1])
+    plain = ops.msda_fused(raw, ref, wide[:, 384:], S * 640, ss.to(DEV), lsi.to(DEV), B, S)      # everything on the gather kernel
+    counter = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    old = ops.MSDA_WINDOW_L1
     try:
-        L.gom_msda_set_window(0)
-        plain = ops.msda_fused(raw, ref, wide[:, 384:], S * 640, ss.to(DEV), lsi.to(DEV), B, S, encoder_hw0=shapes[0])
-        for mode in (1, 2, 3):                                        # single window buffer | double-buffered | owner-computed corner addresses
-            L.gom_msda_set_window(mode)
-            win = ops.msda_fused(raw, ref, wide[:, 384:], S * 640, ss.to(DEV), lsi.to(DEV), B, S, encoder_hw0=shapes[0])
-            assert torch.equal(win, plain), (mode, float((win - plain).abs().max()))
+        L.gom_msda_window_count_fallbacks(ctypes.c_void_p(counter.data_ptr()))
+        for l1, hw in ((False, shapes[0]), (True, hw01)):             # level-0 windows alone | level-0 and level-1 windows
+            ops.MSDA_WINDOW_L1 = l1
+            counter.zero_()
+            win = ops.msda_fused(raw, ref, wide[:, 384:], S * 640, ss.to(DEV), lsi.to(DEV), B, S, encoder_hw0=hw)
+            assert torch.equal(win, plain), (l1, float((win - plain).abs().max()))
+            groups = B * 8 * sum(-(-h // ty) * -(-w // tx) * (ty * tx // 8) for (h, w), (ty, tx) in zip(shapes[:2 if l1 else 1], ((8, 16), (4, 8))))
+            slow = int(counter.item())
+            assert 0 <= slow <= groups
+            if scale <= 1.0:
+                assert slow == 0, "offsets of ~1 pixel must stay inside the 5-pixel halo"
+            if scale >= 9.0:
+                assert slow > groups // 2, "offsets of ~9 pixels must leave the windows"
     finally:
-        L.gom_msda_set_window(1)
-    assert torch.equal(win, ops.msda_fused(raw, ref, wide[:, 384:], S * 640, ss.to(DEV), lsi.to(DEV), B, S))
+        ops.MSDA_WINDOW_L1 = old
+        L.gom_msda_window_count_fallbacks(None)
 
 
 # ------------------------------------------------------------------------------------------ attention

@@ -28,31 +28,54 @@ S = geo["S"]
 L0 = det.enc[0]
 rv = ops.linear(src, L0["attn"]["raw_value"], R=geo["pos_w"][0], r_cols=384, r_period=S if geo["pos_periodic"] else 0)
 Lh = lib.load()
+import ctypes                                                     # noqa: E402
+import hashlib                                                    # noqa: E402
 
 
-def run(window, overlap=1):
-    Lh.gom_msda_set_overlap(overlap)
-    Lh.gom_msda_set_window(int(window))
-    return ops.msda_fused(rv, geo["enc_ref"], rv[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, None, encoder_hw0=geo["hw0"])
+def run(mask, rv_=None):
+    """mask 0: everything on the lane-distributed (gather) kernel; 1: level-0 queries from LDS windows; 3: level-0 and level-1."""
+    ops.MSDA_WINDOW = mask != 0
+    ops.MSDA_WINDOW_L1 = mask == 3
+    r = rv if rv_ is None else rv_
+    return ops.msda_fused(r, geo["enc_ref"], r[:, 384:], S * 640, geo["shapes"], geo["lsi"], B, S, None, encoder_hw0=geo["hw0"])
 
 
-a, b, c, d = run(0), run(1), run(2), run(3)
-import hashlib
-print("sha1 lane %s window %s" % (hashlib.sha1(a.cpu().numpy().tobytes()).hexdigest()[:16], hashlib.sha1(b.cpu().numpy().tobytes()).hexdigest()[:16]))
-print("bit-identical:", bool(torch.equal(a, b)), bool(torch.equal(a, c)), bool(torch.equal(a, d)), "max |d| %.3e" % float((a - b).abs().max()))
-
-
-def burst(window, n=10, overlap=1):
+def burst(mask, n=10, rv_=None):
+    run(mask, rv_)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
-        run(window, overlap)
+        run(mask, rv_)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+a, b, c = run(0), run(1), run(3)
+print("sha1 gather %s windows %s" % (hashlib.sha1(a.cpu().numpy().tobytes()).hexdigest()[:16], hashlib.sha1(c.cpu().numpy().tobytes()).hexdigest()[:16]))
+print("bit-identical:", bool(torch.equal(a, b)), bool(torch.equal(a, c)), "max |d| %.3e" % float((a - c).abs().max()))
 for rnd in range(4):
-    print("round %d: lane-distributed kernel %.1f us | level-0 from LDS windows + coarser levels on the lane kernel: single buffer %.1f us, "
-          "double-buffered %.1f us, single buffer, TWO corner addresses computed at the owner %.1f us" % (rnd, burst(0), burst(1), burst(2), burst(3)), flush=True)
-Lh.gom_msda_set_window(1)
+    print("round %d: gather kernel %.1f us | level-0 windows + gather for the rest %.1f us | level-0 + level-1 windows + gather for levels 2-3 %.1f us"
+          % (rnd, burst(0), burst(1), burst(3)), flush=True)
+
+# ---- what the window assumption is worth when the offsets are larger than the synthetic weights make them (VERDICT r5 3b): the
+#      sampling offsets (raw columns [0, 256), in pixels of the sampled level) scaled x1 / x2 / x4; halo R = 5 pixels ----
+counter = torch.zeros((1,), dtype=torch.int32, device="cuda")
+Lh.gom_msda_window_count_fallbacks(ctypes.c_void_p(counter.data_ptr()))
+h0, w0, h1, w1 = geo["hw0"]
+groups = B * 8 * (-(-h0 // 8) * -(-w0 // 16) * 16 + -(-h1 // 4) * -(-w1 // 8) * 4)
+off = rv[:, :256].float()
+print("offsets of the bench model's first encoder layer: |off| mean %.2f, p99 %.2f, max %.2f pixels"
+      % (float(off.abs().mean()), float(off.abs().flatten()[::97].quantile(0.99)), float(off.abs().max())))
+for scale in (1.0, 2.0, 4.0):
+    r2 = rv.clone()
+    r2[:, :256] *= scale
+    counter.zero_()
+    ref_out = run(0, r2)
+    got = run(3, r2)
+    torch.cuda.synchronize()
+    slow = int(counter.item())
+    print("offsets x %.0f: %6.2f %% of the octet groups fall back to the gather path (%d of %d), bit-identical %s | gather %.1f us, "
+          "level-0 windows %.1f us, level-0 + level-1 windows %.1f us"
+          % (scale, 100.0 * slow / groups, slow, groups, bool(torch.equal(ref_out, got)), burst(0, 10, r2), burst(1, 10, r2), burst(3, 10, r2)), flush=True)
+Lh.gom_msda_window_count_fallbacks(None)
