@@ -311,9 +311,6 @@ def main():
                          "secondary leg of configs[3] (GoMatching_PP_DSText: 1920x1080 -> 1280x2276, 300 queries) / configs[4] "
                          "(GoMatching_BOVText: voc 5462, mixed-resolution clip) as `value_dstext` / `value_bovtext`; all (default) = both")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the secondary configs[3] / configs[4] legs of the default run")
-    ap.add_argument("--detector-lanes", type=int, default=1, choices=[1, 2],
-                    help="2: consecutive steps' detector passes alternate between two streams (GoMatching.detector_lanes), so that a "
-                         "pass starts while the previous one still runs")
     ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU,
                     help="diagnostic: frames of the clip each rank owns per step (BASELINE.json: 8; the self-launch test compares "
                          "N=2 x 8 with N=1 x 16, the same 16-frame clip)")
@@ -377,7 +374,6 @@ def main():
         model, sd = build_model(cfg, device)
         if args.h2d:
             model.h2d_mode = args.h2d
-        model.detector_lanes = args.detector_lanes
         cus = args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world >= 8 else 0)
         if cus > 0 and device.type == "cuda":
             try:
@@ -610,7 +606,7 @@ def main():
                    "long_term_match": "chain of 13 launches",
                    "tracker_cus": args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world >= 8 else 0),
                    "pipelining": "upload(step i+1) and detector(step i+1) overlap tracker(step i)",
-                   "detector_hipgraph": graphed, "detector_lanes": args.detector_lanes,
+                   "detector_hipgraph": graphed,
                    "parallelism": "frame-sharded dp%d + 1 all-gather/step"
                    % world if world > 1 else "single GPU",
                    "detect_frac": args.detect_frac,
@@ -712,7 +708,7 @@ def main():
             pd = sum(p_[0].elapsed_time(p_[1]) for p_ in pl_prof)
             pb = sum(p_[3] for p_ in pl_prof)
             line["roofline_proj_ln"] = {
-                "bound": "hbm", "kernel": "proj_ln2_kernel<FORM, 4> (64-row tiles, two workgroups per CU)" if getattr(ops, "PROJ_LN_V2", False) else "proj_ln_kernel<FORM>", "achieved": pb / (pd * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
+                "bound": "hbm", "kernel": "proj_ln2_kernel<FORM> (64-row tiles, two workgroups per CU)", "achieved": pb / (pd * 1e-3) / 1e12, "peak": 8.0, "unit": "TB/s",
                 "frac": pb / (pd * 1e-3) / 1e12 / 8.0, "traffic": pmc_traffic("proj_ln_kernel"),
                 "launches_per_step": len(pl_prof) // PROFILE_STEPS, "avg_launch_us": pd * 1e3 / len(pl_prof),
                 "share_of_step_time": (pd / PROFILE_STEPS) / (elapsed / args.steps * 1e3),

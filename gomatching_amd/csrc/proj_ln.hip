@@ -7,16 +7,9 @@
 // intra / inter / cross blocks).  As two launches (GEMM with the residual in its epilogue, then LayerNorm) the pair moves
 // 1 + 1 + 1 | 1 + 1 = 5 KB per token through HBM for 131 kFLOP -- 26 FLOP/B, a pure HBM stream; fused it is 3 KB.
 //
-// Structure: the second half of the fused FFN kernel (ffn_fused.hip) with the input rows as the B operand.  One workgroup = 4
-// waves = 128 rows, one wave per SIMD with the whole register file: each wave splits its 32 rows once into MFMA operand
-// fragments (128 VGPRs, whole K), the EIGHT 32-column accumulators stay in AGPRs, and the product is computed transposed
-// (row of X = lane), Y^T[256 x 32 rows] += W[:, 16-wide k-step] . X^T, so that the LayerNorm's row statistics are in-lane sums.
-// The weights stream through a two-stage LDS ring by MUBUF LDS-DMA from a fragment-linear, k-major image: 4 stages of 64 KB =
-// 4 k-steps x 8 column tiles x 2 planes each; one DMA per six MFMAs inside the product.  The loop over the 4 stages is unrolled
-// (the B operand of k-step s is a fixed register set).  Per output element the plane products run in the tile kernel's order
-// (X-lo W-hi, X-hi W-lo, X-hi W-hi per 16-wide k-step, k ascending): the pre-norm values are gom_gemm_f32_f16x3's bits.
-// Epilogue = the fused FFN kernel's: Y^T through the (now free) ring to row-major, then 16 lanes per row apply the weight
-// scale, bias, residual and norm.hip's two-pass LayerNorm and store whole rows.
+// Structure (round 5; the round-2 form -- 128-row tiles at one workgroup per CU, 32x32x16, the tile kernel's bits -- was one
+// workgroup's 27 us latency chain whatever the launch's length and left in round 6: docs/LAB_NOTES.md): a workgroup owns 64 rows,
+// a wave 16 of them as v_mfma_f32_16x16x32_f16 operand fragments, TWO workgroups per CU; see proj_ln2_kernel below.
 #include "common.h"
 
 namespace {
@@ -28,11 +21,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int D = 256;                                   // model width = K = N (fixed: every shipped config)
 constexpr int FRAG = 1024;                               // bytes of one MFMA operand fragment
-constexpr int STAGE_FRAGS = 4 * (D / 32) * 2;            // 4 k-steps x 8 column tiles x 2 planes
-constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG;          // 64 KB
-constexpr int STAGES = (D / 16) / 4;                     // 4
-constexpr int BM = 128;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;               // = BM * D * 4: the epilogue's row-major staging fits the ring exactly
 
 struct ProjArgs {
     const float* X;
@@ -45,7 +33,7 @@ struct ProjArgs {
     float* Y;
     int* flag;
     float eps;
-    int ldx, ldr, ldy, M, stagger;
+    int ldx, ldr, ldy, M;
     const float* dot_w;                                      // dot form: out[m] = <Y[m, :], dot_w> + dot_b, Y itself is not stored
     float* dot_out;
     float dot_b;
@@ -86,188 +74,10 @@ __device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned
 
 // FORM 0: + residual, rows stored (the attention blocks); 1: no residual, rows stored; 2: no residual, only <row, dot_w> + dot_b
 // stored.  Compile-time: as run-time branches the residual loads of form 0 were no longer batched (268 -> 405 us at 297k rows).
-template <int FORM>
-__global__ __launch_bounds__(256, 1) void proj_ln_kernel(const ProjArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 31, fh = lane >> 5;
-    const long row0 = (long)blockIdx.x * BM + wave * 32;
-
-    // long launches: the first round of workgroups starts staggered over the CUs of an XCD, so that the CUs' memory phases
-    // (prologue loads, epilogue residual reads and stores) do not all fall on the same moments (ffn_fused.hip): 303 -> 277 us
-    if (p.stagger > 0 && blockIdx.x < 256)
-        for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-    const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, STAGES * STAGE_BYTES, 0x00020000);
-    // this wave's 32 rows as operand fragments (whole-line loads + a layout change in the ring's second slot: common.h); stage 0
-    // -- 64 fragments, sixteen per wave (fragments wave, wave + 4, ...) -- is requested behind the first loads
-    int range_bad = 0;
-    half8 xf[2][D / 16];
-    {
-        float xmax = 0.f;
-        auto xrow = [&](int r) {
-            long m = row0 + r;
-            if (m > p.M - 1) m = p.M - 1;                     // tail rows recompute the last row (never stored)
-            return p.X + (size_t)m * p.ldx;
-        };
-        gom_rows_to_fragments<128, false>(xrow, xrow, reinterpret_cast<float*>(smem + STAGE_BYTES) + wave * (32 * 128), lane, xf, xmax,
-                                          [&]() {
-                                              for (int f = wave; f < STAGE_FRAGS; f += 4)
-                                                  dma_fragment(rs_img, f * FRAG + lane * 16, smem + f * FRAG);
-                                          });
-        range_bad = !(xmax <= 65504.f);
-    }
-
-    f32x16 acc[D / 32];
-#pragma unroll
-    for (int t = 0; t < D / 32; ++t)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    constexpr unsigned OOB = 0x7FFF0000u;                    // beyond num_records: such a DMA writes zeros (into an unused stage)
-#pragma unroll
-    for (int c = 0; c < STAGES; ++c) {
-        const int st = c & 1;
-        const unsigned nsrc = c + 1 < STAGES ? (unsigned)(c + 1) * STAGE_BYTES + wave * FRAG + lane * 16 : OOB;
-        unsigned char* ndst = smem + (st ^ 1) * STAGE_BYTES + wave * FRAG;
-        const unsigned char* base = smem + st * STAGE_BYTES + lane * 16;
-        half8 fa[8], fb[8];
-#define PLN_DMA(i) dma_fragment(rs_img, nsrc + (i) * 4 * FRAG, ndst + (i) * 4 * FRAG);
-#define PLN_LOAD(dst, g)                                                                                      \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                          \
-        dst[i_] = *reinterpret_cast<const half8*>(base + ((g) * 8 + i_) * FRAG);
-#define PLN_PIN()                                         \
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        // group g of a stage (8 fragments): k-step pair g >> 2, column tiles 2 (g & 3), 2 (g & 3) + 1; fragment 2 i + p of the
-        // group = plane p of (tile 2 (g & 3) + (i >> 1), k-step 4 c + 2 (g >> 2) + (i & 1))
-#define PLN_MFMA(src, g)                                                                                      \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
-        const int t_ = ((g) & 3) * 2 + (i_ >> 1), s_ = 4 * c + 2 * ((g) >> 2) + (i_ & 1);                     \
-        acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[1][s_], acc[t_], 0, 0, 0);           \
-        acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_ + 1], xf[0][s_], acc[t_], 0, 0, 0);       \
-        acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[2 * i_], xf[0][s_], acc[t_], 0, 0, 0);           \
-    }
-        PLN_LOAD(fa, 0)
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        PLN_LOAD(fb, 1) PLN_MFMA(fa, 0) PLN_DMA(0) PLN_DMA(1) PLN_PIN()
-        PLN_LOAD(fa, 2) PLN_MFMA(fb, 1) PLN_DMA(2) PLN_DMA(3) PLN_PIN()
-        PLN_LOAD(fb, 3) PLN_MFMA(fa, 2) PLN_DMA(4) PLN_DMA(5) PLN_PIN()
-        PLN_LOAD(fa, 4) PLN_MFMA(fb, 3) PLN_DMA(6) PLN_DMA(7) PLN_PIN()
-        PLN_LOAD(fb, 5) PLN_MFMA(fa, 4) PLN_DMA(8) PLN_DMA(9) PLN_PIN()
-        PLN_LOAD(fa, 6) PLN_MFMA(fb, 5) PLN_DMA(10) PLN_DMA(11) PLN_PIN()
-        PLN_LOAD(fb, 7) PLN_MFMA(fa, 6) PLN_DMA(12) PLN_DMA(13) PLN_PIN()
-        PLN_MFMA(fb, 7) PLN_DMA(14) PLN_DMA(15)
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-#undef PLN_DMA
-#undef PLN_LOAD
-#undef PLN_PIN
-#undef PLN_MFMA
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of the next stage has landed
-        __syncthreads();                                     // ... and everybody's; nobody still reads this stage
-    }
-
-    // ---- epilogue: Y^T (row of X on the lane, output feature in the registers) -> row-major through LDS ----
-    float* stg = reinterpret_cast<float*>(smem);             // [128][256] fp32; 16-byte chunk c of row r at chunk c ^ (r & 7)
-    {
-        float* mine = stg + (wave * 32 + fr) * D;
-#pragma unroll
-        for (int t = 0; t < D / 32; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-                const int chunk = 8 * t + 2 * q + fh;        // features 32 t + 8 q + 4 h .. + 3
-                *reinterpret_cast<f32x4*>(mine + ((chunk ^ (fr & 7)) << 2)) = v;
-            }
-    }
-    __syncthreads();
-    // row pass: FOUR rows per wave-instruction, 16 lanes per row, each lane four 16-byte column chunks (sub, sub + 16, ...)
-    const int sub = lane & 15, rsel = lane >> 4;
-    f32x4 sc[4], bi[4], ga[4], be[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int col = (sub + 16 * k) * 4;
-        sc[k] = *reinterpret_cast<const f32x4*>(p.inv + col);
-        bi[k] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        ga[k] = *reinterpret_cast<const f32x4*>(p.gamma + col);
-        be[k] = *reinterpret_cast<const f32x4*>(p.beta + col);
-    }
-    f32x4 dw[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        dw[k] = FORM == 2 ? *reinterpret_cast<const f32x4*>(p.dot_w + (sub + 16 * k) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    int bad = range_bad;
-#pragma unroll 2
-    for (int g = 0; g < 8; ++g) {
-        const int lr = wave * 32 + 4 * g + rsel;               // row inside the workgroup's tile
-        const long m = (long)blockIdx.x * BM + lr;
-        const long mc = m < p.M ? m : p.M - 1;                  // tail rows recompute the last row, never stored
-        f32x4 v[4];
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ch = sub + 16 * k;
-            const f32x4 y = *reinterpret_cast<const f32x4*>(stg + lr * D + ((ch ^ (lr & 7)) << 2));
-            if constexpr (FORM == 0) {
-                const f32x4 r = *reinterpret_cast<const f32x4*>(p.R + (size_t)mc * p.ldr + ch * 4);
-                v[k] = y * sc[k] + bi[k] + r;                   // the tile kernel's epilogue: fma(acc, scale, bias) + residual
-            } else {
-                v[k] = y * sc[k] + bi[k];
-            }
-            sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
-        }
-        const float mean = row16_sum(sum) * (1.f / D);
-        float q = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[k] = v[k] - mean;
-            q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
-        }
-        const float rstd = rsqrtf(row16_sum(q) * (1.f / D) + p.eps);
-        float dot = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f32x4 o = v[k] * rstd * ga[k] + be[k];
-            bad |= !(fabsf(o[0]) <= 3.4e38f) | !(fabsf(o[1]) <= 3.4e38f) | !(fabsf(o[2]) <= 3.4e38f) | !(fabsf(o[3]) <= 3.4e38f);
-            if constexpr (FORM == 2) dot += (o[0] * dw[k][0] + o[1] * dw[k][1]) + (o[2] * dw[k][2] + o[3] * dw[k][3]);
-            else if (m < p.M) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + (sub + 16 * k) * 4) = o;
-        }
-        if constexpr (FORM == 2) {
-            dot = row16_sum(dot) + p.dot_b;
-            if (sub == 0 && m < p.M) p.dot_out[m] = dot;
-        }
-    }
-    if (bad && p.flag) atomicOr(p.flag, 1);                  // an operand left fp16's range (gemm_f16x3.hip contract)
-}
-
-// k-major fragment-linear image of W[256, 256] (row-scaled planes of gom_split_f16x2).  Stage c (k-steps 4c .. 4c + 3), group g
-// (0..7), fragment 2 i + p of the group (i = 0..3): element j of lane (r, h) =
-//     plane p of Ws[32 (2 (g & 3) + (i >> 1)) + r][16 (4 c + 2 (g >> 2) + (i & 1)) + 8 h + j]
-__global__ __launch_bounds__(256) void proj_ln_image_kernel(const unsigned short* __restrict__ planes, long plane_stride, int ldw,
-                                                            unsigned short* __restrict__ img) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)STAGES * STAGE_FRAGS * 512;
-    if (idx >= total) return;
-    const int e = (int)(idx % 512), f = (int)((idx / 512) % STAGE_FRAGS), c = (int)(idx / (512L * STAGE_FRAGS));
-    const int l = e >> 3, j = e & 7, r = l & 31, h = l >> 5;
-    const int g = f >> 3, i = (f >> 1) & 3, pl = f & 1;
-    const int t = 2 * (g & 3) + (i >> 1), s = 4 * c + 2 * (g >> 2) + (i & 1);
-    img[idx] = planes[pl * plane_stride + (size_t)(32 * t + r) * ldw + 16 * s + 8 * h + j];
-}
-
 // ---- round 5: the TWO-WORKGROUPS-PER-CU form ----
-// The kernel above is one workgroup's serial chain -- rows in (HBM latency), 384 MFMAs per wave, staged epilogue with the residual
-// in and the rows out -- at one workgroup per CU: a 128-row tile takes ~27 us whether the launch has 157 tiles or 2 324, i.e. the
-// launch is bound by that chain's latency, not by HBM (3.6 of 8 TB/s at M = 297 368).  Here a workgroup owns 64 rows -- a wave 16,
+// The round-2 kernel was one workgroup's serial chain -- rows in (HBM latency), 384 MFMAs per wave, staged epilogue with the residual
+// in and the rows out -- at one workgroup per CU: a 128-row tile took ~27 us whether the launch had 157 tiles or 2 324, i.e. the
+// launch was bound by that chain's latency, not by HBM (3.6 of 8 TB/s at M = 297 368).  Here a workgroup owns 64 rows -- a wave 16,
 // as v_mfma_f32_16x16x32_f16 operand fragments in 64 VGPRs, sixteen 16 x 16 accumulators in 64 more -- so that its <= 256 registers
 // and 64 KB of LDS (a two-stage ring of 32 KB k-step stages = the epilogue's staging area) let TWO workgroups share a CU: one's
 // row / residual / store phases run under the other's MFMAs, and twice as many loads are in flight per CU.  The weights cross
@@ -293,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void proj_ln2_kernel(const ProjArgs p) {
     const int fn = lane & 15, fg = lane >> 4;
     const long tile0 = (long)blockIdx.x * V2_BM;
     const long row0 = tile0 + wave * 16;
-    const unsigned char* img = p.img + (size_t)STAGES * STAGE_BYTES;          // the v2 image follows the first form's
+    const unsigned char* img = p.img;
     const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, (int)V2_IMAGE_BYTES, 0x00020000);
 
     // ---- this wave's 16 rows as B-operand fragments: lane (n, kg) holds X[row n][32 s + 8 kg .. + 7], two planes.  Whole-line loads
@@ -470,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void proj_ln2_kernel(const ProjArgs p) {
     if (bad && p.flag) atomicOr(p.flag, 1);
 }
 
-// v2 image, behind the first form's: stage c = k-step c (32 inputs); fragment f = 2 t + p: element j of lane (m, kg) = plane p of
+// the image: stage c = k-step c (32 inputs); fragment f = 2 t + p: element j of lane (m, kg) = plane p of
 // Ws[16 t + m][32 c + 8 kg + j].
 __global__ __launch_bounds__(256) void proj_ln2_image_kernel(const unsigned short* __restrict__ planes, long plane_stride, int ldw,
                                                              unsigned short* __restrict__ img) {
@@ -485,49 +295,31 @@ __global__ __launch_bounds__(256) void proj_ln2_image_kernel(const unsigned shor
 
 }  // namespace
 
-static int g_proj_ln_v2 = 1;
-/* [host] 1 (default): launches of 1 024 rows or more run the two-workgroups-per-CU form (64-row tiles); 0: the 128-row form. */
-extern "C" int gom_proj_ln_set_v2(int on) {
-    g_proj_ln_v2 = on ? 1 : 0;
-    return GOM_OK;
-}
-
 extern "C" long gom_proj_ln_image_bytes(int n, int k) {
     if (n != D || k != D) return -1;
-    return (long)STAGES * STAGE_BYTES + V2_IMAGE_BYTES;       // both forms' images, one behind the other
+    return V2_IMAGE_BYTES;
 }
 
 extern "C" int gom_proj_ln_image(const void* w_planes, long w_plane_stride, int ldw, int n, int k, void* image,
                                  long image_bytes, void* stream) {
     GOM_CHECK_ARG(w_planes && image && n == D && k == D && ldw >= D);
     GOM_CHECK_ARG(image_bytes >= gom_proj_ln_image_bytes(n, k));
-    const long total = (long)STAGES * STAGE_FRAGS * 512;
-    hipLaunchKernelGGL(proj_ln_image_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)w_planes, w_plane_stride, ldw, (unsigned short*)image);
     const long total2 = (long)V2_STAGES * V2_STAGE_FRAGS * 512;
     hipLaunchKernelGGL(proj_ln2_image_kernel, dim3((unsigned)cdiv(total2, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)w_planes, w_plane_stride, ldw,
-                       (unsigned short*)((unsigned char*)image + (size_t)STAGES * STAGE_BYTES));
+                       (const unsigned short*)w_planes, w_plane_stride, ldw, (unsigned short*)image);
     return gom_launch_status();
 }
 
 template <int FORM>
 static int proj_ln_launch_t(const ProjArgs& a, hipStream_t stream) {
-    if (g_proj_ln_v2) {                                      // (every launch: a row's bits must not depend on the launch's length)
-        hipError_t e2 = hipFuncSetAttribute((const void*)proj_ln2_kernel<FORM>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);
-        if (e2 != hipSuccess) return GOM_ERR_HIP_BASE + (int)e2;
-        hipLaunchKernelGGL(proj_ln2_kernel<FORM>, dim3((unsigned)cdiv(a.M, V2_BM)), dim3(256), V2_LDS_BYTES, stream, a);
-        return gom_launch_status();
-    }
     // (the attribute is per DEVICE: set on every launch -- a process-wide flag would miss a second GPU; it costs ~1 us)
-    hipError_t e = hipFuncSetAttribute((const void*)proj_ln_kernel<FORM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
-    hipLaunchKernelGGL(proj_ln_kernel<FORM>, dim3((unsigned)cdiv(a.M, BM)), dim3(256), LDS_BYTES, stream, a);
+    hipError_t e2 = hipFuncSetAttribute((const void*)proj_ln2_kernel<FORM>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);
+    if (e2 != hipSuccess) return GOM_ERR_HIP_BASE + (int)e2;
+    hipLaunchKernelGGL(proj_ln2_kernel<FORM>, dim3((unsigned)cdiv(a.M, V2_BM)), dim3(256), V2_LDS_BYTES, stream, a);
     return gom_launch_status();
 }
 
 static int proj_ln_launch(ProjArgs a, hipStream_t stream) {
-    a.stagger = cdiv(a.M, BM) >= 1024 ? 4 : 0;               // >= 4 rounds of workgroups
     if (a.dot_out) return proj_ln_launch_t<2>(a, stream);
     return a.R ? proj_ln_launch_t<0>(a, stream) : proj_ln_launch_t<1>(a, stream);
 }

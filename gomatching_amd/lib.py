@@ -63,7 +63,6 @@ SIGNATURES = {
     "gom_dec_attn_raw_image": (I, [P, L, I, P, P, P, L, P]),
     "gom_dec_attn_raw_f32": (I, [P, I, P, F, P, I, P, I, P, I, I, I, I, P, P]),
     "gom_dec_inter_heads_f32": (I, [P, I, P, P, I, I, I, I, P, P]),
-    "gom_proj_ln_set_v2": (I, [I]),
     "gom_proj_ln_image_bytes": (L, [I, I]),
     "gom_proj_ln_image": (I, [P, L, I, I, I, P, L, P]),
     "gom_proj_ln_f32": (I, [P, I, P, P, P, P, I, P, P, F, P, I, I, P, P]),

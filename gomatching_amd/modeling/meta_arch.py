@@ -63,12 +63,6 @@ class GoMatching:
         self.use_graphs = use_graphs                             # hipGraph replay of the detector (see _detect_graphed)
         self._graphs = {}
         self.max_graphs = 2
-        # detector_lanes = 2: consecutive steps' detector passes alternate between two streams (each with its own graph, static
-        # buffers and range-flag word), so that step i + 1's pass starts while step i's still runs: its kernels fill what the
-        # other pass leaves idle -- the decoder's launches (<= 200 of 256 CUs), tail rounds, dispatch gaps.  Same results per step.
-        self.detector_lanes = 1
-        self._lane_next = 0
-        self._lanes = None
         # tracker descriptor uploads (see _h2d): "kernel" = a copy kernel reads the device-mapped pinned staging buffer, so
         # the upload is ordered against the match kernels by plain kernel order; "dma" = async hipMemcpy; "sync" = dma + wait
         self.h2d_mode = "kernel"
@@ -283,8 +277,7 @@ class GoMatching:
         B = len(batched_inputs)
         first = batched_inputs[0]
         src = first["frame_u8"] if "frame_u8" in first else first["image"]
-        key = (B, tuple(src.shape), str(src.dtype), tuple(first.get("resize_hw", ())), bool(first.get("flip_channels")),
-               getattr(self, "_lane_slot", 0))
+        key = (B, tuple(src.shape), str(src.dtype), tuple(first.get("resize_hw", ())), bool(first.get("flip_channels")))
         state = self._graphs.pop(key, None)
         if state is not None:
             self._graphs[key] = state                           # most recently used last
@@ -335,21 +328,6 @@ class GoMatching:
         with a non-blocking D2H copy of the nq-padded detection summary and an event.  No host sync, no tracker
         state touched -- a caller may queue the next step's detection before finishing this one."""
         assert not self.training
-        if self.detector_lanes > 1 and getattr(self, "_det_stream", None) is None and not getattr(self, "_in_lane", False):
-            if self._lanes is None:
-                self._lanes = [(torch.cuda.Stream(device=self.device), torch.zeros((1,), dtype=torch.int32, device=self.device))
-                               for _ in range(self.detector_lanes)]
-                self.max_graphs = max(self.max_graphs, 2 * self.detector_lanes)
-            slot = self._lane_next
-            self._lane_next = (slot + 1) % self.detector_lanes
-            stream, flag = self._lanes[slot]
-            stream.wait_stream(torch.cuda.current_stream())
-            self._in_lane, self._lane_slot = True, slot
-            try:
-                with torch.cuda.stream(stream), ops.flag_scope(flag):
-                    return self.detect_launch(batched_inputs, time_cost)
-            finally:
-                self._in_lane, self._lane_slot = False, 0
         lane = getattr(self, "_det_stream", None)
         if lane is not None and torch.cuda.current_stream() != lane:     # CU-partitioned step: the detector's own lane
             lane.wait_stream(torch.cuda.current_stream())

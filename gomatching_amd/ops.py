@@ -4,9 +4,7 @@ Every function launches hand-written HIP kernels from libgomatching_hip.so on to
 none has a CPU or torch-op fallback.
 """
 import contextlib
-import contextvars
 import ctypes
-import weakref
 
 import numpy as np
 import torch
@@ -128,29 +126,8 @@ def _dev_index(device):
     return d.index if d.index is not None else torch.cuda.current_device()
 
 
-# a detector lane's own flag word while that lane's kernels are queued (GoMatching.detector_lanes): context-local (a second model,
-# another thread or a fallback pass between launch and finish never sees it), entered with `flag_scope`
-_flag_override = contextvars.ContextVar("gom_range_flag_override", default=None)
-_lane_flags = []                     # every flag word ever handed to `flag_scope` (weak references): `check_range_flag` scans them too
-
-
-@contextlib.contextmanager
-def flag_scope(flag):
-    """Kernels queued inside the block raise `flag` (a one-word int32 device tensor) instead of the device's default word."""
-    if not any(r() is flag for r in _lane_flags):
-        _lane_flags[:] = [r for r in _lane_flags if r() is not None] + [weakref.ref(flag)]
-    tok = _flag_override.set(flag)
-    try:
-        yield flag
-    finally:
-        _flag_override.reset(tok)
-
-
 def range_flag(device):
     """Device word the f16x3 kernels set when a result is not finite (an activation beyond fp16's range)."""
-    ov = _flag_override.get()
-    if ov is not None:
-        return ov
     key = _dev_index(device)
     if key not in _range_flags:
         _range_flags[key] = torch.zeros((1,), dtype=torch.int32, device=torch.device("cuda", key))
@@ -160,8 +137,7 @@ def range_flag(device):
 def check_range_flag(device):
     """Host check at a sync point: raises instead of letting an out-of-range activation pass as a result."""
     key = _dev_index(device)
-    words = [_range_flags.get(key)] + [r() for r in _lane_flags]
-    words = [f for f in words if f is not None and f.device.index == key]
+    words = [f for f in [_range_flags.get(key)] if f is not None]
     up = [f for f in words if int(f.item()) != 0]
     if up:
         for f in up:
@@ -547,8 +523,6 @@ PROJ_LN = _switch("PROJ_LN")         # f16x3 back-end: out_proj + residual + Lay
 POS_PERIODIC = _switch("POS_PERIODIC")   # f16x3 back-end: the encoder's position table read as row m % S (no broadcast copy)
 
 
-PROJ_LN_V2 = _switch("PROJ_LN_V2")   # out_proj + LayerNorm launches on 64-row tiles at two workgroups per CU (round 5); 0: the 128-row form
-_proj_ln_v2_set = [None]
 
 
 class ProjLN:
@@ -578,9 +552,6 @@ def proj_ln_block(pair, norm):
 
 
 def _proj_ln_form():
-    if _proj_ln_v2_set[0] != PROJ_LN_V2:                     # library-side switch follows ops.PROJ_LN_V2
-        _L().gom_proj_ln_set_v2(1 if PROJ_LN_V2 else 0)
-        _proj_ln_v2_set[0] = PROJ_LN_V2
 
 
 def proj_ln(x, blk, R, out=None):

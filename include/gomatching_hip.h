@@ -189,10 +189,9 @@ int gom_stem_conv_pool_f32(const float* X, const void* Wplanes, long w_plane_str
  *     Y = LayerNorm(X W^T + b + R) * gamma + beta,   X, R, Y [M, 256] fp32 (row strides ldx / ldr / ldy; Y may alias R), W [256, 256]
  * = `norm1(src + out_proj(...))` of an encoder layer and the three `norm_*(tgt + out_proj(...))` of a decoder layer
  * (deformable_transformer.py:258-264, 386-422): 3 KB of HBM traffic per token instead of the 5 KB of GEMM + LayerNorm.  f16x3
- * scheme, range contract and *flag of gom_gemm_f32_f16x3; the pre-norm values are that kernel's bits.  gom_proj_ln_image:
+ * scheme, range contract and *flag of gom_gemm_f32_f16x3 (fp32-class agreement with it, k-steps of 32).  gom_proj_ln_image:
  * one-time weight preparation from the gom_split_f16x2 planes (gom_proj_ln_image_bytes bytes; -1 = shape not served);
  * w_inv_scale = the split's inverse row scales, bias may be NULL. */
-int gom_proj_ln_set_v2(int on);          /* [host] 1 (default): the two-workgroups-per-CU form (64-row tiles, 16x16x32 MFMA); 0: the 128-row form */
 long gom_proj_ln_image_bytes(int n, int k);
 int gom_proj_ln_image(const void* w_planes, long w_plane_stride, int ldw, int n, int k, void* image, long image_bytes,
                       void* stream);

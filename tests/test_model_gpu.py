@@ -501,54 +501,6 @@ def test_detector_graph_replay_equals_eager_and_is_bounded():
     assert sum(isinstance(v, dict) for v in model._graphs.values()) <= model.max_graphs
 
 
-def test_two_detector_lanes_equal_one():
-    """GoMatching.detector_lanes = 2 (consecutive steps' detector passes on alternating streams, each with its own graph, static
-    buffers and range-flag word): every step's results equal the single-lane run's, through warm / capture / replay, and an
-    out-of-range activation is attributed to the step (lane) that produced it."""
-    from gomatching_amd.modeling import GoMatching
-    from gomatching_amd.predictor import ClipPipeline
-    from gomatching_amd.weights import synth_state_dict
-    cfg = mini_cfg("icdar15", device=DEV)
-    sd = synth_state_dict(cfg, seed=7, cls_bias={"detection_transformer.ctrl_point_class.0.bias": 0.5})
-    g = torch.Generator().manual_seed(5)
-    steps = [[{"image": (torch.rand(3, 96, 128, generator=g) * 255).to(DEV)} for _ in range(3)] for _ in range(7)]
-
-    def run(lanes):
-        model = GoMatching(cfg, sd, device=DEV, frames_per_step=3)
-        model.detector_lanes = lanes
-        outs = []
-
-        def finish(h):
-            dets = model.detect_finish(h, _time_cost())
-            return [(d.scores.clone(), d.bd.clone(), d.recs.clone(), d.reid_features.clone()) for d in dets]
-        pipe = ClipPipeline(model, finish)
-        for st in steps:
-            r = pipe.push(st, _time_cost())
-            if r is not None:
-                outs.append(r)
-        outs.append(pipe.flush())
-        assert model.fallback_steps == 0
-        return outs, model
-    one, _ = run(1)
-    two, m2 = run(2)
-    assert len(one) == len(two) == len(steps)
-    for a, b in zip(one, two):
-        for fa, fb in zip(a, b):
-            for x, y in zip(fa, fb):
-                assert torch.equal(x, y)
-    assert sum(isinstance(v, dict) for v in m2._graphs.values()) == 2          # one captured graph per lane
-    # a NaN frame in ONE step: that step (and only it) reports it
-    bad = [dict(x) for x in steps[0]]
-    bad[1] = {"image": torch.full((3, 96, 128), float("nan"), device=DEV)}
-    m2.precision_fallback = False
-    h_bad = m2.detect_launch(bad, _time_cost())
-    h_ok = m2.detect_launch(steps[1], _time_cost())
-    with pytest.raises(Exception, match="non-finite|fp16"):
-        m2.detect_finish(h_bad, _time_cost())
-    m2.detect_finish(h_ok, _time_cost())
-    m2.close()
-
-
 def test_mixed_resolution_clip():
     """Frames of different sizes in one batch_inference call are split into per-size steps (config #5)."""
     from gomatching_amd.modeling import GoMatching

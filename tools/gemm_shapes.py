@@ -67,7 +67,7 @@ for label, M in (("enc out_proj + residual + LayerNorm fused (proj_ln)", S8), ("
     x = torch.randn((M, 256), generator=g).to(dev)
     r = torch.randn((M, 256), generator=g).to(dev)
     y = torch.empty_like(x)
-    run(label, lambda: ops.proj_ln(x, blk, r, out=y), 2.0 * M * 256 * 256, "proj_ln2_kernel" if ops.PROJ_LN_V2 else "proj_ln_kernel")
+    run(label, lambda: ops.proj_ln(x, blk, r, out=y), 2.0 * M * 256 * 256, "proj_ln2_kernel")
     del x, r, y
 for label, M in (("enc FFN block fused (linear1+ReLU+linear2+residual+LayerNorm)", S8), ("dec FFN block fused (stand-alone; in the product inside the tail launch)", Q)):
     F = 1024
@@ -87,7 +87,8 @@ tail = ops.DecTail(tuple(dv(v) for v in ffn_w), [(dv(w), dv(b)) for w, b in coor
                    proj_w=(wo, bo, torch.ones((256,), device=dev), torch.zeros((256,), device=dev)))
 samp, X, R = dv(torch.randn((Q, 256), generator=g)), dv(x), dv(ref)
 run("dec layer tail: cross out_proj + norm, FFN + norm3, ctrl_point_coord + refinement, next ref_point_head (one launch)",
-    lambda: ops.dec_tail(samp, tail, R, want_qpos=True, residual=X), 2.0 * Q * 256 * (256 + 2 * 1024 + 4 * 256 + 2), "dec_tail_kernel")
+    lambda: ops.dec_tail(samp, tail, R, want_qpos=True, residual=X), 2.0 * Q * 256 * (256 + 2 * 1024 + 4 * 256 + 2),
+    "dec_tail2_kernel" if tail.form == 2 else "dec_tail_kernel")
 in_w, in_b = dv(torch.randn((768, 256), generator=g) / 16), dv(torch.randn((768,), generator=g) * 0.1)
 ones, zeros = torch.ones((256,), device=dev), torch.zeros((256,), device=dev)
 rw, rb = dv(torch.randn((384, 256), generator=g) / 16), dv(torch.randn((384,), generator=g) * 0.1)
