@@ -523,8 +523,6 @@ PROJ_LN = _switch("PROJ_LN")         # f16x3 back-end: out_proj + residual + Lay
 POS_PERIODIC = _switch("POS_PERIODIC")   # f16x3 back-end: the encoder's position table read as row m % S (no broadcast copy)
 
 
-
-
 class ProjLN:
     """`LayerNorm(x W^T + b + R)` prepared for gom_proj_ln_f32 (csrc/proj_ln.hip): k-major fragment image of the f16x3 planes of
     W [256, 256] + inverse row scales + bias + the norm's gain / bias.  `pair` / `norm` stay available for the two-launch path."""
@@ -551,12 +549,8 @@ def proj_ln_block(pair, norm):
     return None
 
 
-def _proj_ln_form():
-
-
 def proj_ln(x, blk, R, out=None):
     """LayerNorm(x @ W^T + b [+ R]) * gamma + beta in one launch; x, R [M, 256] row-strided (R may be None)."""
-    _proj_ln_form()
     assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == 256 and x.dtype == _f32
     assert R is None or (R.shape == x.shape and R.stride(1) == 1 and R.dtype == _f32)
     M = x.shape[0]
@@ -583,7 +577,6 @@ PROPOSAL_DOT = _switch("PROPOSAL_DOT")   # f16x3 back-end: enc_output + norm + c
 def proj_ln_dot(x, blk, w, b):
     """[M] = <LayerNorm(x @ W^T + b) * gamma + beta, w> + b in one launch (the normalised rows are not stored); w [256] fp32
     device tensor, b a Python float."""
-    _proj_ln_form()
     assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == 256 and x.dtype == _f32
     _chk_f32(w)
     assert w.numel() == 256

@@ -841,12 +841,15 @@ def detect_frames(sd, cfg, images, taps=None, topk_override=None):
     return roi_heads_forward(sd, cfg, props)
 
 
-def run_clip(sd, cfg, images, orig_hw=None, log=None):
-    """Whole path for one clip (GoMBatchPredictor.__call__ window, text_track_visualizer.py:325-334)."""
+def run_clip(sd, cfg, images, orig_hw=None, log=None, per_frame=None):
+    """Whole path for one clip (GoMBatchPredictor.__call__ window, text_track_visualizer.py:325-334).  per_frame: the frames'
+    detections when a caller already has them (`detect_frames` of each image on its own: tests share them between cases)."""
     with torch.no_grad():
-        per_frame = []
-        for im in images:                                   # one frame at a time, as the reference does
-            per_frame.extend(detect_frames(sd, cfg, [im]))
+        if per_frame is None:
+            per_frame = []
+            for im in images:                               # one frame at a time, as the reference does
+                per_frame.extend(detect_frames(sd, cfg, [im]))
+        assert len(per_frame) == len(images)
         instances, id_count = track_clip(sd, cfg, per_frame, log=log)
         if cfg.VIDEO_TEST.MIN_TRACK_LEN > 0:
             instances = remove_short_track(cfg, instances)

@@ -112,6 +112,25 @@ def _same_detections(got, ref, px_tol):
     return worst
 
 
+# The oracle's detector on a full-size frame is 10-20 s of CPU work; the rank-conditioned and the unconditioned test of a clip
+# look at the same frames of the same clip under the same weights, so each frame is detected once per session and shared
+# (deep copies: the oracle's tracker writes into its inputs).  The taps kept are the two the rank test reads.
+_ORACLE_DETS = {}
+
+
+def _oracle_detect(key, sd, ocfg, image, f):
+    import copy
+    from oracle import gom_oracle as O
+    k = key + (f,)
+    if k not in _ORACLE_DETS:
+        taps = {}
+        with torch.no_grad():
+            det = O.detect_frames(sd, ocfg, [image], taps=taps)[0]
+        _ORACLE_DETS[k] = (det, {"topk": taps["topk"].clone(), "enc_class": taps["enc_class"].clone()})
+    det, taps = _ORACLE_DETS[k]
+    return copy.deepcopy(det), taps
+
+
 def _clip_vs_oracle(builtin, frames_rgb, frac, check_frames, log, full=FULL, opts=()):
     """Runs the clip through `GoMatching.batch_inference` + short-track removal + rescaling and through the oracle.
     `full`: `oracle.run_clip` over EVERY frame, the oracle detecting on its own in its own rank order (unconditioned)."""
@@ -140,13 +159,14 @@ def _clip_vs_oracle(builtin, frames_rgb, frac, check_frames, log, full=FULL, opt
         assert torch.equal(a["scores"], b.scores.cpu()) and torch.equal(a["pred_boxes"], b.pred_boxes.tensor.cpu())
     raw_ids = [x.track_ids.cpu().clone() for x in insts]
     torch.set_num_threads(min(32, os.cpu_count() or 8))
+    import hashlib
+    key = (builtin, tuple(opts), float(frac), len(frames_rgb), hashlib.sha1(np.ascontiguousarray(frames_rgb[0]).tobytes()).hexdigest())
     t0 = time.time()
     log["checked_frames"] = []
     if not FULL:
         with torch.no_grad():
             for f in check_frames:                                     # the CPU detector on a subset of the frames
-                taps_o = {}
-                ref = O.detect_frames(sd, ocfg, [images[f]], taps=taps_o)[0]
+                ref, taps_o = _oracle_detect(key, sd, ocfg, images[f], f)
                 s0, s1 = [st for st in model._steps(inputs) if st[0] <= f < st[1]][0]
                 moved, order = _rank_swaps(model, inputs[s0:s1], f - s0, taps_o, cfg.MODEL.TRANSFORMER.NUM_QUERIES)
                 if len(moved):                                         # near-tied winners fell the other way: same order, again
@@ -160,7 +180,8 @@ def _clip_vs_oracle(builtin, frames_rgb, frac, check_frames, log, full=FULL, opt
     log["tracks"] = int(id_count)
     with torch.no_grad():
         if FULL:
-            o_res, o_count = O.run_clip(sd, ocfg, images, orig_hw=sizes)
+            per_frame = [_oracle_detect(key, sd, ocfg, im, f)[0] for f, im in enumerate(images)]
+            o_res, o_count = O.run_clip(sd, ocfg, images, orig_hw=sizes, per_frame=per_frame)
         else:
             o_inst, o_count = O.track_clip(sd, ocfg, raw)
             for f, x in enumerate(o_inst):
