@@ -149,3 +149,4 @@ def test_dec_tail_with_out_proj_in_front(M, want, form):
     assert float((y - y2).abs().max()) <= 3e-5 and float((nref - nref2).abs().max()) <= 2e-6
     if want:
         assert float((qp - qp2).abs().max()) <= 3e-5
+
