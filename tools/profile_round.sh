@@ -2,7 +2,7 @@
 # Round profiles (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats, the two PMC passes, per-shape GEMM
 # trace.  Everything lands under gpurun_out/final/; copy what is judged into profiles/.
 #   usage: bash tools/profile_round.sh [tag]
-tag=${1:-r05}
+tag=${1:-r06}
 out=gpurun_out/final_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -17,23 +17,6 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $ou
 echo "write rc $?"
 python3 tools/pmc_traffic.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv $tag $out/gemm_api_grids.json | head -14
 cp profiles/pmc_traffic.json $out/pmc_traffic.json
-# the encoder projection's traffic with the separable position table (ops.POS_SEPARABLE, off by default): same two passes, that kernel only
-GOM_POS_SEPARABLE=1 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch_sep -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-backends --no-config-legs > /dev/null 2> $out/pmc_sep.err
-GOM_POS_SEPARABLE=1 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write_sep -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-backends --no-config-legs > /dev/null 2>> $out/pmc_sep.err
-python3 - $out/pmc_fetch_sep/f_counter_collection.csv $out/pmc_write_sep/w_counter_collection.csv profiles/pmc_traffic.json > $out/${tag}_k256_separable_pmc.txt <<'PY'
-import csv, json, sys
-def mean(path, counter):
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and "gemm_k256_kernel<true>" in r["Kernel_Name"]]
-    return sum(v) / max(len(v), 1) * 1024.0, len(v)
-f, n = mean(sys.argv[1], "FETCH_SIZE")
-w, _ = mean(sys.argv[2], "WRITE_SIZE")
-base = json.load(open(sys.argv[3])).get("gemm_k256_kernel<true>", {})
-print("gemm_k256_kernel<true>, HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, mean over %d launches: 6 x N = 640 + 1 x N = 1536 per step)" % n)
-print("  per-pixel position table (default):     fetch x2 %.1f MB + write %.1f MB = %.1f MB" % (base.get("fetch_bytes_x2", 0) / 1e6, base.get("write_bytes", 0) / 1e6, base.get("hbm_bytes_per_launch", 0) / 1e6))
-print("  separable table (GOM_POS_SEPARABLE=1):  fetch x2 %.1f MB + write %.1f MB = %.1f MB" % (2 * f / 1e6, w / 1e6, (2 * f + w) / 1e6))
-print("  algorithmic (M = 297 368 rows: A 304.5 MB + C 761.3 MB (N = 640) / 1 827 MB (N = 1536), mean over the 7 launches): %.1f MB" % ((6 * (304.5 + 761.3) + 304.5 + 1827.0) / 7))
-PY
-rm -rf $out/pmc_fetch_sep $out/pmc_write_sep
 # the round's bench line AFTER the PMC passes: `roofline.traffic` then carries the counters of this very build
 timeout 600 python3 bench.py --steps 20 --warmup 3 > $out/${tag}_bench_final.json 2> $out/bench_final.err
 echo "bench rc $?"
