@@ -364,8 +364,14 @@ __global__ __launch_bounds__(256, 1) void dec_tail_kernel(const TailArgs p) {
             const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b2 + col);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const f32x4 xr = WITH_PROJ ? *reinterpret_cast<const f32x4*>(p.Y + (size_t)mrow[r] * p.ldy + col)
-                                           : *reinterpret_cast<const f32x4*>(p.X + (size_t)mrow[r] * p.ldx + col);
+                // (WITH_PROJ: the residual parked in Y by this lane above; a tail lane has parked nothing and must not read row
+                //  M - 1 while its owner stores there -- ADVICE r5 -- so it takes zeros: its values are never stored)
+                f32x4 xr = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (WITH_PROJ) {
+                    if (live[r]) xr = *reinterpret_cast<const f32x4*>(p.Y + (size_t)mrow[r] * p.ldy + col);
+                } else {
+                    xr = *reinterpret_cast<const f32x4*>(p.X + (size_t)mrow[r] * p.ldx + col);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = fmaf(acc2[t][r][e], sc[e], bi[e]) + xr[e];

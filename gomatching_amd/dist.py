@@ -167,6 +167,10 @@ def exchange_and_track(model, dets, batch_id, id_count, instances, time_cost, gr
     if world == 1 or not shard:
         return model.track_frames(all_dets, batch_id, id_count, instances, time_cost)
     rank = dist.get_rank(group)
+    # fixed-shape exchange: every rank contributes the same number of frames (the block-sharding of a clip: bench.py, north_star)
+    assert int(allrec.shape[0]) == world * F_local, ("ranks detected different numbers of frames", int(allrec.shape[0]), world, F_local)
+    import time
+    t0 = time.time()
     base = 1 if len(instances) else 0
     window = ([instances[-1]] if base else []) + list(all_dets)
     carried = list(instances[-max(model.test_len - 1, 1):]) if base else []
@@ -176,4 +180,5 @@ def exchange_and_track(model, dets, batch_id, id_count, instances, time_cost, gr
     blocks = pack_short_term(st_local, mine, T.NUM_QUERIES, model.device)
     allblk = all_gather_records(blocks, group)
     st = unpack_short_term(allblk, [base + j for j in range(world * F_local)])
+    time_cost["short_match"] = time_cost.get("short_match", 0.0) + (time.time() - t0)   # this rank's share + the second exchange
     return model.track_frames(all_dets, batch_id, id_count, instances, time_cost, st=st)
