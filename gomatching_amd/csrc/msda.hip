@@ -358,7 +358,11 @@ __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __re
 //   * workgroup id = tile * 8 + head: workgroups go round-robin to the 8 XCDs, so XCD m sees exactly head m's lines (1/8 of the
 //     value map per L2) and consecutive tiles, which share their halos, meet in the same L2.
 // Queries of the coarser levels (25 % of the tokens) keep the lane-distributed kernel (q_begin / q_count above).
-template <int TY, int TX, int R, int CAP, int NB>
+// GLV (round 6): the samples of the GLV finest levels are GATHERED from global memory (the lane-distributed kernel's loads, its
+// arithmetic, its accumulation order) instead of served from a window -- for tiles of level-1 queries, whose projection on level 0
+// (twice the pixels per query) is the window that does not fit: an 8 x 16 level-1 tile needs 27 x 43 = 1 161 level-0 lines, its
+// level-1 .. 3 windows 513 + 285 + 195.
+template <int TY, int TX, int R, int CAP, int NB, int GLV = 0>
 __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __restrict__ value,
                                                              const int64_t* __restrict__ shapes,
                                                              const int64_t* __restrict__ lsi,
@@ -432,6 +436,7 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
     // groups' loads, swizzles and LDS reads -- a wave has at most one partner on its SIMD to hide latency behind)
     float sw1[ITERS][2], sw2[ITERS][2], sw3[ITERS][2], sw4[ITERS][2], sww[ITERS][2];
     unsigned pk[ITERS][2];                                   // LDS byte address of corner (yc0, xc0) | dx << 20 | dy << 21
+    unsigned go1[GLV ? ITERS : 1][2], go2[GLV ? ITERS : 1][2], go3[GLV ? ITERS : 1][2], go4[GLV ? ITERS : 1][2];   // GLV: global corner offsets
     f32x4 acc[ITERS];
     long qrow[ITERS];
     bool fast[ITERS], live[ITERS];
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
         sw3[IT][T] = (y1 && x0) ? lh * hw : 0.f;                                                                  \
         sw4[IT][T] = (y1 && x1) ? lh * lw : 0.f;                                                                  \
         /* a sample outside the map carries weight 0: any finite line serves (the kernels above read the map's corner there) */ \
-        OK = !inside || (yc0 >= my0 && yc1 <= my1 && xc0 >= mx0 && xc1 <= mx1);                                   \
+        OK = !inside || l < GLV || (yc0 >= my0 && yc1 <= my1 && xc0 >= mx0 && xc1 <= mx1);                        \
         const bool use = inside && OK; /* (an address inside the buffer in every case) */                         \
         const int ly0 = use ? yc0 - my0 : 0, lx0 = use ? xc0 - mx0 : 0;                                           \
         const unsigned la_ = (unsigned)((ly0 * mww + lx0) * 128);                                                 \
@@ -506,10 +511,14 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
         }
         const float inv_sum = 1.f / sum;
         bool ok0, ok1;
-        unsigned sa1, sa2, sa3, sa4;
+        unsigned sa1, sa2, sa3, sa4, sb1, sb2, sb3, sb4;
         MSDA_GEOMETRY(it, 0, offs[it], rxs[it], rys[it], e0, inv_sum, ok0, sa)
-        MSDA_GEOMETRY(it, 1, offs[it], rxs[it], rys[it], e1, inv_sum, ok1, sa)
-        (void)sa1; (void)sa2; (void)sa3; (void)sa4;
+        MSDA_GEOMETRY(it, 1, offs[it], rxs[it], rys[it], e1, inv_sum, ok1, sb)
+        if constexpr (GLV > 0) {                                // the global byte offsets of this lane's two samples' corners
+            go1[it][0] = sa1; go2[it][0] = sa2; go3[it][0] = sa3; go4[it][0] = sa4;
+            go1[it][1] = sb1; go2[it][1] = sb2; go3[it][1] = sb3; go4[it][1] = sb4;
+        }
+        (void)sa1; (void)sa2; (void)sa3; (void)sa4; (void)sb1; (void)sb2; (void)sb3; (void)sb4;
         fast[it] = __builtin_amdgcn_ballot_w64(!(ok0 && ok1)) == 0;   // wave-uniform: every sample of the 8 queries is inside
         any_slow |= fast[it] ? 0u : 1u;
         acc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -599,7 +608,69 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
         __syncthreads();                                                                                          \
         level_samples(std::integral_constant<int, L>{}, win);                                                     \
     }
-    MSDA_LEVEL_SINGLE(0) MSDA_LEVEL_SINGLE(1) MSDA_LEVEL_SINGLE(2) MSDA_LEVEL_SINGLE(3)
+    // GLV: the four samples of a GATHERED level -- the lane-distributed kernel's inner loop (corner offsets broadcast from the owner
+    // lane, four 16-byte loads of the head's 128-byte slices, the same products in the same order)
+    auto level_gather = [&](auto LEVC) {
+        constexpr int lev = decltype(LEVC)::value;
+#pragma unroll
+        for (int pnt = 0; pnt < POINTS; ++pnt) {
+            const int i = lev * POINTS + pnt, o = i >> 1, t = i & 1;
+#pragma unroll
+            for (int half = 0; half < ITERS; half += NB) {
+                bool any_fast = false;
+#pragma unroll
+                for (int u = 0; u < NB; ++u) any_fast = any_fast || fast[half + u];
+                if (!any_fast) continue;
+                unsigned a1[NB], a2[NB], a3[NB], a4[NB];
+                float w1[NB], w2[NB], w3[NB], w4[NB], ww[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int it = half + u;
+                    asm volatile("" : "+v"(go1[it][t]), "+v"(go2[it][t]), "+v"(go3[it][t]), "+v"(go4[it][t]));
+                    asm volatile("" : "+v"(sw1[it][t]), "+v"(sw2[it][t]), "+v"(sw3[it][t]), "+v"(sw4[it][t]), "+v"(sww[it][t]));
+                    a1[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, go1[it][t]), o)) + mine;
+                    a2[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, go2[it][t]), o)) + mine;
+                    a3[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, go3[it][t]), o)) + mine;
+                    a4[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, go4[it][t]), o)) + mine;
+                    w1[u] = bcast(sw1[it][t], o);
+                    w2[u] = bcast(sw2[it][t], o);
+                    w3[u] = bcast(sw3[it][t], o);
+                    w4[u] = bcast(sw4[it][t], o);
+                    ww[u] = bcast(sww[it][t], o);
+                }
+                f32x4 v1[NB], v2[NB], v3[NB], v4[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    v1[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a1[u], 0, 0));
+                    v2[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a2[u], 0, 0));
+                    v3[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a3[u], 0, 0));
+                    v4[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a4[u], 0, 0));
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const f32x4 val = w1[u] * v1[u] + w2[u] * v2[u] + w3[u] * v3[u] + w4[u] * v4[u];
+                    acc[half + u] += val * ww[u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    static_assert(GLV == 0 || GLV == 1, "only the finest level is ever gathered");
+    if constexpr (GLV == 0) {
+        MSDA_LEVEL_SINGLE(0)
+    } else {
+        // level 1's window is requested first and lands under level 0's gathers (accumulation order l = 0, 1, 2, 3 as everywhere)
+        fill(std::integral_constant<int, 1>{}, win);
+        level_gather(std::integral_constant<int, 0>{});
+    }
+    if constexpr (GLV == 0) {
+        MSDA_LEVEL_SINGLE(1)
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        level_samples(std::integral_constant<int, 1>{}, win);
+    }
+    MSDA_LEVEL_SINGLE(2) MSDA_LEVEL_SINGLE(3)
 #undef MSDA_LEVEL_SINGLE
     if (any_slow) {
         if (slow_groups && lane == 0) {                       // diagnostic count (gom_msda_window_count_fallbacks): octet groups on the global path
@@ -721,7 +792,7 @@ extern "C" int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, cons
     GOM_CHECK_ARG(((uintptr_t)raw % 16) == 0 && ((uintptr_t)value % 16) == 0);
     GOM_CHECK_ARG(h0 > 0 && w0 > 0 && h1 >= 0 && w1 >= 0 && (long)h0 * w0 + (long)h1 * w1 <= num_query);
     constexpr int R = 5, CAP = 576;                          // 72 KB of window lines: two workgroups per CU
-    constexpr int TY0 = 8, TX0 = 16, TY1 = 4, TX1 = 8;
+    constexpr int TY0 = 8, TX0 = 16, TY1 = 8, TX1 = 16;       // level-1 tiles: their level-0 samples are gathered (GLV = 1)
     const long n0 = (long)h0 * w0, n1 = (long)h1 * w1;       // (host copies of spatial_shapes[0], [1]: the tile grids)
     const long wgs0 = (long)batch * cdiv(h0, TY0) * cdiv(w0, TX0) * 8;
     const long wgs1 = (long)batch * cdiv(h1, TY1) * cdiv(w1, TX1) * 8;
@@ -739,7 +810,7 @@ extern "C" int gom_msda_fused_forward_encoder(const float* raw, int ld_raw, cons
     }
     long done = n0;
     if ((g_msda_window & 2) && n1 > 0) {
-        auto kern = msda_window_kernel<TY1, TX1, R, CAP, 1>;
+        auto kern = msda_window_kernel<TY1, TX1, R, CAP, 4, 1>;
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CAP * 128);
         if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
         hipLaunchKernelGGL(kern, dim3((unsigned)wgs1), dim3(256), CAP * 128, s, value, spatial_shapes, level_start_index, raw, ld_raw,

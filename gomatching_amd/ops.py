@@ -1150,7 +1150,7 @@ def msda_window_groups(encoder_hw0, B):
     h0, w0 = int(encoder_hw0[0]), int(encoder_hw0[1])
     n = -(-h0 // 8) * -(-w0 // 16) * 16
     if MSDA_WINDOW_L1 and len(encoder_hw0) >= 4:
-        n += -(-int(encoder_hw0[2]) // 4) * -(-int(encoder_hw0[3]) // 8) * 4
+        n += -(-int(encoder_hw0[2]) // 8) * -(-int(encoder_hw0[3]) // 16) * 16
     return B * 8 * n
 
 

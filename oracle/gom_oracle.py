@@ -617,10 +617,15 @@ class MatchLog:
         return mi, mj, payload
 
     def summary(self):
-        """Smallest margins over the clip (what a reader needs to judge how close the ids sit to a flip)."""
+        """Smallest margins over the clip (what a reader needs to judge how close the ids sit to a flip).  `exact_ties`: matches whose
+        best alternative has EXACTLY the optimum's total (structurally identical scores -- e.g. IoU = 1.0 of a static box against two
+        tracks' identical last boxes: the tie then falls by the assignment solver's order, SciPy's in both implementations);
+        `min_nonzero_assign_gap`: the smallest gap among the others."""
         fin = lambda v: None if v == float("inf") else v
-        return {"matches": len(self.calls),
-                "min_assign_gap": fin(min([c["assign_gap"] for c in self.calls], default=float("inf"))),
+        gaps = [c["assign_gap"] for c in self.calls]
+        return {"matches": len(self.calls), "exact_ties": sum(1 for g_ in gaps if g_ == 0.0),
+                "min_assign_gap": fin(min(gaps, default=float("inf"))),
+                "min_nonzero_assign_gap": fin(min([g_ for g_ in gaps if g_ > 0.0], default=float("inf"))),
                 "min_thr_margin": fin(min([c["thr_margin"] for c in self.calls], default=float("inf")))}
 
 

@@ -388,7 +388,7 @@ def test_msda_encoder_window_kernel_is_bit_identical(shapes, B, scale):
     """The encoder form of the fused op (level-0 and level-1 queries served from LDS windows of the value map, csrc/msda.hip)
     against the lane-distributed kernel on the same inputs: the SAME BITS -- with offsets of a few pixels (everything inside the
     windows), with offsets far beyond the halo (the octet groups' global-memory path, counted), on maps that are not multiples of
-    the 8 x 16 / 4 x 8 tiles and on the bench's pyramid."""
+    the 8 x 16 tiles and on the bench's pyramid (level-1 tiles gather their level-0 samples and window the rest)."""
     ops = _ops()
     from gomatching_amd import lib
     g = torch.Generator().manual_seed(int(scale * 10) + B)
@@ -412,7 +412,7 @@ def test_msda_encoder_window_kernel_is_bit_identical(shapes, B, scale):
             counter.zero_()
             win = ops.msda_fused(raw, ref, wide[:, 384:], S * 640, ss.to(DEV), lsi.to(DEV), B, S, encoder_hw0=hw)
             assert torch.equal(win, plain), (l1, float((win - plain).abs().max()))
-            groups = B * 8 * sum(-(-h // ty) * -(-w // tx) * (ty * tx // 8) for (h, w), (ty, tx) in zip(shapes[:2 if l1 else 1], ((8, 16), (4, 8))))
+            groups = B * 8 * sum(-(-h // ty) * -(-w // tx) * (ty * tx // 8) for (h, w), (ty, tx) in zip(shapes[:2 if l1 else 1], ((8, 16), (8, 16))))
             slow = int(counter.item())
             assert 0 <= slow <= groups
             if scale <= 1.0:

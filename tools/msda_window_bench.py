@@ -63,7 +63,7 @@ for rnd in range(4):
 counter = torch.zeros((1,), dtype=torch.int32, device="cuda")
 Lh.gom_msda_window_count_fallbacks(ctypes.c_void_p(counter.data_ptr()))
 h0, w0, h1, w1 = geo["hw0"]
-groups = B * 8 * (-(-h0 // 8) * -(-w0 // 16) * 16 + -(-h1 // 4) * -(-w1 // 8) * 4)
+groups = B * 8 * (-(-h0 // 8) * -(-w0 // 16) * 16 + -(-h1 // 8) * -(-w1 // 16) * 16)
 off = rv[:, :256].float()
 print("offsets of the bench model's first encoder layer: |off| mean %.2f, p99 %.2f, max %.2f pixels"
       % (float(off.abs().mean()), float(off.abs().flatten()[::97].quantile(0.99)), float(off.abs().max())))
