@@ -1128,10 +1128,10 @@ _msda_lanes_set = [None]
 
 
 MSDA_WINDOW = _switch("MSDA_WINDOW")   # encoder calls: level-0 queries served from LDS windows of the value map (same bits)
-# ... and the level-1 queries (4 x 8 tiles, round 6): bit-identical, SLOWER at the bench shape (958 vs 865 us per encoder call: a 4 x 8
-# tile's windows are 36 lines per (query, head) against 9 for an 8 x 16 level-0 tile, and an 8 x 16 level-1 tile's level-0 window is
-# 1 161 lines = 145 KB); off by default, kept for A/B runs and its parity test
-MSDA_WINDOW_L1 = _switch("MSDA_WINDOW_L1", False)
+# ... and the level-1 queries (round 6): 8 x 16 tiles whose level-0 samples are gathered from global memory (their level-0 window
+# would be 1 161 lines) and whose level-1 .. 3 samples come from windows: bit-identical, encoder call 830 -> 808 us.  (4 x 8 tiles with
+# all four levels from windows were slower: 958 vs 865 us; profiles/r06_msda_level1_windows_and_offset_scale.log)
+MSDA_WINDOW_L1 = _switch("MSDA_WINDOW_L1")
 _msda_window_set = [None]
 
 

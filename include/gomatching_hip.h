@@ -88,10 +88,11 @@ int gom_msda_fused_forward(const float* raw, int ld_raw, const float* ref, const
                            float* output, int batch, int num_query, void* stream);
 /* The same op for an ENCODER call (num_query = the pyramid's tokens, query q of a frame IS token q: the level-0 pixels in raster
  * order, then the coarser levels'; reference points = the tokens' own positions: deformable_transformer.py:288-300).  h0 x w0 and
- * h1 x w1 = host copies of spatial_shapes[0] and [1] (h1 = w1 = 0: no level-1 windows).  Level-0 queries (tiles of 8 x 16) and
- * level-1 queries (tiles of 4 x 8, round 6) are served from per-workgroup LDS windows of the value map -- the tile's projection on
- * every level + 5 pixels of halo, one head per workgroup; an octet group with a sample outside its window falls back to global
- * memory -- the coarser levels' by the kernel of gom_msda_fused_forward.  Bit-identical to gom_msda_fused_forward.
+ * h1 x w1 = host copies of spatial_shapes[0] and [1] (h1 = w1 = 0: no level-1 windows).  Level-0 and level-1 queries (tiles of
+ * 8 x 16, one head per workgroup) are served from per-workgroup LDS windows of the value map -- the tile's projection on every level
+ * + 5 pixels of halo; level-1 tiles (round 6) gather their level-0 samples from global memory instead (that window does not fit);
+ * an octet group with a sample outside its window falls back to global memory -- the coarser levels' queries run on the kernel of
+ * gom_msda_fused_forward.  Bit-identical to gom_msda_fused_forward.
  * [host] gom_msda_set_window(mask): bit 0 = level-0 windows, bit 1 = level-1 windows (default 3), 0 = always the gather kernel.
  * [host] gom_msda_window_count_fallbacks(ptr): diagnostic device word the window launches add their fallback octet groups to. */
 int gom_msda_set_window(int mask);
