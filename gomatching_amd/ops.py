@@ -5,6 +5,7 @@ none has a CPU or torch-op fallback.
 """
 import contextlib
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -988,13 +989,30 @@ DEC_TAIL2 = _switch("DEC_TAIL2")            # ... as the CU-cooperative split-N 
 DEC_TAIL_PROJ = _switch("DEC_TAIL_PROJ")    # ... with the cross-attention's out_proj + norm_cross in front of it
 
 
+def tail_form2_wins(M, cus=256):
+    """Which form of the tail launch is faster at M rows.  A form-2 workgroup (80 rows) takes ~108 us, a form-1 workgroup (128 rows)
+    ~148 us -- 0.74 against 0.86 rows per us and CU: form 2 wins by OCCUPANCY where whole rounds of one-per-CU workgroups decide
+    (8 x 100 x 25 rows: 250 workgroups in one round against 157 in one), form 1 by throughput where they do not (8 x 300 x 25 rows:
+    three rounds of 108 us against two of 148)."""
+    def t(rows, us):
+        rounds = -(-M // rows) / float(cus)
+        return (math.ceil(rounds) if rounds <= 4 else rounds) * us
+    return t(80, 108.0) <= t(128, 148.0)
+
+
 def dec_tail_block(ffn_w, coord_w, qpos_w, dim_t, proj_w=None):
-    """DecTail when the back-end and shapes allow, else None (callers keep the four-launch path)."""
+    """DecTail when the back-end and shapes allow, else None (callers keep the four-launch path).  Under `DEC_TAIL2` the block is the
+    CU-cooperative form with the round-5 form beside it (`.alt`): `dec_tail` takes the faster one for the call's row count
+    (`tail_form2_wins`)."""
     ok = DEC_TAIL and FUSED_FFN and FUSED_MLP2 and REF_UPDATE and GEMM_MODE == "f16x3" and ffn_w[0].shape[1] == 256 and \
         ffn_w[0].shape[0] % 32 == 0 and all(tuple(w.shape) == (256, 256) for w in (coord_w[0][0], coord_w[1][0], qpos_w[0][0], qpos_w[1][0]))
     if proj_w is not None and not (DEC_TAIL_PROJ and tuple(proj_w[0].shape) == (256, 256)):
         proj_w = None
-    return DecTail(ffn_w, coord_w, qpos_w, dim_t, proj_w=proj_w) if ok else None
+    if not ok:
+        return None
+    blk = DecTail(ffn_w, coord_w, qpos_w, dim_t, proj_w=proj_w)
+    blk.alt = DecTail(ffn_w, coord_w, qpos_w, dim_t, proj_w=proj_w, form=1) if blk.form == 2 else None
+    return blk
 
 
 def dec_tail(x, blk, ref, want_qpos=True, residual=None):
@@ -1006,6 +1024,8 @@ def dec_tail(x, blk, ref, want_qpos=True, residual=None):
     _chk_f32(ref)
     M = x.shape[0]
     assert ref.numel() == 2 * M
+    if blk.form == 2 and getattr(blk, "alt", None) is not None and not tail_form2_wins(M):
+        blk = blk.alt                                            # many rounds of workgroups: the 128-row form's throughput wins
     out = torch.empty((M, 256), dtype=_f32, device=x.device)
     new_ref = torch.empty_like(ref)
     qpos = torch.empty((M, 256), dtype=_f32, device=x.device) if want_qpos else None

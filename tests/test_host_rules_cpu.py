@@ -93,3 +93,13 @@ def test_builtin_configs_cover_the_reference_yamls():
         if os.path.exists(ref):
             r = setup_cfg(ref)
             assert keys(r) == w and more(r) == more(c), name
+
+
+def test_tail_form_rule_takes_occupancy_for_short_launches_and_throughput_for_long_ones():
+    """ops.tail_form2_wins: the CU-cooperative tail (80-row workgroups, ~108 us each) against the round-5 form (128 rows, ~148 us):
+    one round of the chip at the BASELINE decoder's 8 x 100 x 25 rows -> form 2; 8 x 300 x 25 rows (configs[3]) = three rounds of
+    form 2 against two of form 1 -> form 1."""
+    from gomatching_amd import ops
+    assert ops.tail_form2_wins(8 * 100 * 25) and ops.tail_form2_wins(2500) and ops.tail_form2_wins(1)
+    assert not ops.tail_form2_wins(8 * 300 * 25)
+    assert ops.tail_form2_wins(16 * 100 * 25)
