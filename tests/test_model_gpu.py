@@ -80,7 +80,7 @@ def test_msda_window_policy_follows_the_measured_offsets():
                 assert sorted(net.msda_window_fallback) == list(range(net.n_enc))
                 assert all(L["msda_window"] is want for L in net.enc), (scale, net.msda_window_fallback)
                 if want:
-                    assert max(net.msda_window_fallback.values()) == 0.0
+                    assert max(net.msda_window_fallback.values()) < 0.01   # (a handful of octet groups on random features)
                 else:
                     assert min(net.msda_window_fallback.values()) > ops.MSDA_WINDOW_MAX_FALLBACK
                 ops.MSDA_WINDOW_POLICY = False
