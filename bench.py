@@ -296,9 +296,10 @@ def main():
     ap.add_argument("--h2d", default=None, choices=["kernel", "dma", "sync"],
                     help="diagnostic: how the tracker uploads its per-match descriptors (GoMatching.h2d_mode)")
     ap.add_argument("--tracker-cus", type=int, default=-1,
-                    help="compute units reserved for the tracker's per-frame recurrence (CU-masked streams); -1 = 32 when the tracker "
-                         "handles the frames of 8 or more GPUs (world size x --emulate-world), else 0: measured 48.6 -> 42.2 ms "
-                         "per step at 8 GPUs' load, 37.4 -> 39.6 at 4 (the detector pays 5 %% for the lost CUs)")
+                    help="compute units reserved for the tracker's per-frame recurrence (CU-masked streams); default 0 = no lane.  "
+                         "Rounds 2-5 reserved 32 from 8 GPUs' frames per tracker on (48.6 -> 42.2 ms per step in round 2); with "
+                         "round 6's kernels the lane LOSES at 8 GPUs' load: 32.3-32.6 ms against 30.5-30.7 without it (three "
+                         "alternating pairs, one box, N = 1: 28.05)")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="N=1 diagnostic: run the replicated tracker over W copies of this GPU's records per step, i.e. "
                          "the tracker load of a W-GPU run, beside one GPU's detection (value still counts 8 frames/step)")
@@ -376,7 +377,7 @@ def main():
         model, sd = build_model(cfg, device)
         if args.h2d:
             model.h2d_mode = args.h2d
-        cus = args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world >= 8 else 0)
+        cus = args.tracker_cus if args.tracker_cus >= 0 else 0
         if cus > 0 and device.type == "cuda":
             try:
                 model.reserve_tracker_cus(cus)
@@ -610,7 +611,7 @@ def main():
                                          "sharded: a rank scores the frame pairs it detected, second all-gather of the [F, 2 + nq^2] blocks")
                    if world * args.emulate_world > 1 else "single rank",
                    "long_term_match": "chain of 13 launches",
-                   "tracker_cus": args.tracker_cus if args.tracker_cus >= 0 else (32 if world * args.emulate_world >= 8 else 0),
+                   "tracker_cus": args.tracker_cus if args.tracker_cus >= 0 else 0,
                    "pipelining": "upload(step i+1) and detector(step i+1) overlap tracker(step i)",
                    "detector_hipgraph": graphed,
                    "parallelism": "frame-sharded dp%d + 1 all-gather/step"
@@ -751,7 +752,11 @@ def main():
                 n0 += geo_["hw0"][2] * geo_["hw0"][3]
         tail_grid = ((FRAMES_PER_GPU * (n_tok - n0) + 3) // 4) * 256
         # (pmc_traffic sums the per-call bytes of every window launch of an encoder call: the level-0 and the level-1 grids)
-        t_win, t_tail = pmc_traffic("msda_window_kernel"), pmc_traffic("msda_fused_lanes_kernel<false> [grid %d]" % tail_grid)
+        l1_on = bool(getattr(ops, "MSDA_WINDOW_L1", False))
+        t_win, t_tail = pmc_traffic("msda_window_kernel<8,16,5,576,4,0>"), pmc_traffic("msda_fused_lanes_kernel<false> [grid %d]" % tail_grid)
+        if l1_on and t_win is not None:                       # an encoder call = the level-0 launch + the level-1 launch + the tail launch
+            t_l1 = pmc_traffic("msda_window_kernel<8,16,5,576,4,1>")
+            t_win = None if t_l1 is None else t_win + t_l1
         enc_traffic = (t_win + t_tail) if (win_on and t_win is not None and t_tail is not None) else None
         line["roofline_msda"] = {
             "bound": "hbm", "kernel": (("msda_window_kernel<8,16,5,576,4> (level-0 queries) + <4,8,5,576,1> (level-1 queries) + "
