@@ -1,10 +1,8 @@
 // The wave- and workgroup-sized pieces of a long-term match (lstmatcher.py:333-381, transformer.py:60-96,
-// gom_lstmatcher.py:429-445/510-547) as device functions over a VIRTUAL task index, shared by
-//   * the one-kernel-per-step launches of the chain (gemm_small.hip, attn.hip, track.hip: task = the hardware wave / block), and
-//   * the whole chain as ONE launch (match_fused.hip: every phase is a grid-stride loop over the same tasks, a grid barrier between
-//     phases).
-// An output's arithmetic is a function of the task alone (its rows, columns and K; never of which wave runs it, or beside what),
-// so both forms return the same bits -- tests/test_match_fused_gpu.py compares them with torch.equal.
+// gom_lstmatcher.py:429-445/510-547) as device functions over a VIRTUAL task index, used by the one-kernel-per-step launches of the
+// chain (gemm_small.hip, attn.hip, track.hip: task = the hardware wave / block).  (Round 5 also walked the same tasks from ONE
+// persistent launch with grid barriers -- bit-identical, slower, out of the build since round 6: tools/exp/match_fused/.)
+// An output's arithmetic is a function of the task alone (its rows, columns and K; never of which wave runs it, or beside what).
 #pragma once
 #include "common.h"
 
