@@ -146,11 +146,17 @@ def mha(q_in, k_in, v_in, sd, name, nheads):
 # A7  multi-scale deformable attention sampling
 #     third_party/adet/layers/csrc/DeformAttn/ms_deform_im2col_cuda.cuh:33-84 (bilinear), :237-299 (kernel)
 # --------------------------------------------------------------------------
-def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, q_chunk=1024):
     """value [B,S,M,D]; spatial_shapes [L,2] (H,W) int64; sampling_loc [B,Lq,M,L,P,2] (x,y in [0,1]);
-    attn_weight [B,Lq,M,L,P]  ->  [B,Lq,M*D].  Zero outside the map; per-corner bounds as the kernel."""
+    attn_weight [B,Lq,M,L,P]  ->  [B,Lq,M*D].  Zero outside the map; per-corner bounds as the kernel.
+    The queries are processed `q_chunk` at a time: every operation below is per (batch, query) row, so the chunking changes no
+    bit of the result -- it keeps the ~20 temporaries of a level (each Lq x M x P x D floats: 245 MB at 60k tokens) in the CPU's
+    caches, which is where a full-size frame's oracle time went (elementwise add / mul / compare over such temporaries)."""
     B, S, M, D = value.shape
     _, Lq, _, L, P, _ = sampling_loc.shape
+    if q_chunk and Lq > q_chunk:
+        return torch.cat([ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc[:, q0:q0 + q_chunk],
+                                                 attn_weight[:, q0:q0 + q_chunk], q_chunk=0) for q0 in range(0, Lq, q_chunk)], dim=1)
     out = value.new_zeros((B, Lq, M, D))
     vflat = value.reshape(B * S * M, D)
     bm = (torch.arange(B).view(B, 1, 1, 1) * S) * M + torch.arange(M).view(1, 1, M, 1)   # row of (b, s=0, m)
