@@ -624,8 +624,9 @@ class MatchLog:
 
     def summary(self):
         """Smallest margins over the clip (what a reader needs to judge how close the ids sit to a flip).  `exact_ties`: matches whose
-        best alternative has EXACTLY the optimum's total (structurally identical scores -- e.g. IoU = 1.0 of a static box against two
-        tracks' identical last boxes: the tie then falls by the assignment solver's order, SciPy's in both implementations);
+        best alternative has EXACTLY the optimum's total (scores that are the same float -- two detections whose association softmax
+        saturates at exactly 1.0 for one track, or IoU = 1.0: the tie then falls by the assignment solver's order, SciPy's in both
+        implementations);
         `min_nonzero_assign_gap`: the smallest gap among the others."""
         fin = lambda v: None if v == float("inf") else v
         gaps = [c["assign_gap"] for c in self.calls]
