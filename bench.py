@@ -68,6 +68,10 @@ def pmc_traffic(kernel):
 def ffn_traffic(calls):
     """HBM bytes per fused-FFN CALL from the PMC passes: the 128-row-tile launch + (long launches only) its half-height tail launch,
     weighted by how many of the step's calls have one."""
+    from gomatching_amd import ops
+    if not (getattr(ops, "DEC_TAIL", True) and getattr(ops, "FUSED_FFN", True)):
+        return None                                          # an ablation run (GOM_DEC_TAIL=0): the decoder's short FFN launches are in the
+                                                             # population and the per-call counters of the committed passes do not apply
     main = pmc_traffic("ffn_fused_kernel<false,2>")
     tail = pmc_traffic("ffn_fused_kernel<false,1>")
     if main is None:
