@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgomatching_hip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["abi.hip", "gemm_conv.hip", "gemm_bf16x6.hip", "gemm_f16x3.hip", "stem_pool.hip", "conv3x3_patch.hip", "ffn_fused.hip", "dec_tail.hip", "dec_tail2.hip", "proj_ln.hip", "dec_attn.hip", "dec_inter.hip", "bneck_fused.hip", "bneck2.hip", "gemm_k256.hip", "gemm_small.hip", "msda.hip", "msda_any.hip", "norm.hip", "attn.hip", "elementwise.hip", "topk.hip",
+SOURCES = ["abi.hip", "gemm_conv.hip", "gemm_bf16x6.hip", "gemm_f16x3.hip", "stem_pool.hip", "conv3x3_patch.hip", "ffn_fused.hip", "dec_tail.hip", "dec_tail2.hip", "proj_ln.hip", "dec_attn.hip", "dec_attn2.hip", "dec_inter.hip", "bneck_fused.hip", "bneck2.hip", "gemm_k256.hip", "gemm_small.hip", "msda.hip", "msda_any.hip", "norm.hip", "attn.hip", "elementwise.hip", "topk.hip",
            "detect.hip", "track.hip", "records.hip", "train.hip", "ingest.hip", "swin.hip", "vitae.hip", "attn_flash.hip", "tracker_rt.hip", "stream.hip", "lsa.cpp", "matcher_rt.cpp"]
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
 # device code is built without packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): DESIGN.md,

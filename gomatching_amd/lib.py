@@ -62,6 +62,12 @@ SIGNATURES = {
     "gom_dec_attn_raw_image_bytes": (L, []),
     "gom_dec_attn_raw_image": (I, [P, L, I, P, P, P, L, P]),
     "gom_dec_attn_raw_f32": (I, [P, I, P, F, P, I, P, I, P, I, I, I, I, P, P]),
+    "gom_dec_attn2_image_bytes": (L, [I, I]),
+    "gom_dec_attn2_image": (I, [P, L, I, P, P, P, L, I, P, P, P, P, I, P, L, P]),
+    "gom_dec_attn2_f32": (I, [P, I, P, I, P, F, P, I, I, I, I, I, P, P]),
+    "gom_dec_attn2_raw_image_bytes": (L, []),
+    "gom_dec_attn2_raw_image": (I, [P, L, I, P, P, P, L, P]),
+    "gom_dec_attn2_raw_f32": (I, [P, I, P, F, P, I, P, I, P, I, I, I, I, P, P]),
     "gom_dec_inter_heads_f32": (I, [P, I, P, P, I, I, I, I, P, P]),
     "gom_proj_ln_image_bytes": (L, [I, I]),
     "gom_proj_ln_image": (I, [P, L, I, I, I, P, L, P]),

@@ -677,9 +677,11 @@ class DecAttnBlock:
     out_proj.weight [256, 256] in the kernel's stage order + what its epilogue needs.  `inter`: attention over the queries of a
     (frame, point) (deformable_transformer.py:396-404) instead of over the points of a query (:386-394)."""
 
-    def __init__(self, in_w, in_b, out_w, out_b, gamma, beta, inter, eps=1e-5, raw=None):
+    def __init__(self, in_w, in_b, out_w, out_b, gamma, beta, inter, eps=1e-5, raw=None, form=None):
         """raw = (weight [384, 256] as a SplitWeight or fp32 tensor, bias [384]) of the cross attention's sampling_offsets |
-        attention_weights layers: an inter block then also serves `dec_attn(..., raw_pos=query_pos)`."""
+        attention_weights layers: an inter block then also serves `dec_attn(..., raw_pos=query_pos)`.  form 2 (default, `DEC_ATTN2`):
+        16-token waves, two per SIMD (csrc/dec_attn2.hip); the form-1 image is kept beside it (dec_inter_heads reads its stages)."""
+        self.form = form if form is not None else (2 if DEC_ATTN2 else 1)
         assert tuple(in_w.shape) == (768, 256) and tuple(out_w.shape) == (256, 256)
         nbytes = _L().gom_dec_attn_image_bytes(256, 8)
         if nbytes < 0:
@@ -703,9 +705,19 @@ class DecAttnBlock:
             _chk_f32(raw[1])
             check(_L().gom_dec_attn_raw_image(_p(sr.planes), sr.planes.stride(0), sr.planes.stride(1), _p(sr.inv_scale), _p(raw[1]),
                                               _p(self.image), nbytes, _stream()), "gom_dec_attn_raw_image")
+        if self.form == 2:
+            n2 = _L().gom_dec_attn2_raw_image_bytes() if raw is not None else _L().gom_dec_attn2_image_bytes(256, 8)
+            self.image2 = torch.empty((n2,), dtype=torch.uint8, device=si.planes.device)
+            check(_L().gom_dec_attn2_image(_p(pi), pi.stride(0), pi.stride(1), _p(si.inv_scale), _p(in_b), _p(po), po.stride(0),
+                                           po.stride(1), _p(so.inv_scale), _p(out_b), _p(gamma), _p(beta), 1 if inter else 0,
+                                           _p(self.image2), n2, _stream()), "gom_dec_attn2_image")
+            if raw is not None:
+                check(_L().gom_dec_attn2_raw_image(_p(sr.planes), sr.planes.stride(0), sr.planes.stride(1), _p(sr.inv_scale), _p(raw[1]),
+                                                   _p(self.image2), n2, _stream()), "gom_dec_attn2_raw_image")
 
 
 DEC_ATTN_RAW = _switch("DEC_ATTN_RAW")      # the inter block's launch also makes the cross attention's offsets | logits
+DEC_ATTN2 = _switch("DEC_ATTN2")            # the two blocks on 16-token waves, two per SIMD (csrc/dec_attn2.hip, round 6)
 
 
 def dec_attn_block(in_w, in_b, out_pair, norm, inter, raw=None):
@@ -739,9 +751,10 @@ def dec_attn(x, blk, groups, group_tokens, inner=1, pos=None, out=None, raw_pos=
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        check(_L().gom_dec_attn_raw_f32(_p(x), x.stride(0) if rows > 1 else 256, _p(blk.image), blk.eps, _p(out),
-                                        out.stride(0) if rows > 1 else 256, _p(raw_pos), raw_pos.stride(0) if rows > 1 else 256,
-                                        _p(raw), 384, groups, group_tokens, inner, _p(range_flag(x.device)), _stream()),
+        fn, img = (_L().gom_dec_attn2_raw_f32, blk.image2) if blk.form == 2 else (_L().gom_dec_attn_raw_f32, blk.image)
+        check(fn(_p(x), x.stride(0) if rows > 1 else 256, _p(img), blk.eps, _p(out),
+                 out.stride(0) if rows > 1 else 256, _p(raw_pos), raw_pos.stride(0) if rows > 1 else 256,
+                 _p(raw), 384, groups, group_tokens, inner, _p(range_flag(x.device)), _stream()),
               "gom_dec_attn_raw_f32")
         if prof is not None:
             e1.record()
@@ -759,11 +772,11 @@ def dec_attn(x, blk, groups, group_tokens, inner=1, pos=None, out=None, raw_pos=
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_L().gom_dec_attn_f32(_p(x), x.stride(0) if x.shape[0] > 1 else 256, _p(pos),
-                                (pos.stride(0) if pos.shape[0] > 1 else 256) if pos is not None else 0, _p(blk.image),
-                                blk.eps, _p(out),
-                                out.stride(0) if out.shape[0] > 1 else 256, groups, group_tokens, inner,
-                                1 if blk.inter else 0, _p(range_flag(x.device)), _stream()), "gom_dec_attn_f32")
+    fn, img = (_L().gom_dec_attn2_f32, blk.image2) if blk.form == 2 else (_L().gom_dec_attn_f32, blk.image)
+    check(fn(_p(x), x.stride(0) if x.shape[0] > 1 else 256, _p(pos),
+             (pos.stride(0) if pos.shape[0] > 1 else 256) if pos is not None else 0, _p(img), blk.eps, _p(out),
+             out.stride(0) if out.shape[0] > 1 else 256, groups, group_tokens, inner,
+             1 if blk.inter else 0, _p(range_flag(x.device)), _stream()), "gom_dec_attn_f32")
     if prof is not None:
         e1.record()
         # the block's nn.Linear products (in_proj 768 + out_proj 256 columns) + QK^T and PV of every head

@@ -260,6 +260,23 @@ int gom_dec_attn_raw_image(const void* raw_planes, long raw_plane_stride, int ld
 int gom_dec_attn_raw_f32(const float* X, int ldx, const void* image, float eps, float* Y, int ldy, const float* P2, int ldp2,
                          float* raw, int ldraw, int groups, int group_tokens, int inner, int* flag, void* stream);
 
+/* The same two blocks and the same contract on 16-token waves, two per SIMD (csrc/dec_attn2.hip, round 6): eight waves per workgroup
+ * on v_mfma_f32_16x16x32_f16 sharing one weight ring, an attention group spread over a pair of waves (inter = 0) or all eight
+ * (inter = 1) that exchange a head's K / V fragments through LDS.  Arguments as the gom_dec_attn_* entry of the same name; the images
+ * differ (16x16x32 fragment order, the epilogue vectors in front) and are NOT interchangeable with gom_dec_attn_image's. */
+long gom_dec_attn2_image_bytes(int d_model, int heads);
+int gom_dec_attn2_image(const void* in_planes, long in_plane_stride, int ld_in, const float* in_inv_scale, const float* in_bias,
+                        const void* out_planes, long out_plane_stride, int ld_out, const float* out_inv_scale,
+                        const float* out_bias, const float* gamma, const float* beta, int inter, void* image, long image_bytes,
+                        void* stream);
+int gom_dec_attn2_f32(const float* X, int ldx, const float* P, int ldp, const void* image, float eps, float* Y, int ldy, int groups,
+                      int group_tokens, int inner, int inter, int* flag, void* stream);
+long gom_dec_attn2_raw_image_bytes(void);
+int gom_dec_attn2_raw_image(const void* raw_planes, long raw_plane_stride, int ld_raw, const float* raw_inv_scale,
+                            const float* raw_bias, void* image, long image_bytes, void* stream);
+int gom_dec_attn2_raw_f32(const float* X, int ldx, const void* image, float eps, float* Y, int ldy, const float* P2, int ldp2,
+                          float* raw, int ldraw, int groups, int group_tokens, int inner, int* flag, void* stream);
+
 /* The inter-instance attention (deformable_transformer.py:396-404) for MORE than 128 queries per frame (GoMatching_PP_DSText.yaml:
  * 300), csrc/dec_inter.hip: in_proj + the 8 x 32 attention core, one workgroup per (group, head) with the head's K / V^T of all
  * `group_tokens` <= 352 tokens in LDS and an online softmax over the key blocks:

@@ -41,19 +41,23 @@ def _ref(x, pos, w, groups):
     return out
 
 
-def _block(ops, w, inter):
+FORMS = [1, 2]                                                   # csrc/dec_attn.hip | csrc/dec_attn2.hip (16-token waves, two per SIMD)
+
+
+def _block(ops, w, inter, form=None):
     d = [t.to(DEV) for t in w]
-    return ops.DecAttnBlock(d[0], d[1], d[2], d[3], d[4], d[5], inter)
+    return ops.DecAttnBlock(d[0], d[1], d[2], d[3], d[4], d[5], inter, form=form)
 
 
-@pytest.mark.parametrize("groups,G", [(1, 25), (4, 25), (37, 25), (800, 25), (5, 32), (9, 3), (6, 1)])
-def test_intra_block(groups, G):
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("groups,G", [(1, 25), (4, 25), (37, 25), (800, 25), (5, 32), (9, 3), (6, 1), (3, 16), (7, 17)])
+def test_intra_block(groups, G, form):
     from gomatching_amd import ops
     g = torch.Generator().manual_seed(groups * 31 + G)
     w = _weights(1)
     rows = groups * G
     x, pos = torch.randn(rows, 256, generator=g), torch.randn(rows, 256, generator=g) * 0.7
-    blk = _block(ops, w, False)
+    blk = _block(ops, w, False, form)
     out = torch.full((rows + 3, 256), 7.0, device=DEV)
     xd = torch.cat([x, torch.zeros(3, 256)]).to(DEV)
     pd = torch.cat([pos, torch.zeros(3, 256)]).to(DEV)
@@ -65,14 +69,15 @@ def test_intra_block(groups, G):
     ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
 
 
-@pytest.mark.parametrize("B,nq,P", [(1, 100, 25), (2, 12, 25), (8, 100, 25), (1, 128, 3), (3, 7, 2), (2, 1, 5), (1, 97, 1)])
-def test_inter_block(B, nq, P):
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("B,nq,P", [(1, 100, 25), (2, 12, 25), (8, 100, 25), (1, 128, 3), (3, 7, 2), (2, 1, 5), (1, 97, 1), (1, 121, 2)])
+def test_inter_block(B, nq, P, form):
     from gomatching_amd import ops
     g = torch.Generator().manual_seed(B * 131 + nq * 7 + P)
     w = _weights(2)
     rows = B * nq * P
     x = torch.randn(rows, 256, generator=g)
-    blk = _block(ops, w, True)
+    blk = _block(ops, w, True, form)
     out = torch.full((rows, 256), 7.0, device=DEV)
     ops.dec_attn(x.to(DEV), blk, B * P, nq, inner=P, out=out)
     idx = torch.arange(rows).view(B, nq, P).permute(0, 2, 1).reshape(B * P, nq)
@@ -118,29 +123,31 @@ def test_inter_block_more_than_128_queries(B, nq, P):
             ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
 
 
-def test_blocks_raise_the_range_flag():
+@pytest.mark.parametrize("form", FORMS)
+def test_blocks_raise_the_range_flag(form):
     from gomatching_amd import ops
     dev = torch.device(DEV, torch.cuda.current_device())
     w = _weights(3)
     ops.check_range_flag(dev)
     x = torch.randn(100, 256, device=DEV)
     x[37, 5] = 7e4
-    ops.dec_attn(x, _block(ops, w, False), 4, 25, pos=torch.zeros_like(x))
+    ops.dec_attn(x, _block(ops, w, False, form), 4, 25, pos=torch.zeros_like(x))
     with pytest.raises(Exception, match="fp16's range"):
         ops.check_range_flag(dev)
-    ops.dec_attn(x, _block(ops, w, True), 4, 25, inner=1)
+    ops.dec_attn(x, _block(ops, w, True, form), 4, 25, inner=1)
     with pytest.raises(Exception, match="fp16's range"):
         ops.check_range_flag(dev)
     big = list(w)
     big[0] = w[0].clone()
     big[0][300] *= 1e6                                               # one k feature beyond fp16 after the projection
-    ops.dec_attn(torch.randn(100, 256, device=DEV), _block(ops, big, True), 4, 25, inner=1)
+    ops.dec_attn(torch.randn(100, 256, device=DEV), _block(ops, big, True, form), 4, 25, inner=1)
     with pytest.raises(Exception, match="fp16's range"):
         ops.check_range_flag(dev)
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("B,nq,P", [(1, 100, 25), (8, 100, 25), (2, 12, 25), (1, 128, 3), (3, 7, 2), (1, 97, 1)])
-def test_inter_block_with_offsets_and_logits_behind_it(B, nq, P):
+def test_inter_block_with_offsets_and_logits_behind_it(B, nq, P, form):
     """The RAW form: the inter block's launch also makes the cross attention's sampling_offsets | attention_weights product,
     raw = (out + query_pos) Wraw^T + braw (ms_deform_attn.py:117-131 on query = tgt + query_pos).  `out` must be the plain
     form's bits; raw against float64 and against the row-resident GEMM launch it replaces."""
@@ -152,8 +159,8 @@ def test_inter_block_with_offsets_and_logits_behind_it(B, nq, P):
     rw = torch.randn(384, 256, generator=g) / 16 * torch.logspace(-1, 1, 384).view(-1, 1) ** 0.3
     rb = torch.randn(384, generator=g) * 0.1
     d = [t.to(DEV) for t in w]
-    blk = ops.DecAttnBlock(d[0], d[1], d[2], d[3], d[4], d[5], True, raw=(rw.to(DEV), rb.to(DEV)))
-    plain = _block(ops, w, True)
+    blk = ops.DecAttnBlock(d[0], d[1], d[2], d[3], d[4], d[5], True, raw=(rw.to(DEV), rb.to(DEV)), form=form)
+    plain = _block(ops, w, True, form)
     xd, qd = x.to(DEV), qpos.to(DEV)
     out, raw = ops.dec_attn(xd, blk, B * P, nq, inner=P, raw_pos=qd)
     want = ops.dec_attn(xd, plain, B * P, nq, inner=P)

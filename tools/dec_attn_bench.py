@@ -22,7 +22,12 @@ wi = ops.split_weight(in_w, kind="f16x3")
 wo = ops.split_weight(out_w, kind="f16x3")
 qk, v_, qkv = ops.K256Linear(wi[:512], in_b[:512]), ops.K256Linear(wi[512:], in_b[512:]), ops.k256_linear(wi, in_b)
 pl = ops.ProjLN(wo, out_b, gamma, beta)
-intra, inter = ops.DecAttnBlock(wi, in_b, wo, out_b, gamma, beta, False), ops.DecAttnBlock(wi, in_b, wo, out_b, gamma, beta, True)
+intra, inter = ops.DecAttnBlock(wi, in_b, wo, out_b, gamma, beta, False, form=1), ops.DecAttnBlock(wi, in_b, wo, out_b, gamma, beta, True, form=1)
+intra2, inter2 = ops.DecAttnBlock(wi, in_b, wo, out_b, gamma, beta, False, form=2), ops.DecAttnBlock(wi, in_b, wo, out_b, gamma, beta, True, form=2)
+rw = ops.split_weight((torch.randn(384, 256, generator=g) / 16).to(DEV), kind="f16x3")
+rb = (torch.randn(384, generator=g) * 0.1).to(DEV)
+raw1 = ops.DecAttnBlock(wi, in_b, wo, out_b, gamma, beta, True, raw=(rw, rb), form=1)
+raw2 = ops.DecAttnBlock(wi, in_b, wo, out_b, gamma, beta, True, raw=(rw, rb), form=2)
 attn = torch.empty((Q, E), device=DEV)
 
 
@@ -50,6 +55,14 @@ def new_inter():
     return ops.dec_attn(x, inter, B * P, nq, inner=P)
 
 
+def new_intra2():
+    return ops.dec_attn(x, intra2, B * nq, P, pos=pos)
+
+
+def new_inter2():
+    return ops.dec_attn(x, inter2, B * P, nq, inner=P)
+
+
 def timeit(fn, n=30):
     for _ in range(3):
         fn()
@@ -68,5 +81,11 @@ print("max |fused - unfused| intra %.2e inter %.2e" % (float((new_intra() - old_
 for rnd in range(3):
     print("round %d: intra unfused %.1f us fused %.1f us | inter unfused %.1f us fused %.1f us" % (
         rnd, timeit(old_intra), timeit(new_intra), timeit(old_inter), timeit(new_inter)))
+print("form 2 (16-token waves, two per SIMD): max |form 2 - form 1| intra %.2e inter %.2e" % (
+    float((new_intra2() - new_intra()).abs().max()), float((new_inter2() - new_inter()).abs().max())))
+for rnd in range(3):
+    print("round %d: intra form 1 %.1f us form 2 %.1f us | inter %.1f / %.1f us | inter + raw %.1f / %.1f us" % (
+        rnd, timeit(new_intra), timeit(new_intra2), timeit(new_inter), timeit(new_inter2),
+        timeit(lambda: ops.dec_attn(x, raw1, B * P, nq, inner=P, raw_pos=pos)), timeit(lambda: ops.dec_attn(x, raw2, B * P, nq, inner=P, raw_pos=pos))))
 fl = 2.0 * Q * 256 * 1024
 print("fused intra: %.0f TFLOP/s of nn.Linear products; inter: %.0f" % (fl / timeit(new_intra) / 1e6, fl / timeit(new_inter) / 1e6))
