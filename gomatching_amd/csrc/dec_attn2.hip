@@ -71,6 +71,36 @@ __device__ __forceinline__ void dma_fragment(__amdgpu_buffer_rsrc_t rs, unsigned
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_frag, 16, (int)lane_off, (int)frag_off, 0, 0);
 }
 
+// -DA2_STAMPS (tools/dec_attn2_variants.py only): s_memtime between the phases of every wave, summed per kind into a buffer set by
+// gom_dec_attn2_set_stamps -- [workgroup][wave][8] cycles: prologue, stage products, stage epilogues (+ exchange writes, stores),
+// end-of-stage waits + barriers, attention, the intra form's row reload, residual + LayerNorm, total
+#ifdef A2_STAMPS
+__device__ unsigned long long* g_a2_stamps = nullptr;
+__device__ __forceinline__ unsigned long long a2_clock() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define A2_T(k)                                                        \
+    {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        const unsigned long long n_ = a2_clock();                      \
+        a2_b[k] += n_ - a2_last;                                       \
+        a2_last = n_;                                                  \
+        __builtin_amdgcn_sched_barrier(0);                             \
+    }
+#else
+#define A2_T(k)
+#endif
+
+// exp2(x) where the lane's bit of `mask` (wave-uniform, in SGPRs) is set, else 0.  One asm block: the compiler's hazard recognizer
+// does not look inside inline asm, and a VALU instruction must not read a transcendental's result in the very next slot (s_nop).
+__device__ __forceinline__ float exp2_if(const float x, const unsigned long long mask) {
+    float r;
+    asm("v_exp_f32 %0, %1\n\ts_nop 0\n\tv_cndmask_b32 %0, 0, %0, %2" : "=&v"(r) : "v"(x), "s"(mask));
+    return r;
+}
+
 // four fp32 values -> their fp16 planes: {hi01, hi23} and {lo01, lo23}
 __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
     unsigned h0, l0, h1, l1;
@@ -80,12 +110,48 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
     lo = u32x2{l0, l1};
 }
 
-// a wave's 16 rows x 256 fp32 -> xf[plane][k-step]: lane (n = lane & 15, kg = lane >> 4) ends up with floats 32 s + 8 kg .. + 7 of
-// row n.  Whole-line loads (a wave-instruction = 64 floats of four rows) + a layout change in a wave-private 4 KB scratch
-// (common.h gom_rows_to_fragments, for one 16-row group).
-template <bool ADD, typename FA, typename FB, typename FH>
-__device__ __forceinline__ void rows16_to_fragments(FA row_a, FB row_b, float* scratch, int lane, half8 (&xf)[2][8], float& amax,
-                                                    FH after_first_loads) {
+// A wave's 16 rows x 256 fp32 in FRAGMENT order: consume(s, a, b) receives, for every 32-wide k-step s, lane (n = lane & 15, kg =
+// lane >> 4)'s floats 32 s + 8 kg .. + 3 (a) and .. + 4 .. + 7 (b) of row n.  Whole-line loads (a wave-instruction = 64 floats of four
+// rows: 8 lines, where the fragment layout straight from memory would touch 16 -- the texture-address unit pays per line, LAB_NOTES) and
+// a layout change in a wave-private 4 KB scratch, 16-byte pieces XOR-swizzled by the row (common.h gom_rows_to_fragments for one
+// 16-row group).  ALL loads are issued before the first exchange: their latency is paid once.  ADD: the rows are row_a + row_b.
+template <typename FA>
+__device__ __forceinline__ void rows16_load(FA row_a, int lane, f32x4 (&v)[4][4]) {
+    const int pc = lane & 15, r0 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float* ra = row_a(r0 + 4 * i) + pc * 4;
+#pragma unroll
+        for (int part = 0; part < 4; ++part) v[part][i] = *reinterpret_cast<const f32x4*>(ra + part * 64);
+    }
+}
+template <typename FC>
+__device__ __forceinline__ void rows16_exchange(const f32x4 (&v)[4][4], float* scratch, int lane, FC consume) {
+    const int pc = lane & 15, r0 = lane >> 4;
+    const int fn = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 4 * i;
+            *reinterpret_cast<f32x4*>(scratch + r * 64 + ((pc ^ (r & 15)) << 2)) = v[part][i];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int p0 = 8 * s + 2 * fg;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(scratch + fn * 64 + ((p0 ^ fn) << 2));
+            const f32x4 b = *reinterpret_cast<const f32x4*>(scratch + fn * 64 + (((p0 + 1) ^ fn) << 2));
+            consume(2 * part + s, a, b);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// the rows (ADD: row_a + row_b), one 64-float part at a time (measured against two parts in flight, and against all sixteen loads up
+// front: 9.7k cycles for the intra form's reload against 13.6k -- the texture-address unit, not the latency, bounds eight waves
+// loading at once)
+template <bool ADD, typename FA, typename FB, typename FH, typename FC>
+__device__ __forceinline__ void rows16_stream(FA row_a, FB row_b, float* scratch, int lane, FH after_loads, FC consume) {
     const int pc = lane & 15, r0 = lane >> 4;
     const int fn = lane & 15, fg = lane >> 4;
 #pragma unroll
@@ -99,7 +165,7 @@ __device__ __forceinline__ void rows16_to_fragments(FA row_a, FB row_b, float* s
         }
         if (part == 0) {
             __builtin_amdgcn_sched_barrier(0);
-            after_first_loads();
+            after_loads();
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -113,12 +179,21 @@ __device__ __forceinline__ void rows16_to_fragments(FA row_a, FB row_b, float* s
             const int p0 = 8 * s + 2 * fg;
             const f32x4 a = *reinterpret_cast<const f32x4*>(scratch + fn * 64 + ((p0 ^ fn) << 2));
             const f32x4 b = *reinterpret_cast<const f32x4*>(scratch + fn * 64 + (((p0 + 1) ^ fn) << 2));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(a[e]), fabsf(b[e])));
-            gom_split8_f16(a, b, xf[0][2 * part + s], xf[1][2 * part + s]);
+            consume(2 * part + s, a, b);
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// ... as the two fp16 planes of the wave's MFMA operand fragments, xf[plane][k-step]
+template <bool ADD, typename FA, typename FB, typename FH>
+__device__ __forceinline__ void rows16_to_fragments(FA row_a, FB row_b, float* scratch, int lane, half8 (&xf)[2][8], float& amax,
+                                                    FH after_loads) {
+    rows16_stream<ADD>(row_a, row_b, scratch, lane, after_loads, [&](const int s, const f32x4 a, const f32x4 b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(a[e]), fabsf(b[e])));
+        gom_split8_f16(a, b, xf[0][s], xf[1][s]);
+    });
     asm volatile("" : "+v"(amax));
 }
 
@@ -150,6 +225,7 @@ __device__ __forceinline__ void rows16_to_fragments(FA row_a, FB row_b, float* s
         A2_LOAD(fa, 6) MFMA(fb, 5) A2_PIN0()                                                                  \
         A2_LOAD(fb, 7) MFMA(fa, 6) A2_DMA(3) A2_PIN()                                                         \
         MFMA(fb, 7)                                                                                           \
+        A2_T(1)                                                                                               \
     }
 #define A2_STAGE_LAST(MFMA)                                                                                   \
     {                                                                                                         \
@@ -164,6 +240,7 @@ __device__ __forceinline__ void rows16_to_fragments(FA row_a, FB row_b, float* s
         A2_LOAD(fa, 6) MFMA(fb, 5) A2_PIN0()                                                                  \
         A2_LOAD(fb, 7) MFMA(fa, 6) A2_PIN0()                                                                  \
         MFMA(fb, 7)                                                                                           \
+        A2_T(1)                                                                                               \
     }
 // fragment 2 Hh + p of a group = plane p of feature tile Hh at k-step g
 // transposed: acc[Hh][feature 16 Hh + 4 rg + e][token] += W . X^T   (A = weight fragment, B = the rows)
@@ -194,12 +271,17 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fn = lane & 15, fg = lane >> 4;
     const int b0 = INTER ? 0 : (wave & ~1);                  // first key block of this wave's attention group
+#ifdef A2_STAMPS
+    unsigned long long a2_b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long a2_t0 = a2_clock();
+    unsigned long long a2_last = a2_t0;
+#endif
     const int t0 = b0 >> 1;                                  // and its first V k-step
 
     // ---- token slot r (0..15) of this wave -> its row; slots beyond the group's tokens recompute token 0 (masked as keys, never stored)
     long gbase, gstep;                                       // row of token tq = gbase + tq * gstep
     int first, mine;                                         // this wave's first token and its token count
-    int ntok[NB];
+    int n_full, tok_full, tok_last;                          // key blocks 0 .. n_full - 1 hold tok_full tokens, block n_full tok_last, the rest none
     if constexpr (!INTER) {
         const long gi = (long)blockIdx.x * 4 + (wave >> 1);
         const long g = gi < p.groups ? gi : p.groups - 1;
@@ -208,21 +290,26 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
         first = (wave & 1) * 16;
         const int left = p.G - first;
         mine = gi < p.groups ? (left < 0 ? 0 : (left < 16 ? left : 16)) : 0;
-        ntok[0] = p.G < 16 ? p.G : 16;
-        ntok[1] = p.G > 16 ? p.G - 16 : 0;
+        n_full = 1;
+        tok_full = p.G < 16 ? p.G : 16;
+        tok_last = p.G > 16 ? p.G - 16 : 0;
     } else {
         const long gi = blockIdx.x;
         const long b = gi / p.inner, pp = gi % p.inner;
         gbase = b * p.G * p.inner + pp;
         gstep = p.inner;
         first = wave * p.per_wave;
-#pragma unroll
-        for (int w = 0; w < NB; ++w) {
-            const int left = p.G - w * p.per_wave;
-            ntok[w] = left < 0 ? 0 : (left < p.per_wave ? left : p.per_wave);
-        }
         const int left = p.G - first;
         mine = left < 0 ? 0 : (left < p.per_wave ? left : p.per_wave);
+        n_full = p.G / p.per_wave;
+        tok_full = p.per_wave;
+        tok_last = p.G - n_full * p.per_wave;
+    }
+    unsigned long long m_full[4], m_last[4];                 // lanes whose key slot 4 fg + e is a token, per kind of block
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        m_full[e] = __builtin_amdgcn_ballot_w64(4 * fg + e < tok_full);
+        m_last[e] = __builtin_amdgcn_ballot_w64(4 * fg + e < tok_last);
     }
     auto slot_row = [&](int r) -> long { return gbase + (r < mine ? (long)(first + r) : 0L) * gstep; };
     const bool valid = fn < mine;
@@ -246,6 +333,7 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    A2_T(0)
 
 #define A2_STAGE_VARS(i)                                                                                      \
     const unsigned char* base = smem + ((i) % SLOTS) * CHUNK_BYTES + lane * 16;                               \
@@ -258,14 +346,18 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
     // end of a stage: everything older than this stage's four (wave 0: five) requests has landed (= stage i + 1, requested a stage
     // ago; loads return in issue order); the LDS writes of the exchange are covered by the barrier's fence
 #define A2_STAGE_END()                                                                                        \
+    A2_T(2)                                                                                                   \
     if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                           \
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                     \
     __syncthreads();                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    A2_T(3)
 #define A2_STAGE_END_ALL()                                                                                    \
+    A2_T(2)                                                                                                   \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
     __syncthreads();                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    A2_T(3)
 
     // transposed stage epilogue: value = acc * (1 / row scale) + bias of features 16 Hh + 4 fg + e
     auto finish_t = [&](f32x4 (&acc)[2], const float* aux) {
@@ -335,25 +427,39 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
 #pragma unroll
             for (int b = 0; b < KB; ++b) s[bb + b] = mfma16(k_hi[b], q_hi, s[bb + b]);
         }
-        // softmax(scale * S^T) over the keys: lane (query, fg) holds keys 4 fg + e of every block
-        float mx = -INFINITY;
+        // the first k-step's V fragments: on their way under the softmax
+        half8 v[4];
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const half8*>(xch_v + (t0 * 4 + i) * FRAG + lane * 16);
+        // softmax over the keys: lane (query, fg) holds keys 4 fg + e of every block, already x scale x log2(e) (folded into q's
+        // stage vectors by the image).  The maximum runs over EVERY slot: a padded slot recomputes a token of the group, so its score
+        // is one of the valid ones; the probabilities of padded slots are cleared by lane masks made once per kernel.  (Reductions
+        // as trees: the compiler keeps the order it is given, and 32 dependent fmaxf / adds are 32 issue latencies.)
+        float mb[NB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[b][e] = 4 * fg + e < ntok[b] ? s[b][e] * p.scale : -INFINITY;
-                mx = fmaxf(mx, s[b][e]);
-            }
+        for (int b = 0; b < NB; ++b) mb[b] = fmaxf(fmaxf(s[b][0], s[b][1]), fmaxf(s[b][2], s[b][3]));
+#pragma unroll
+        for (int w = 1; w < NB; w *= 2)
+#pragma unroll
+            for (int b = 0; b + w < NB; b += 2 * w) mb[b] = fmaxf(mb[b], mb[b + w]);
+        float mx = mb[0];
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
+        float sb[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                s[b][e] = __expf(s[b][e] - mx);
-                sum += s[b][e];
+                const unsigned long long km = b < n_full ? m_full[e] : (b == n_full ? m_last[e] : 0ull);
+                s[b][e] = exp2_if(s[b][e] - mx, km);
             }
+            sb[b] = (s[b][0] + s[b][1]) + (s[b][2] + s[b][3]);
+        }
+#pragma unroll
+        for (int w = 1; w < NB; w *= 2)
+#pragma unroll
+            for (int b = 0; b + w < NB; b += 2 * w) sb[b] += sb[b + w];
+        float sum = sb[0];
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
@@ -362,15 +468,21 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
         for (int t = 0; t < NB / 2; ++t) {
             half8 p_hi, p_lo;
             gom_split8_f16(s[2 * t], s[2 * t + 1], p_hi, p_lo);
-            half8 v[4];
+            half8 vn[4];
+            if (t + 1 < NB / 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const half8*>(xch_v + ((t0 + t) * 4 + i) * FRAG + lane * 16);
+                for (int i = 0; i < 4; ++i) vn[i] = *reinterpret_cast<const half8*>(xch_v + ((t0 + t + 1) * 4 + i) * FRAG + lane * 16);
+            }
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) o[hh] = mfma16(v[2 * hh + 1], p_hi, o[hh]);
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) o[hh] = mfma16(v[2 * hh], p_lo, o[hh]);
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) o[hh] = mfma16(v[2 * hh], p_hi, o[hh]);
+            if (t + 1 < NB / 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = vn[i];
+            }
         }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
@@ -386,6 +498,24 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
         vo[h][1] = __builtin_bit_cast(u32x4, o_lo);
     };
 
+    // Head h's attention needs the K / V fragments of the stage(s) just ended and must be over before the NEXT head's k stage writes the
+    // exchange again: it runs at the head of the interval of the stage that follows (the next head's q stage, or the first out_proj
+    // stage).  (Measured and dropped: the waves 4..7 -- which share their SIMDs with the waves 0..3 -- running it BEHIND that stage's
+    // products instead, so that one wave's softmax runs under the other's MFMAs: inter 127.6k -> 132.2k cycles.  A head's attention is
+    // a LATENCY chain -- exchange reads, dependent MFMAs, two cross-lane reductions, exp, splits: ~4k cycles per wave whether or not
+    // the SIMD's other wave is in it too -- and two of them overlap each other better than one overlaps 768 cycles of MFMAs.)
+    constexpr bool early = true;
+    half8 qp_hi, qp_lo;                                      // q of the head whose attention is pending
+#define A2_ATTEND_EARLY(h)                                                                                    \
+    if ((h) >= 0 && early) {                                                                                  \
+        attend(qp_hi, qp_lo, (h));                                                                            \
+        A2_T(4)                                                                                               \
+    }
+#define A2_ATTEND_LATE(h)                                                                                     \
+    if ((h) >= 0 && !early) {                                                                                 \
+        attend(qp_hi, qp_lo, (h));                                                                            \
+        A2_T(4)                                                                                               \
+    }
     if constexpr (!INTER) {
         // ---- sweep 1: V of every head (stages 0 .. 7), this wave's halves parked in vo[h] until the head's attention ----
 #pragma unroll
@@ -411,15 +541,17 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
         }
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
+        A2_T(5)
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            half8 q_hi, q_lo;
             {
+                A2_ATTEND_EARLY(h - 1)
                 A2_STAGE_VARS(NH + 2 * h)
                 f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
                 A2_STAGE(A2_MFMA_T)
+                A2_ATTEND_LATE(h - 1)
                 finish_t(acc, aux);
-                gom_split8_f16(acc[0], acc[1], q_hi, q_lo);
+                gom_split8_f16(acc[0], acc[1], qp_hi, qp_lo);
                 A2_STAGE_END()
             }
             {
@@ -432,19 +564,19 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
                       u32x2{vo[h][1][2], vo[h][1][3]});
                 A2_STAGE_END()
             }
-            attend(q_hi, q_lo, h);
         }
     } else {
         // ---- per head: q, k, v of tgt (stages 3 h, 3 h + 1, 3 h + 2) ----
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            half8 q_hi, q_lo;
             {
+                A2_ATTEND_EARLY(h - 1)
                 A2_STAGE_VARS(3 * h)
                 f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
                 A2_STAGE(A2_MFMA_T)
+                A2_ATTEND_LATE(h - 1)
                 finish_t(acc, aux);
-                gom_split8_f16(acc[0], acc[1], q_hi, q_lo);
+                gom_split8_f16(acc[0], acc[1], qp_hi, qp_lo);
                 A2_STAGE_END()
             }
             {
@@ -466,23 +598,31 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
                 put_v(hi0, lo0, hi1, lo1);
                 A2_STAGE_END()
             }
-            attend(q_hi, q_lo, h);
         }
     }
 
-    // ---- out_proj: Y^T[256 x tokens] += Wo[:, head h's features] . O_h^T, eight stages ----
+    // ---- out_proj: Y^T[256 x tokens] += Wo[:, head h's features] . O_h^T, eight stages.  Its image orders the output rows so that
+    // lane (token, fg) holds features 32 s + 8 fg .. + 7 of its token in yacc[2 s], yacc[2 s + 1] -- the FRAGMENT order of the rows:
+    // the residual rows (and the RAW form's query_pos) then arrive as WHOLE lines through the exchange area, idle since the last head's
+    // attention (8 lines per wave-instruction where the accumulator layout straight from memory touches 16); they are requested in
+    // front of the last stage (the heads' fragments are dead by then: their registers) ----
     f32x4 yacc[D / 16];
 #pragma unroll
     for (int t = 0; t < D / 16; ++t) yacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* rr = p.X + (size_t)row * p.ldx + 4 * fg;
-    f32x4 res[8];
+    f32x4 rv[4][4];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const half8 o_hi = __builtin_bit_cast(half8, vo[h][0]), o_lo = __builtin_bit_cast(half8, vo[h][1]);
+        if (h == NH - 1) {
+            rows16_load(xrow, lane, rv);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (RAW || h < NH - 2) {
+            if (h == 0) { A2_ATTEND_EARLY(NH - 1) }
             A2_STAGE_VARS(3 * NH + h)
             (void)aux;
             A2_STAGE(A2_MFMA_O)
+            if (h == 0) { A2_ATTEND_LATE(NH - 1) }
             A2_STAGE_END()
         } else {
             const unsigned char* base = smem + ((3 * NH + h) % SLOTS) * CHUNK_BYTES + lane * 16;
@@ -491,30 +631,32 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
         }
     }
 
-    // ---- residual + LayerNorm in registers: lane (token, fg) holds features 16 t + 4 fg .. + 3 of its token ----
+    // ---- residual + LayerNorm in registers (lane (token, fg): features 32 s + 8 fg .. + 7 in yacc[2 s], yacc[2 s + 1]) ----
+    __builtin_amdgcn_sched_barrier(0);
     {
-        const float* v_inv = vecs;
-        const float* v_bias = vecs + 256;
-        const float* v_gamma = vecs + 512;
-        const float* v_beta = vecs + 768;
+        const float* v_inv = vecs + 8 * fg;
+        const float* v_bias = vecs + 256 + 8 * fg;
+        const float* v_gamma = vecs + 512 + 8 * fg;
+        const float* v_beta = vecs + 768 + 8 * fg;
+        float* scratch = reinterpret_cast<float*>(xch_k) + wave * (16 * 64);
         float sum = 0.f;
+        rows16_exchange(rv, scratch, lane, [&](const int s2, const f32x4 a, const f32x4 b) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) res[i] = *reinterpret_cast<const f32x4*>(rr + 16 * i);
-        f32x4 res2[8];
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(v_inv + 32 * s2 + 4 * i);
+                const f32x4 bi = *reinterpret_cast<const f32x4*>(v_bias + 32 * s2 + 4 * i);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) res2[i] = *reinterpret_cast<const f32x4*>(rr + 16 * (8 + i));
-#pragma unroll
-        for (int t = 0; t < D / 16; ++t) {
-            const int col = 16 * t + 4 * fg;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(v_inv + col);
-            const f32x4 bi = *reinterpret_cast<const f32x4*>(v_bias + col);
-            const f32x4 r = t < 8 ? res[t & 7] : res2[t & 7];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = fmaf(yacc[t][e], sc[e], bi[e]) + r[e];
-                yacc[t][e] = v;
-                sum += v;
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaf(yacc[2 * s2 + i][e], sc[e], bi[e]) + (i ? b[e] : a[e]);
+                    yacc[2 * s2 + i][e] = v;
+                    sum += v;
+                }
             }
+        });
+        if constexpr (RAW) {
+            __builtin_amdgcn_sched_barrier(0);
+            rows16_load([&](int r) { return p.P2 + (size_t)slot_row(r) * p.ldp2; }, lane, rv);   // query_pos: under the statistics
+            __builtin_amdgcn_sched_barrier(0);
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
@@ -530,38 +672,41 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
         sq += __shfl_xor(sq, 16, 64);
         sq += __shfl_xor(sq, 32, 64);
         const float rstd = rsqrtf(sq * (1.f / D) + p.eps);
-        float* yr = p.Y + (size_t)row * p.ldy + 4 * fg;
-        const float* pr = RAW ? p.P2 + (size_t)row * p.ldp2 + 4 * fg : nullptr;
-#pragma unroll
-        for (int s = 0; s < D / 32; ++s) {
+        float* yr = p.Y + (size_t)row * p.ldy + 8 * fg;
+        // (s2, a, b): the output's features 32 s2 + 8 fg .. + 7; RAW: a | b = query_pos there, and (output + query_pos) becomes k-step s2
+        // of the NEXT product's B operand
+        auto finish = [&](const int s2, const f32x4 a, const f32x4 b) {
             f32x4 x2[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int t = 2 * s + i;
-                const int col = 16 * t + 4 * fg;
-                const f32x4 ga = *reinterpret_cast<const f32x4*>(v_gamma + col);
-                const f32x4 be = *reinterpret_cast<const f32x4*>(v_beta + col);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(v_gamma + 32 * s2 + 4 * i);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(v_beta + 32 * s2 + 4 * i);
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = yacc[t][e] * rstd * ga[e] + be[e];
+                    o[e] = yacc[2 * s2 + i][e] * rstd * ga[e] + be[e];
                     chk = fmaf(o[e], 0.f, chk);
                 }
-                if (valid) *reinterpret_cast<f32x4*>(yr + 16 * t) = o;
+                if (valid) *reinterpret_cast<f32x4*>(yr + 32 * s2 + 4 * i) = o;
                 if constexpr (RAW) {
-                    const f32x4 pq = *reinterpret_cast<const f32x4*>(pr + 16 * t);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        x2[i][e] = o[e] + pq[e];
+                        x2[i][e] = o[e] + (i ? b[e] : a[e]);
                         amax = fmaxf(amax, fabsf(x2[i][e]));
                     }
                 }
             }
-            // RAW: the rows of the NEXT product as B-operand fragments, k-step s = tiles 2 s, 2 s + 1 in accumulator order
-            if constexpr (RAW) gom_split8_f16(x2[0], x2[1], xf[0][s], xf[1][s]);
+            if constexpr (RAW) gom_split8_f16(x2[0], x2[1], xf[0][s2], xf[1][s2]);
+        };
+        if constexpr (RAW) {
+            rows16_exchange(rv, scratch, lane, finish);
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < D / 32; ++s2) finish(s2, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f});
         }
         asm volatile("" : "+v"(chk), "+v"(amax));
     }
+    A2_T(6)
     if constexpr (RAW) {
         // ---- raw = (Y + query_pos) Wraw^T + braw: twelve 32-column stages, transposed (lane = token); a stage's two stores are
         // issued at the START of the next one (then the oldest vector-memory operations of that stage: dec_attn.hip) ----
@@ -614,6 +759,15 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
             for (int hh = 0; hh < 2; ++hh) *reinterpret_cast<f32x4*>(ro + 32 * (RAW_STAGES - 1) + 16 * hh) = pend[hh];
         }
     }
+#ifdef A2_STAMPS
+    A2_T(2)
+    if (g_a2_stamps && lane == 0) {
+        unsigned long long* o = g_a2_stamps + ((size_t)blockIdx.x * WAVES + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) o[i] = a2_b[i];
+        o[7] = a2_last - a2_t0;
+    }
+#endif
     if ((!(amax <= 65504.f) || !(chk == 0.f)) && p.flag) atomicOr(p.flag, 1);
 }
 
@@ -621,8 +775,10 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
 // out_proj's 1 / row scale | bias | gamma | beta (256 floats each).  Stages behind them, in dec_attn.hip's order -- intra: v_0 .. v_7,
 // then (q_h, k_h); inter: (q_h, k_h, v_h); then the eight out_proj stages.  Element j of lane l = (m, kg) = (l & 15, l >> 4):
 //   projection stage, rows row0 .. row0 + 31 of in_proj:  fragment 4 s + 2 Hh + p = plane p of Ws[row0 + 16 Hh + m][32 s + 8 kg + j];
-//                                                         fragment 32: floats 0..31 = 1 / row scale, 32..63 = bias
-//   out_proj stage hd: fragment 2 t + p = plane p of Wo[16 t + m][32 hd + 16 (j >> 2) + 4 kg + (j & 3)]  (O^T's accumulator order)
+//                                                         fragment 32: floats 0..31 = 1 / row scale, 32..63 = bias (q rows: both
+//                                                         x 1 / sqrt(32) x log2(e))
+//   out_proj stage hd: fragment 2 t + p = plane p of Wo[32 (t >> 1) + 8 (m >> 2) + 4 (t & 1) + (m & 3)][32 hd + 16 (j >> 2) + 4 kg + (j & 3)]
+//       (columns: O^T's accumulator order; rows: so that a lane's accumulators of tiles 2 s, 2 s + 1 are features 32 s + 8 rg .. + 7)
 __global__ __launch_bounds__(256) void dec_attn2_image_kernel(const unsigned short* __restrict__ in_planes, long in_stride, int ld_in,
                                                               const float* __restrict__ in_inv, const float* __restrict__ in_bias,
                                                               const unsigned short* __restrict__ out_planes, long out_stride,
@@ -652,10 +808,13 @@ __global__ __launch_bounds__(256) void dec_attn2_image_kernel(const unsigned sho
             const int s = f >> 2, hh = (f >> 1) & 1, pl = f & 1;
             v16 = in_planes[pl * in_stride + (size_t)(row0 + 16 * hh + m) * ld_in + 32 * s + 8 * kg + j];
         } else {
+            // (q stages: x 1 / sqrt(32) x log2(e) -- the scores leave the MFMA ready for exp2)
+            const bool is_q = inter ? (st % 3) == 0 : (st >= NH && ((st - NH) & 1) == 0);
+            const float c = is_q ? 0.17677669529663688f * 1.4426950408889634f : 1.f;
             const int fi = e >> 1;
             float v = 0.f;
-            if (fi < 32) v = in_inv[row0 + fi];
-            else if (fi < 64) v = in_bias ? in_bias[row0 + fi - 32] : 0.f;
+            if (fi < 32) v = in_inv[row0 + fi] * c;
+            else if (fi < 64) v = in_bias ? in_bias[row0 + fi - 32] * c : 0.f;
             const unsigned bits = __builtin_bit_cast(unsigned, v);
             v16 = (unsigned short)((e & 1) ? (bits >> 16) : (bits & 0xffffu));
         }
@@ -663,15 +822,16 @@ __global__ __launch_bounds__(256) void dec_attn2_image_kernel(const unsigned sho
         const int hd = st - 3 * NH;
         if (f < W_FRAGS) {
             const int t = f >> 1, pl = f & 1;
-            v16 = out_planes[pl * out_stride + (size_t)(16 * t + m) * ld_out + 32 * hd + 16 * (j >> 2) + 4 * kg + (j & 3)];
+            const int orow = 32 * (t >> 1) + 8 * (m >> 2) + 4 * (t & 1) + (m & 3);
+            v16 = out_planes[pl * out_stride + (size_t)orow * ld_out + 32 * hd + 16 * (j >> 2) + 4 * kg + (j & 3)];
         }
     }
     img[idx] = v16;
 }
 
 // RAW stages behind a block image: stage c = rows 32 c .. 32 c + 31 of the [384, 256] offsets | logits weight; fragment 4 s + 2 Hh + p =
-// plane p of Ws[32 c + 16 Hh + m][32 s + 16 (j >> 2) + 4 kg + (j & 3)] -- the accumulator order in which the block's own output
-// becomes this product's operand; fragment 32 = 1 / row scale | bias.
+// plane p of Ws[32 c + 16 Hh + m][32 s + 8 kg + j] (the block's own output reaches this product in fragment order); fragment 32 =
+// 1 / row scale | bias.
 __global__ __launch_bounds__(256) void dec_attn2_raw_image_kernel(const unsigned short* __restrict__ planes, long stride, int ld,
                                                                   const float* __restrict__ inv, const float* __restrict__ bias,
                                                                   unsigned short* __restrict__ img) {
@@ -683,7 +843,7 @@ __global__ __launch_bounds__(256) void dec_attn2_raw_image_kernel(const unsigned
     unsigned short v16 = 0;
     if (f < W_FRAGS) {
         const int s = f >> 2, hh = (f >> 1) & 1, pl = f & 1;
-        v16 = planes[pl * stride + (size_t)(32 * c + 16 * hh + m) * ld + 32 * s + 16 * (j >> 2) + 4 * kg + (j & 3)];
+        v16 = planes[pl * stride + (size_t)(32 * c + 16 * hh + m) * ld + 32 * s + 8 * kg + j];
     } else {
         const int fi = e >> 1;
         float v = 0.f;
@@ -696,6 +856,12 @@ __global__ __launch_bounds__(256) void dec_attn2_raw_image_kernel(const unsigned
 }
 
 }  // namespace
+
+#ifdef A2_STAMPS
+extern "C" int gom_dec_attn2_set_stamps(void* device_buffer) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_a2_stamps), &device_buffer, sizeof(void*));
+}
+#endif
 
 extern "C" long gom_dec_attn2_image_bytes(int d_model, int heads) {
     if (d_model != D || heads != NH) return -1;
