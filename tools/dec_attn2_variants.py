@@ -79,6 +79,22 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e3
 
+    junk = torch.empty((768 << 20,), dtype=torch.uint8, device=dev)
+
+    def timeit_cold(fn, n=12):
+        """every launch behind a 768 MB fill: inputs and weights come from HBM, as between the layers of a step"""
+        ts = []
+        for _ in range(n):
+            junk.fill_(1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        ts.sort()
+        return ts[len(ts) // 2]
+
     for name, lib in libs.items():
         run_intra(lib)
         d0 = float((y - want_intra).abs().max())
@@ -88,6 +104,8 @@ def main():
     for rnd in range(3):
         print("round %d: " % rnd + " | ".join("%s intra %.1f inter %.1f inter+raw %.1f us" % (
             name, timeit(lambda: run_intra(lib)), timeit(lambda: run_inter(lib)), timeit(lambda: run_raw(lib))) for name, lib in libs.items()))
+    print("cold (a 768 MB fill in front of every launch): " + " | ".join("%s intra %.1f inter %.1f inter+raw %.1f us" % (
+        name, timeit_cold(lambda: run_intra(lib)), timeit_cold(lambda: run_inter(lib)), timeit_cold(lambda: run_raw(lib))) for name, lib in libs.items()))
     if "stamps" in libs:
         lib = libs["stamps"]
         lib.gom_dec_attn2_set_stamps.argtypes = [ctypes.c_void_p]
