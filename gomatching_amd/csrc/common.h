@@ -50,6 +50,26 @@ __device__ __forceinline__ void gom_split2_f16(float x, float y, unsigned int& h
     lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(r, gom_h2));
 }
 
+// A launch's weight image towards this XCD's L2, once, at the start.  Between two launches that use it the image (0.3 - 3.4 MB, last
+// read a layer or a step ago) is in HBM; every workgroup of a round then streams the same stage at the same time, and a ring's one or
+// two stages of lookahead do not cover a miss per stage (dec_attn2.hip: inter + raw 76 us warm, 100 us behind a 768 MB fill, 88 us with
+// this).  Workgroups go to the XCDs round-robin (1-D grids): the first-round workgroups of an XCD (at most 32) touch one line in 128
+// bytes of the image each, a slice per workgroup.  The loads' results are never used; they are the oldest vector-memory operations of
+// the wave, so the first counted wait of the kernel covers them.  Decoder launches only (one round of one-per-CU workgroups, 200-250 of
+// them): in the encoder's and the backbone's row-resident kernels -- nine or more rounds, the image cold for the first only -- the
+// same call measured -0.5 % frames/s (same box, three alternating pairs) and is not made.
+__device__ __forceinline__ void gom_prefetch_image(const void* img, unsigned bytes, unsigned tid, unsigned nthreads) {
+    const unsigned first = gridDim.x < 256u ? gridDim.x : 256u;
+    if (blockIdx.x >= first) return;
+    const unsigned nsl = (first + 7) / 8, sl = blockIdx.x / 8;
+    const unsigned lines = bytes / 128;
+    const unsigned per = (lines + nsl - 1) / nsl;
+    for (unsigned l = tid; l < per && l < 16 * nthreads; l += nthreads) {
+        const unsigned line = sl * per + l;
+        if (line < lines) (void)*reinterpret_cast<const volatile unsigned*>(reinterpret_cast<const unsigned char*>(img) + (size_t)line * 128);
+    }
+}
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // eight fp32 values -> one MFMA operand fragment piece per plane (hi, lo)

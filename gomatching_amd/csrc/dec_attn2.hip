@@ -321,17 +321,8 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
 
     // ---- the weight image towards this XCD's L2, once, at the start: between the layers of a step the image (1.1 - 1.5 MB, last read
     // a step ago) is in HBM, and the ring's two stages of lookahead do not cover a miss per stage (tools/dec_attn2_variants.py, a
-    // 768 MB fill in front of every launch: inter + raw 76 -> 99 us).  Workgroups go to the XCDs round-robin: the gridDim.x / 8 of an
-    // XCD touch one line in 128 bytes of the image each, a slice per workgroup; the loads' results are never used ----
-    {
-        const unsigned nsl = (gridDim.x + 7) / 8, sl = blockIdx.x / 8;
-        const unsigned lines = (VEC_BYTES + NST * CHUNK_BYTES) / 128;
-        const unsigned per = (lines + nsl - 1) / nsl;
-        for (unsigned l = tid; l < per && l < 4 * 512; l += 512) {
-            const unsigned line = sl * per + l;
-            if (line < lines) (void)*reinterpret_cast<const volatile unsigned*>(p.img + (size_t)line * 128);
-        }
-    }
+    // 768 MB fill in front of every launch: inter + raw 76 -> 99 us).  common.h gom_prefetch_image ----
+    gom_prefetch_image(p.img, (unsigned)(VEC_BYTES + NST * CHUNK_BYTES), tid, 512);
 
     float amax = 0.f, chk = 0.f;
     half8 xf[2][8];

@@ -166,18 +166,8 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
     const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, (int)p.img_bytes, 0x00020000);
     const int voff = lane * 16;
     int so = (int)(wave * p.wave_stride);                    // byte offset of the current block / chunk in the stream (uniform)
-    // the whole image (3.4 MB) towards this XCD's L2 at the start: between the layers of a step it is in HBM, and a weight group that
-    // misses stalls its wave for the trip (dec_attn2.hip has the measurement).  Workgroups go to the XCDs round-robin: the
-    // gridDim.x / 8 of an XCD touch one line in 128 bytes each, a slice per workgroup; the loads' results are never used
-    {
-        const unsigned nsl = (gridDim.x + 7) / 8, sl = blockIdx.x / 8;
-        const unsigned lines = p.img_bytes / 128;
-        const unsigned per = (lines + nsl - 1) / nsl;
-        for (unsigned l = tid; l < per && l < 16 * 256; l += 256) {
-            const unsigned line = sl * per + l;
-            if (line < lines) (void)*reinterpret_cast<const volatile unsigned*>(reinterpret_cast<const unsigned char*>(p.img) + (size_t)line * 128);
-        }
-    }
+    // the whole image (3.4 MB) towards this XCD's L2 at the start: a weight group that misses stalls its wave for the trip to HBM
+    gom_prefetch_image(p.img, p.img_bytes, tid, 256);
     half8 a0[8], a1[8], b0[10], b1[10];
 #define T2_LOADA_(dst, grp)                                                                                                 \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                                        \
