@@ -44,7 +44,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha1()
     for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "proj_ln.hip", "msda.hip",
-                 "dec_attn.hip", "dec_tail.hip", "dec_tail2.hip", "bneck_fused.hip", "bneck2.hip", "conv3x3_patch.hip", "common.h"):
+                 "dec_attn.hip", "dec_attn2.hip", "dec_tail.hip", "dec_tail2.hip", "bneck_fused.hip", "bneck2.hip", "conv3x3_patch.hip", "common.h"):
         with open(os.path.join(ROOT, "gomatching_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -838,7 +838,9 @@ def main():
         qside = 2.0 * rows * d_ * (2 * d_ + 2 * 4 * d_ + 384 + d_ + 2 * F_ + 2 * d_ + 2) * L_
         dd = sum(p_[0].elapsed_time(p_[1]) for p_ in dec_prof) / PROFILE_STEPS * 1e-3
         def pipe_busy(kind, us_per_launch):
-            """Static MFMA work of the decoder's launches per wave (see csrc/dec_attn.hip, dec_tail.hip) against their duration."""
+            """Static MFMA work of the decoder's launches per SIMD (see csrc/dec_attn.hip, dec_attn2.hip, dec_tail.hip) against their
+            duration.  (dec_attn2: two 16-token waves per SIMD on the 16-cycle shape issue what one 32-token wave issues on the 32-cycle
+            shape: the same cycles per SIMD in both forms.)"""
             # the tail launch by the form in effect (ops.DEC_TAIL2, ops.DEC_TAIL_PROJ): form 2 = 80-row workgroups, a wave issues 480
             # MFMAs per 128-unit chunk and per plain 256 -> 256 layer; form 1 = 128-row workgroups, 192 per 32-unit stage
             tail2 = bool(getattr(ops, "DEC_TAIL2", False)) and F_ % 128 == 0
@@ -871,8 +873,8 @@ def main():
             "by_kernel_us_per_step": {k_: dict({"launches": v_[0] // PROFILE_STEPS, "us": v_[1] * 1e3 / PROFILE_STEPS},
                                            **pipe_busy(k_, v_[1] * 1e3 / max(v_[0], 1)))
                                       for k_, v_ in sorted(kinds.items())},
-            "pipe_busy_note": "mfma_cycles_per_wave = the launch's MFMA instructions per wave (static count, csrc) x their pipe cycles (32 "
-                              "for 32x32x16, 16 for 16x16x32); matrix_pipe_busy = that over the launch's duration at the nominal 2.4 GHz "
+            "pipe_busy_note": "mfma_cycles_per_wave = the launch's MFMA instructions per SIMD (static count, csrc: one wave per SIMD, or the "
+                              "two 16-token waves of dec_attn2) x their pipe cycles (32 for 32x32x16, 16 for 16x16x32); matrix_pipe_busy = that over the launch's duration at the nominal 2.4 GHz "
                               "(a LOWER bound of the busy fraction of a SIMD that holds a wave: the chip clocks at or below 2.4 GHz); "
                               "cus_with_work = one-per-CU workgroups of the launch / 256.  The chip fraction of a launch is the product",
             "note": "the six composite decoder layers' Q-side nn.Linear products (44.25 GFLOP per frame at 100 queries) over the "

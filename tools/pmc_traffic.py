@@ -42,7 +42,7 @@ def kernel_source_hash():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha1()
     for name in ("gemm_f16x3.hip", "gemm_bf16x6.hip", "gemm_conv.hip", "gemm_k256.hip", "ffn_fused.hip", "proj_ln.hip", "msda.hip",
-                 "dec_attn.hip", "dec_tail.hip", "dec_tail2.hip", "bneck_fused.hip", "bneck2.hip", "conv3x3_patch.hip", "common.h"):
+                 "dec_attn.hip", "dec_attn2.hip", "dec_tail.hip", "dec_tail2.hip", "bneck_fused.hip", "bneck2.hip", "conv3x3_patch.hip", "common.h"):
         with open(os.path.join(root, "gomatching_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
