@@ -58,15 +58,22 @@ __device__ __forceinline__ void gom_split2_f16(float x, float y, unsigned int& h
 // the wave, so the first counted wait of the kernel covers them.  Decoder launches only (one round of one-per-CU workgroups, 200-250 of
 // them): in the encoder's and the backbone's row-resident kernels -- nine or more rounds, the image cold for the first only -- the
 // same call measured -0.5 % frames/s (same box, three alternating pairs) and is not made.
+// K loads per lane, unconditional (addresses clamped) and unrolled: the compiler can then COUNT them -- behind a loop of unknown length
+// or a branch it waits for every outstanding load at the next use of any loaded value, and the rows of the prologue would wait for the
+// image's lines (the counter is in order).  K x nthreads lines per workgroup are covered; a launch of few workgroups covers less.
+template <int K>
 __device__ __forceinline__ void gom_prefetch_image(const void* img, unsigned bytes, unsigned tid, unsigned nthreads) {
     const unsigned first = gridDim.x < 256u ? gridDim.x : 256u;
-    if (blockIdx.x >= first) return;
-    const unsigned nsl = (first + 7) / 8, sl = blockIdx.x / 8;
+    const unsigned nsl = (first + 7) / 8, sl = (blockIdx.x < first ? blockIdx.x : 0u) / 8;
     const unsigned lines = bytes / 128;
     const unsigned per = (lines + nsl - 1) / nsl;
-    for (unsigned l = tid; l < per && l < 16 * nthreads; l += nthreads) {
-        const unsigned line = sl * per + l;
-        if (line < lines) (void)*reinterpret_cast<const volatile unsigned*>(reinterpret_cast<const unsigned char*>(img) + (size_t)line * 128);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        unsigned l = tid + k * nthreads;
+        l = l < per ? l : per - 1;
+        unsigned line = sl * per + l;
+        line = line < lines ? line : lines - 1;
+        (void)*reinterpret_cast<const volatile unsigned*>(reinterpret_cast<const unsigned char*>(img) + (size_t)line * 128);
     }
 }
 

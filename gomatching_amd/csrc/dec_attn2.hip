@@ -319,11 +319,6 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
     constexpr unsigned OOB = 0x7FFF0000u;
     const unsigned lane16 = lane * 16;
 
-    // ---- the weight image towards this XCD's L2, once, at the start: between the layers of a step the image (1.1 - 1.5 MB, last read
-    // a step ago) is in HBM, and the ring's two stages of lookahead do not cover a miss per stage (tools/dec_attn2_variants.py, a
-    // 768 MB fill in front of every launch: inter + raw 76 -> 99 us).  common.h gom_prefetch_image ----
-    gom_prefetch_image(p.img, (unsigned)(VEC_BYTES + NST * CHUNK_BYTES), tid, 512);
-
     float amax = 0.f, chk = 0.f;
     half8 xf[2][8];
     auto xrow = [&](int r) { return p.X + (size_t)slot_row(r) * p.ldx; };
@@ -334,6 +329,10 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
         rows16_to_fragments<false>(xrow, xrow, scratch, lane, xf, amax, [&]() {
             for (int f = wave; f < 2 * CHUNK_FRAGS; f += WAVES) dma_fragment(rs_img, lane16, VEC_BYTES + f * FRAG, smem + f * FRAG);
             if (wave < 4) dma_fragment(rs_img, lane16, wave * FRAG, smem + RING_BYTES + XCH_BYTES + wave * FRAG);
+            // the whole image towards this XCD's L2 (common.h gom_prefetch_image): between the layers of a step it (1.1 - 1.5 MB, last
+            // read a step ago) is in HBM, and the ring's two stages of lookahead do not cover a miss per stage (tools/
+            // dec_attn2_variants.py, a 768 MB fill in front of every launch: inter + raw 76 -> 99 us, 88 with this)
+            gom_prefetch_image<1>(p.img, (unsigned)(VEC_BYTES + NST * CHUNK_BYTES), tid, 512);
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -66,15 +66,14 @@ constexpr int RB = 80;                                   // rows per workgroup
 constexpr int NRG = RB / 16;                             // MFMA row groups per workgroup
 constexpr int HC = 128;                                  // hidden units per chunk (32 per wave)
 constexpr int FRAG = 1024;
-constexpr int GROUP = 8 * FRAG;                          // a wave's weight stream is read in groups of eight fragments
 constexpr int XP_BYTES = 8 * NRG * 2 * FRAG;             // 80 KB: [k-step][row group][plane]
 constexpr int HP_OFF = XP_BYTES;
 constexpr int HP_BYTES = 4 * NRG * 2 * FRAG;             // 40 KB
 constexpr int RED_OFF = HP_OFF + HP_BYTES;
-constexpr int RED_BYTES = 2 * 4 * RB * 8;                // two buffers of [wave][row] float2
+constexpr int RED_BYTES = 2 * 8 * RB * 8;                // two buffers of [wave][row] float2 (up to eight waves)
 constexpr int LDS_BYTES = RED_OFF + RED_BYTES;
-constexpr int LIN_FRAGS = 64;                            // per wave: a 256 -> 256 layer
-constexpr int CHUNK_FRAGS = 64;                          // per wave and chunk of an MLP block: 32 of W1, 32 of W2
+// per wave and 256 -> 256 layer, and per wave and chunk of an MLP block (half W1, half W2): 8 weight groups of 32 / waves fragments
+constexpr int wave_frags(int waves) { return 8 * (32 / waves); }
 
 struct T2Args {
     const float* X;                                          // [M, 256]: tgt behind norm_cross, or (proj) the cross-attention's sampled rows
@@ -138,9 +137,9 @@ __device__ __forceinline__ unsigned long long t2_clock() {
     return t;
 }
 #define T2_STAMP(i)                                                                                        \
-    if (g_t2_stamps && lane == 0) g_t2_stamps[((size_t)blockIdx.x * 4 + wave) * 16 + (i)] = t2_clock() - t2_t0;
+    if (g_t2_stamps && lane == 0) g_t2_stamps[((size_t)blockIdx.x * NW + wave) * 16 + (i)] = t2_clock() - t2_t0;
 #define T2_STAMP_ADD(i, since)                                                                             \
-    if (g_t2_stamps && lane == 0) g_t2_stamps[((size_t)blockIdx.x * 4 + wave) * 16 + (i)] += t2_clock() - (since);
+    if (g_t2_stamps && lane == 0) g_t2_stamps[((size_t)blockIdx.x * NW + wave) * 16 + (i)] += t2_clock() - (since);
 #define T2_NOW(var) const unsigned long long var = t2_clock();
 #else
 #define T2_STAMP(i)
@@ -151,8 +150,15 @@ __device__ __forceinline__ unsigned long long t2_clock() {
 #define T2_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory")
 #define T2_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <bool WITH_QPOS, bool WITH_PROJ>
-__global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
+// NW = waves per workgroup: 4 (one per SIMD; a wave owns 64 output columns and 32 hidden units of a chunk) or 8 (TWO per SIMD; 32 and
+// 16: half the accumulators, <= 256 registers -- one wave's epilogues and activation phases then run under the other's MFMAs)
+template <bool WITH_QPOS, bool WITH_PROJ, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void dec_tail2_kernel(const T2Args p) {
+    constexpr int CGN = 16 / NW;                             // output column groups per wave
+    constexpr int HGN = 8 / NW;                              // hidden groups per wave and chunk
+    constexpr int GF = 32 / NW;                              // fragments per weight group
+    constexpr int WCOLS = 16 * CGN;                          // output columns per wave
+    constexpr int UPW = RB / NW;                             // prologue units per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,12 +172,10 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
     const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, (int)p.img_bytes, 0x00020000);
     const int voff = lane * 16;
     int so = (int)(wave * p.wave_stride);                    // byte offset of the current block / chunk in the stream (uniform)
-    // the whole image (3.4 MB) towards this XCD's L2 at the start: a weight group that misses stalls its wave for the trip to HBM
-    gom_prefetch_image(p.img, p.img_bytes, tid, 256);
-    half8 a0[8], a1[8], b0[10], b1[10];
+    half8 a0[GF], a1[GF], b0[10], b1[10];
 #define T2_LOADA_(dst, grp)                                                                                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                                        \
-        dst[i_] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_img, voff, so + (grp) * GROUP + i_ * FRAG, 0));
+    _Pragma("unroll") for (int i_ = 0; i_ < GF; ++i_)                                                                       \
+        dst[i_] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_img, voff, so + ((grp) * GF + i_) * FRAG, 0));
 #ifdef T2_EXP_NO_A                                       /* timing experiment (wrong results): the weight stream is not read */
 #define T2_LOADA(dst, grp)
 #else
@@ -206,20 +210,25 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
     float amax = 0.f, chk = 0.f;                             // range bookkeeping (gemm_f16x3.hip contract): the input rows, unsplit results
     u16x2 pmax = {0, 0};                                     // ... and every value split inside the kernel (t2_track)
 
-    // ---- prologue: the 80 input rows -> XP.  80 units of (8 rows x 32 floats = one k-step) over the four waves; a unit is ONE load
+    // ---- prologue: the 80 input rows -> XP.  80 units of (8 rows x 32 floats = one k-step) over the waves; a unit is ONE load
     //      instruction of eight whole 128-byte lines (lane: row l & 7, 16-byte piece l >> 3) and two 8-byte LDS stores per lane ----
     {
-        f32x4 v[20];
+        f32x4 v[UPW];
 #pragma unroll
-        for (int i = 0; i < 20; ++i) {
-            const int u = wave * 20 + i, rb = u >> 3, part = u & 7;
+        for (int i = 0; i < UPW; ++i) {
+            const int u = wave * UPW + i, rb = u >> 3, part = u & 7;
             long m = tile0 + 8 * rb + (lane & 7);
             if (m > p.M - 1) m = p.M - 1;
             v[i] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * p.ldx + 32 * part + 4 * (lane >> 3));
         }
+        // the whole image (3.4 MB) towards this XCD's L2: a weight group that misses stalls its wave for the trip to HBM.  BEHIND the
+        // row loads (the vector-memory counter is in order: in front of them the rows wait for the image's lines, +7k cycles)
+        __builtin_amdgcn_sched_barrier(0);
+        gom_prefetch_image<(NW == 8 ? 2 : 4)>(p.img, p.img_bytes, tid, 64 * NW);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 20; ++i) {
-            const int u = wave * 20 + i, rb = u >> 3, part = u & 7;
+        for (int i = 0; i < UPW; ++i) {
+            const int u = wave * UPW + i, rb = u >> 3, part = u & 7;
             const int row = 8 * rb + (lane & 7), pp = lane >> 3;
 #pragma unroll
             for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
@@ -235,35 +244,35 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
     T2_BARRIER_LDS();
     T2_STAMP(0)
 
-    f32x4 acc2[4][NRG];                                      // [column group of the wave][row group]
+    f32x4 acc2[CGN][NRG];                                    // [column group of the wave][row group]
 #define T2_ZERO_ACC2()                                                                                                      \
-    _Pragma("unroll") for (int cg = 0; cg < 4; ++cg)                                                                        \
+    _Pragma("unroll") for (int cg = 0; cg < CGN; ++cg)                                                                        \
         _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg) acc2[cg][rg] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // 60 MFMAs: the wave's four column groups (fragments A[2 cg + plane]) against the five row groups (B[2 rg + plane]);
     // small products first (residual x main, main x residual, main x main), twenty accumulators between dependent ones
 #define T2_MM2(A, B)                                                                                                        \
-    _Pragma("unroll") for (int cg = 0; cg < 4; ++cg)                                                                        \
+    _Pragma("unroll") for (int cg = 0; cg < CGN; ++cg)                                                                        \
         _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg) acc2[cg][rg] = mfma16(A[2 * cg + 1], B[2 * rg], acc2[cg][rg]);   \
-    _Pragma("unroll") for (int cg = 0; cg < 4; ++cg)                                                                        \
+    _Pragma("unroll") for (int cg = 0; cg < CGN; ++cg)                                                                        \
         _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg) acc2[cg][rg] = mfma16(A[2 * cg], B[2 * rg + 1], acc2[cg][rg]);   \
-    _Pragma("unroll") for (int cg = 0; cg < 4; ++cg)                                                                        \
+    _Pragma("unroll") for (int cg = 0; cg < CGN; ++cg)                                                                        \
         _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg) acc2[cg][rg] = mfma16(A[2 * cg], B[2 * rg], acc2[cg][rg]);
     // 30 MFMAs: the wave's two hidden groups (fragments A[4 half + 2 hg + plane]) against the five row groups
 #define T2_MM1(A, half, B)                                                                                                  \
-    _Pragma("unroll") for (int hg = 0; hg < 2; ++hg)                                                                        \
+    _Pragma("unroll") for (int hg = 0; hg < HGN; ++hg)                                                                        \
         _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg)                                                                  \
-            acc1[hg][rg] = mfma16(A[4 * (half) + 2 * hg + 1], B[2 * rg], acc1[hg][rg]);                                     \
-    _Pragma("unroll") for (int hg = 0; hg < 2; ++hg)                                                                        \
+            acc1[hg][rg] = mfma16(A[2 * HGN * (half) + 2 * hg + 1], B[2 * rg], acc1[hg][rg]);                                     \
+    _Pragma("unroll") for (int hg = 0; hg < HGN; ++hg)                                                                        \
         _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg)                                                                  \
-            acc1[hg][rg] = mfma16(A[4 * (half) + 2 * hg], B[2 * rg + 1], acc1[hg][rg]);                                     \
-    _Pragma("unroll") for (int hg = 0; hg < 2; ++hg)                                                                        \
+            acc1[hg][rg] = mfma16(A[2 * HGN * (half) + 2 * hg], B[2 * rg + 1], acc1[hg][rg]);                                     \
+    _Pragma("unroll") for (int hg = 0; hg < HGN; ++hg)                                                                        \
         _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg)                                                                  \
-            acc1[hg][rg] = mfma16(A[4 * (half) + 2 * hg], B[2 * rg], acc1[hg][rg]);
+            acc1[hg][rg] = mfma16(A[2 * HGN * (half) + 2 * hg], B[2 * rg], acc1[hg][rg]);
     // schedule pins: the step's ten LDS reads first, then its MFMAs with the eight weight loads spread between them
 #define T2_PIN_B() __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
 #define T2_PIN_MA(n_mfma_per_load)                                                                                          \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < GF; ++q_) {                                                                      \
         __builtin_amdgcn_sched_group_barrier(0x008, n_mfma_per_load, 0);                                                    \
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                                  \
     }
@@ -278,73 +287,88 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         for (int c = 0; c < (nch); ++c) {                                                                                   \
             const bool more = c + 1 < (nch);                                                                                \
             T2_NOW(tc0_)                                                                                                    \
-            f32x4 acc1[2][NRG];                                                                                             \
-            _Pragma("unroll") for (int hg = 0; hg < 2; ++hg)                                                                \
+            f32x4 acc1[HGN][NRG];                                                                                           \
+            _Pragma("unroll") for (int hg = 0; hg < HGN; ++hg)                                                                \
                 _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg) acc1[hg][rg] = f32x4{0.f, 0.f, 0.f, 0.f};                \
-            f32x4 sc[2], bi[2];                                                                                             \
-            _Pragma("unroll") for (int hg = 0; hg < 2; ++hg) {                                                              \
-                const int h = HC * c + 32 * wave + 16 * hg + 4 * fg;                                                        \
+            f32x4 sc[HGN], bi[HGN];                                                                                         \
+            _Pragma("unroll") for (int hg = 0; hg < HGN; ++hg) {                                                              \
+                const int h = HC * c + 16 * (HGN * wave + hg) + 4 * fg;                                                     \
                 sc[hg] = *reinterpret_cast<const f32x4*>((inv1) + h);                                                       \
                 bi[hg] = *reinterpret_cast<const f32x4*>((bias1) + h);                                                      \
             }                                                                                                               \
-            T2_LOADB(b1, xp_lane, 1) T2_LOADA(a1, 1) T2_MM1(a0, 0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD1) T2_PIN_M(30 - 8 * T2_SPREAD1)                  \
-            T2_LOADB(b0, xp_lane, 2) T2_MM1(a0, 1, b1) T2_PIN_B() T2_PIN_M(30)                                              \
-            T2_LOADB(b1, xp_lane, 3) T2_LOADA(a0, 2) T2_MM1(a1, 0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD1) T2_PIN_M(30 - 8 * T2_SPREAD1)                  \
-            T2_LOADB(b0, xp_lane, 4) T2_MM1(a1, 1, b1) T2_PIN_B() T2_PIN_M(30)                                              \
-            T2_LOADB(b1, xp_lane, 5) T2_LOADA(a1, 3) T2_MM1(a0, 0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD1) T2_PIN_M(30 - 8 * T2_SPREAD1)                  \
-            T2_LOADB(b0, xp_lane, 6) T2_MM1(a0, 1, b1) T2_PIN_B() T2_PIN_M(30)                                              \
-            T2_LOADB(b1, xp_lane, 7) T2_LOADA(a0, 4) T2_MM1(a1, 0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD1) T2_PIN_M(30 - 8 * T2_SPREAD1)                  \
-            T2_MM1(a1, 1, b1) T2_PIN_M(30)                                                                                  \
+            T2_LOADB(b1, xp_lane, 1) T2_LOADA(a1, 1) T2_MM1(a0, 0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD1) T2_PIN_M(15 * HGN - GF * T2_SPREAD1)                  \
+            T2_LOADB(b0, xp_lane, 2) T2_MM1(a0, 1, b1) T2_PIN_B() T2_PIN_M(15 * HGN)                                              \
+            T2_LOADB(b1, xp_lane, 3) T2_LOADA(a0, 2) T2_MM1(a1, 0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD1) T2_PIN_M(15 * HGN - GF * T2_SPREAD1)                  \
+            T2_LOADB(b0, xp_lane, 4) T2_MM1(a1, 1, b1) T2_PIN_B() T2_PIN_M(15 * HGN)                                              \
+            T2_LOADB(b1, xp_lane, 5) T2_LOADA(a1, 3) T2_MM1(a0, 0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD1) T2_PIN_M(15 * HGN - GF * T2_SPREAD1)                  \
+            T2_LOADB(b0, xp_lane, 6) T2_MM1(a0, 1, b1) T2_PIN_B() T2_PIN_M(15 * HGN)                                              \
+            T2_LOADB(b1, xp_lane, 7) T2_LOADA(a0, 4) T2_MM1(a1, 0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD1) T2_PIN_M(15 * HGN - GF * T2_SPREAD1)                  \
+            T2_MM1(a1, 1, b1) T2_PIN_M(15 * HGN)                                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                              \
             T2_STAMP_ADD(10, tc0_)                                                                                          \
             T2_NOW(tc1_)                                                                                                    \
             T2_BARRIER();                                            /* every wave is done with the previous chunk's HP */ \
             _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg) {                                                            \
-                f32x4 v[2];                                                                                                 \
-                _Pragma("unroll") for (int hg = 0; hg < 2; ++hg)                                                            \
+                f32x4 v[HGN];                                                                                               \
+                _Pragma("unroll") for (int hg = 0; hg < HGN; ++hg)                                                          \
                     _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                           \
                         v[hg][e] = fmaxf(fmaf(acc1[hg][rg][e], sc[hg][e], bi[hg][e]), 0.f);                                 \
-                half8 h0, h1;                                                                                               \
-                gom_split8_f16(v[0], v[1], h0, h1);                                                                         \
-                t2_track_nonneg(pmax, h0);                                                                                  \
-                unsigned char* dst = smem + HP_OFF + ((wave * NRG + rg) * 2) * FRAG + lane * 16;                            \
-                *reinterpret_cast<half8*>(dst) = h0;                                                                        \
-                *reinterpret_cast<half8*>(dst + FRAG) = h1;                                                                 \
+                if constexpr (HGN == 2) {                                                                                   \
+                    half8 h0, h1;                                                                                           \
+                    gom_split8_f16(v[0], v[1], h0, h1);                                                                     \
+                    t2_track_nonneg(pmax, h0);                                                                              \
+                    unsigned char* dst = smem + HP_OFF + ((wave * NRG + rg) * 2) * FRAG + lane * 16;                        \
+                    *reinterpret_cast<half8*>(dst) = h0;                                                                    \
+                    *reinterpret_cast<half8*>(dst + FRAG) = h1;                                                             \
+                } else {              /* 16 hidden units per wave: its half of k-step wave >> 1's fragment, 8 bytes per lane */ \
+                    unsigned h0, l0, h1, l1;                                                                                \
+                    gom_split2_f16(v[0][0], v[0][1], h0, l0);                                                               \
+                    gom_split2_f16(v[0][2], v[0][3], h1, l1);                                                               \
+                    pmax = __builtin_elementwise_max(pmax, __builtin_elementwise_max(__builtin_bit_cast(u16x2, h0), __builtin_bit_cast(u16x2, h1))); \
+                    unsigned char* dst = smem + HP_OFF + (((wave >> 1) * NRG + rg) * 2) * FRAG + lane * 16 + 8 * (wave & 1); \
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};                                                         \
+                    *reinterpret_cast<u32x2*>(dst + FRAG) = u32x2{l0, l1};                                                  \
+                }                                                                                                           \
             }                                                                                                               \
             T2_BARRIER_LDS();                                                                                               \
             T2_STAMP_ADD(11, tc1_)                                                                                          \
             T2_NOW(tc2_)                                                                                                    \
             T2_LOADB(b0, hp_lane, 0)                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                              \
-            T2_LOADB(b1, hp_lane, 1) T2_LOADA(a1, 5) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)                     \
-            T2_LOADB(b0, hp_lane, 2) T2_LOADA(a0, 6) T2_MM2(a1, b1) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)                     \
-            T2_LOADB(b1, hp_lane, 3) T2_LOADA(a1, 7) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)                     \
+            T2_LOADB(b1, hp_lane, 1) T2_LOADA(a1, 5) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)                     \
+            T2_LOADB(b0, hp_lane, 2) T2_LOADA(a0, 6) T2_MM2(a1, b1) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)                     \
+            T2_LOADB(b1, hp_lane, 3) T2_LOADA(a1, 7) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)                     \
             __builtin_amdgcn_sched_barrier(0);                                                                              \
             if (more) {                                                                                                     \
                 T2_LOADB(b0, xp_lane, 0)                                                                                    \
             }                                                                                                               \
-            T2_LOADA(a0, 8) T2_MM2(a1, b1) T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)                                                         \
+            T2_LOADA(a0, 8) T2_MM2(a1, b1) T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                              \
             T2_STAMP_ADD(12, tc2_)                                                                                          \
-            so += CHUNK_FRAGS * FRAG;                                                                                       \
+            so += 8 * GF * FRAG;                                                                                            \
         }                                                                                                                   \
     }
 
     // ---- row statistics of v = acc2 across the workgroup's 256 columns: per wave (sum, M2 about the wave's own mean) over its
     //      64 columns, exchanged through RED[buf], combined with Chan's formula.  One barrier. ----
+    // (sums over the waves' contributions in a fixed pairwise order)
+    auto tree = [&](const float (&v)[NW]) {
+        if constexpr (NW == 4) return (v[0] + v[1]) + (v[2] + v[3]);
+        else return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    };
     auto row_stats = [&](int buf, float eps, float (&mean)[NRG], float (&rstd)[NRG]) {
-        float2* red = reinterpret_cast<float2*>(smem + RED_OFF) + buf * 4 * RB;
+        float2* red = reinterpret_cast<float2*>(smem + RED_OFF) + buf * NW * RB;
 #pragma unroll
         for (int rg = 0; rg < NRG; ++rg) {
             float s = 0.f;
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg)
+            for (int cg = 0; cg < CGN; ++cg)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s += acc2[cg][rg][e];
-            const float mw = groups_sum(s) * (1.f / 64.f);
+            const float mw = groups_sum(s) * (1.f / WCOLS);
             float q = 0.f;
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg)
+            for (int cg = 0; cg < CGN; ++cg)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float d = acc2[cg][rg][e] - mw;
@@ -356,53 +380,57 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         T2_BARRIER_LDS();
 #pragma unroll
         for (int rg = 0; rg < NRG; ++rg) {
-            float2 w[4];
+            float wm[NW], wq[NW];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] = red[k * RB + 16 * rg + fn];
-            const float m = ((w[0].x + w[1].x) + (w[2].x + w[3].x)) * 0.25f;
-            float m2 = (w[0].y + w[1].y) + (w[2].y + w[3].y);
+            for (int k = 0; k < NW; ++k) {
+                const float2 w = red[k * RB + 16 * rg + fn];
+                wm[k] = w.x;
+                wq[k] = w.y;
+            }
+            const float m = tree(wm) * (1.f / NW);
+            float m2 = tree(wq);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) m2 = fmaf(64.f * (w[k].x - m), w[k].x - m, m2);
+            for (int k = 0; k < NW; ++k) m2 = fmaf((float)WCOLS * (wm[k] - m), wm[k] - m, m2);
             mean[rg] = m;
             rstd[rg] = rsqrtf(m2 * (1.f / D) + eps);
         }
     };
     // the finished rows o[cg][rg] (accumulator layout) -> XP as the next block's B operand: k-steps 2 w, 2 w + 1
-    auto to_xp = [&](const f32x4 (&o)[4][NRG]) {
+    auto to_xp = [&](const f32x4 (&o)[CGN][NRG]) {
 #pragma unroll
-        for (int sh = 0; sh < 2; ++sh)
+        for (int sh = 0; sh < CGN / 2; ++sh)
 #pragma unroll
             for (int rg = 0; rg < NRG; ++rg) {
                 half8 h0, h1;
                 gom_split8_f16(o[2 * sh][rg], o[2 * sh + 1][rg], h0, h1);
                 t2_track(pmax, h0);
-                unsigned char* dst = smem + (((2 * wave + sh) * NRG + rg) * 2) * FRAG + lane * 16;
+                unsigned char* dst = smem + ((((CGN / 2) * wave + sh) * NRG + rg) * 2) * FRAG + lane * 16;
                 *reinterpret_cast<half8*>(dst) = h0;
                 *reinterpret_cast<half8*>(dst + FRAG) = h1;
             }
     };
 
     // the FFN's residual in the accumulator layout: norm_cross's output (proj) or the input rows
-    f32x4 res[4][NRG];
+    f32x4 res[CGN][NRG];
 
     // ================================ block 0: out_proj of the cross attention + norm_cross ================================
     if constexpr (WITH_PROJ) {
         T2_ZERO_ACC2()
         T2_LOADB(b0, xp_lane, 0)
-        T2_LOADB(b1, xp_lane, 1) T2_LOADA(a1, 1) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)
-        T2_LOADB(b0, xp_lane, 2) T2_LOADA(a0, 2) T2_MM2(a1, b1) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)
-        T2_LOADB(b1, xp_lane, 3) T2_LOADA(a1, 3) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)
-        T2_LOADB(b0, xp_lane, 4) T2_LOADA(a0, 4) T2_MM2(a1, b1) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)
-        T2_LOADB(b1, xp_lane, 5) T2_LOADA(a1, 5) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)
-        T2_LOADB(b0, xp_lane, 6) T2_LOADA(a0, 6) T2_MM2(a1, b1) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)
-        T2_LOADB(b1, xp_lane, 7) T2_LOADA(a1, 7) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)
-        T2_LOADA(a0, 8) T2_MM2(a1, b1) T2_PIN_MA(T2_SPREAD2) T2_PIN_M(60 - 8 * T2_SPREAD2)
+        T2_LOADB(b1, xp_lane, 1) T2_LOADA(a1, 1) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)
+        T2_LOADB(b0, xp_lane, 2) T2_LOADA(a0, 2) T2_MM2(a1, b1) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)
+        T2_LOADB(b1, xp_lane, 3) T2_LOADA(a1, 3) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)
+        T2_LOADB(b0, xp_lane, 4) T2_LOADA(a0, 4) T2_MM2(a1, b1) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)
+        T2_LOADB(b1, xp_lane, 5) T2_LOADA(a1, 5) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)
+        T2_LOADB(b0, xp_lane, 6) T2_LOADA(a0, 6) T2_MM2(a1, b1) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)
+        T2_LOADB(b1, xp_lane, 7) T2_LOADA(a1, 7) T2_MM2(a0, b0) T2_PIN_B() T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)
+        T2_LOADA(a0, 8) T2_MM2(a1, b1) T2_PIN_MA(T2_SPREAD2) T2_PIN_M(15 * CGN - GF * T2_SPREAD2)
         __builtin_amdgcn_sched_barrier(0);
-        so += LIN_FRAGS * FRAG;
+        so += 8 * GF * FRAG;
         T2_STAMP(1)
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            const int col = 64 * wave + 16 * cg + 4 * fg;
+        for (int cg = 0; cg < CGN; ++cg) {
+            const int col = WCOLS * wave + 16 * cg + 4 * fg;
             const f32x4 sc = *reinterpret_cast<const f32x4*>(p.p_s + col);
             const f32x4 bi = *reinterpret_cast<const f32x4*>(p.p_b + col);
 #pragma unroll
@@ -419,8 +447,8 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         float mean[NRG], rstd[NRG];
         row_stats(0, p.p_eps, mean, rstd);
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            const int col = 64 * wave + 16 * cg + 4 * fg;
+        for (int cg = 0; cg < CGN; ++cg) {
+            const int col = WCOLS * wave + 16 * cg + 4 * fg;
             const f32x4 ga = *reinterpret_cast<const f32x4*>(p.p_gamma + col);
             const f32x4 be = *reinterpret_cast<const f32x4*>(p.p_beta + col);
 #pragma unroll
@@ -438,8 +466,8 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
     T2_STAMP(3)
     {
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            const int col = 64 * wave + 16 * cg + 4 * fg;
+        for (int cg = 0; cg < CGN; ++cg) {
+            const int col = WCOLS * wave + 16 * cg + 4 * fg;
             const f32x4 sc = *reinterpret_cast<const f32x4*>(p.s2 + col);
             const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b2 + col);
 #pragma unroll
@@ -452,8 +480,8 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         float mean[NRG], rstd[NRG];
         row_stats(1, p.eps, mean, rstd);
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            const int col = 64 * wave + 16 * cg + 4 * fg;
+        for (int cg = 0; cg < CGN; ++cg) {
+            const int col = WCOLS * wave + 16 * cg + 4 * fg;
             const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + col);
             const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + col);
 #pragma unroll
@@ -478,8 +506,8 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
 #pragma unroll
         for (int rg = 0; rg < NRG; ++rg) dx[rg] = dy[rg] = 0.f;
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            const int col = 64 * wave + 16 * cg + 4 * fg;
+        for (int cg = 0; cg < CGN; ++cg) {
+            const int col = WCOLS * wave + 16 * cg + 4 * fg;
             const f32x4 sc = *reinterpret_cast<const f32x4*>(p.c_s2 + col);
             const f32x4 bi = *reinterpret_cast<const f32x4*>(p.c_b2 + col);
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.W3 + col);
@@ -504,10 +532,14 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         const float bx = p.b3[0], by = p.b3[1];
 #pragma unroll
         for (int rg = 0; rg < NRG; ++rg) {
-            float2 w[4];
+            float wx[NW], wy[NW];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] = red[k * RB + 16 * rg + fn];
-            const float ddx = ((w[0].x + w[1].x) + (w[2].x + w[3].x)) + bx, ddy = ((w[0].y + w[1].y) + (w[2].y + w[3].y)) + by;
+            for (int k = 0; k < NW; ++k) {
+                const float2 w = red[k * RB + 16 * rg + fn];
+                wx[k] = w.x;
+                wy[k] = w.y;
+            }
+            const float ddx = tree(wx) + bx, ddy = tree(wy) + by;
             const float rx0 = p.ref[mrow[rg] * 2], ry0 = p.ref[mrow[rg] * 2 + 1];
             nref[rg][0] = sigmoidf(ddx + inv_sigmoid(rx0));
             nref[rg][1] = sigmoidf(ddy + inv_sigmoid(ry0));
@@ -520,10 +552,10 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         // ---- the next layer's point embedding (gen_point_pos_embed: channels [0, 128) <- x, [128, 256) <- y, sin on even, cos on odd
         //      channels of a pair that shares dim_t), evaluated by the wave that owns the feature, straight into XP ----
         {
-            f32x4 o[4][NRG];
+            f32x4 o[CGN][NRG];
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) {
-                const f32x4 dt = *reinterpret_cast<const f32x4*>(p.dim_t + ((64 * wave + 16 * cg + 4 * fg) & 127));
+            for (int cg = 0; cg < CGN; ++cg) {
+                const f32x4 dt = *reinterpret_cast<const f32x4*>(p.dim_t + ((WCOLS * wave + 16 * cg + 4 * fg) & 127));
                 // pos = pts * 2 pi / dim_t (utils.py:24-37) with the quotient as a product by 1 / dim_t refined to fp32 accuracy (one
                 // Newton step on v_rcp_f32): two reciprocals per column group instead of ten divisions (~10 instructions each)
                 float rdt[2];
@@ -534,7 +566,7 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
                 }
 #pragma unroll
                 for (int rg = 0; rg < NRG; ++rg) {
-                    const float e = nref[rg][wave >> 1] * 6.283185307179586f;
+                    const float e = nref[rg][(WCOLS * wave) >> 7] * 6.283185307179586f;
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {            // channels (4 g + 2 k, 4 g + 2 k + 1) of the quad: one angle
                         float sn, cs;
@@ -552,8 +584,8 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
         T2_MLP(2, p.q_s1, p.q_b1)
         T2_STAMP(7)
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            const int col = 64 * wave + 16 * cg + 4 * fg;
+        for (int cg = 0; cg < CGN; ++cg) {
+            const int col = WCOLS * wave + 16 * cg + 4 * fg;
             const f32x4 sc = *reinterpret_cast<const f32x4*>(p.q_s2 + col);
             const f32x4 bi = *reinterpret_cast<const f32x4*>(p.q_b2 + col);
 #pragma unroll
@@ -583,67 +615,75 @@ __global__ __launch_bounds__(256, 1) void dec_tail2_kernel(const T2Args p) {
 #undef T2_MLP
 }
 
-// ---- weight images: per wave w one linear stream; element j of lane (m, kg) of a fragment holds plane p of a row-scaled weight
-//      (gom_split_f16x2) at row 16 t + m and input index perm(s, kg, j) = 32 s + 16 (j >> 2) + 4 kg + (j & 3) ----
-// a 256 -> 256 layer: fragment q = 8 s + 2 cg + p (s = 0..7 k-step, cg = 0..3): plane p of W[16 (4 w + cg) + m][perm(s, kg, j)]
-__global__ __launch_bounds__(256) void t2_lin_image_kernel(const unsigned short* __restrict__ planes, long ps, int ld,
+// ---- weight images: per wave w (of nw = 4 or 8) one linear stream; element j of lane (m, kg) of a fragment holds plane p of a
+//      row-scaled weight (gom_split_f16x2) at row 16 t + m and input index perm(s, kg, j) = 32 s + 16 (j >> 2) + 4 kg + (j & 3).
+//      cgn = 16 / nw output column groups and hgn = 8 / nw hidden groups per wave, gf = 32 / nw fragments per weight group ----
+// a 256 -> 256 layer: fragment q = gf s + 2 cg + p (s = 0..7 k-step, cg < cgn): plane p of W[16 (cgn w + cg) + m][perm(s, kg, j)]
+__global__ __launch_bounds__(256) void t2_lin_image_kernel(const unsigned short* __restrict__ planes, long ps, int ld, int nw,
                                                            unsigned short* __restrict__ img, long wave_stride_el) {
+    const int lf = wave_frags(nw), gf = 32 / nw, cgn = 16 / nw;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= 4L * LIN_FRAGS * 512) return;
-    const int e = (int)(i % 512), q = (int)((i / 512) % LIN_FRAGS), w = (int)(i / (512L * LIN_FRAGS));
+    if (i >= (long)nw * lf * 512) return;
+    const int e = (int)(i % 512), q = (int)((i / 512) % lf), w = (int)(i / (512L * lf));
     const int l = e >> 3, j = e & 7, m = l & 15, kg = l >> 4;
-    const int s = q >> 3, cg = (q >> 1) & 3, pl = q & 1;
+    const int s = q / gf, cg = (q % gf) >> 1, pl = q & 1;
     img[w * wave_stride_el + (long)q * 512 + e] =
-        planes[pl * ps + (size_t)(16 * (4 * w + cg) + m) * ld + 32 * s + 16 * (j >> 2) + 4 * kg + (j & 3)];
+        planes[pl * ps + (size_t)(16 * (cgn * w + cg) + m) * ld + 32 * s + 16 * (j >> 2) + 4 * kg + (j & 3)];
 }
-// an MLP block of F hidden units: per chunk c of 128, fragments q = 64 c + (4 s + 2 hg + p | 32 + 8 s2 + 2 cg + p):
-//   W1 part: plane p of W1[128 c + 32 w + 16 hg + m][perm(s, kg, j)]
-//   W2 part: plane p of W2[16 (4 w + cg) + m][128 c + perm(s2, kg, j)]
+// an MLP block of F hidden units: per chunk c of 128, fragments q = cf c + (2 hgn s + 2 hg + p | cf / 2 + gf s2 + 2 cg + p), cf = 8 gf:
+//   W1 part: plane p of W1[128 c + 16 (hgn w + hg) + m][perm(s, kg, j)]
+//   W2 part: plane p of W2[16 (cgn w + cg) + m][128 c + perm(s2, kg, j)]
 __global__ __launch_bounds__(256) void t2_mlp_image_kernel(const unsigned short* __restrict__ p1, long ps1, int ld1,
-                                                           const unsigned short* __restrict__ p2, long ps2, int ld2, int F,
+                                                           const unsigned short* __restrict__ p2, long ps2, int ld2, int F, int nw,
                                                            unsigned short* __restrict__ img, long wave_stride_el) {
+    const int cf = wave_frags(nw), gf = 32 / nw, cgn = 16 / nw, hgn = 8 / nw;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long per_wave = (long)(F / HC) * CHUNK_FRAGS * 512;
-    if (i >= 4 * per_wave) return;
+    const long per_wave = (long)(F / HC) * cf * 512;
+    if (i >= nw * per_wave) return;
     const int e = (int)(i % 512), w = (int)(i / per_wave);
     const long qq = (i % per_wave) / 512;
-    const int c = (int)(qq / CHUNK_FRAGS), q = (int)(qq % CHUNK_FRAGS);
+    const int c = (int)(qq / cf), q = (int)(qq % cf);
     const int l = e >> 3, j = e & 7, m = l & 15, kg = l >> 4;
     unsigned short v;
-    if (q < 32) {
-        const int s = q >> 2, hg = (q >> 1) & 1, pl = q & 1;
-        v = p1[pl * ps1 + (size_t)(HC * c + 32 * w + 16 * hg + m) * ld1 + 32 * s + 16 * (j >> 2) + 4 * kg + (j & 3)];
+    if (q < cf / 2) {
+        const int s = q / (2 * hgn), hg = (q % (2 * hgn)) >> 1, pl = q & 1;
+        v = p1[pl * ps1 + (size_t)(HC * c + 16 * (hgn * w + hg) + m) * ld1 + 32 * s + 16 * (j >> 2) + 4 * kg + (j & 3)];
     } else {
-        const int r = q - 32, s2 = r >> 3, cg = (r >> 1) & 3, pl = r & 1;
-        v = p2[pl * ps2 + (size_t)(16 * (4 * w + cg) + m) * ld2 + HC * c + 32 * s2 + 16 * (j >> 2) + 4 * kg + (j & 3)];
+        const int r = q - cf / 2, s2 = r / gf, cg = (r % gf) >> 1, pl = r & 1;
+        v = p2[pl * ps2 + (size_t)(16 * (cgn * w + cg) + m) * ld2 + HC * c + 32 * s2 + 16 * (j >> 2) + 4 * kg + (j & 3)];
     }
     img[w * wave_stride_el + qq * 512 + e] = v;
 }
 
 }  // namespace
 
-/* bytes of ONE wave's stream (= the stride between the four waves' streams); the image is 4 x this */
-extern "C" long gom_dec_tail2_wave_bytes(int d_model, int d_hidden, int with_proj, int with_qpos) {
-    if (d_model != D || d_hidden <= 0 || (d_hidden % HC) != 0) return -1;
-    return (long)((with_proj ? LIN_FRAGS : 0) + (d_hidden / HC + 2 + (with_qpos ? 2 : 0)) * CHUNK_FRAGS) * FRAG;
+/* bytes of ONE wave's stream (= the stride between the waves' streams); the image is `waves` x this.  waves = 4 or 8. */
+extern "C" long gom_dec_tail2_wave_bytes(int d_model, int d_hidden, int with_proj, int with_qpos, int waves) {
+    if (d_model != D || d_hidden <= 0 || (d_hidden % HC) != 0 || (waves != 4 && waves != 8)) return -1;
+    return (long)((with_proj ? 1 : 0) + d_hidden / HC + 2 + (with_qpos ? 2 : 0)) * wave_frags(waves) * FRAG;
 }
 
 extern "C" int gom_dec_tail2_image_lin(const void* w_planes, long w_plane_stride, int ld, void* image, long wave_bytes, long offset_bytes,
-                                       void* stream) {
-    GOM_CHECK_ARG(w_planes && image && ld >= D && wave_bytes >= offset_bytes + (long)LIN_FRAGS * FRAG && (offset_bytes % FRAG) == 0);
-    hipLaunchKernelGGL(t2_lin_image_kernel, dim3((unsigned)cdiv(4L * LIN_FRAGS * 512, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)w_planes, w_plane_stride, ld, (unsigned short*)((unsigned char*)image + offset_bytes), wave_bytes / 2);
+                                       int waves, void* stream) {
+    GOM_CHECK_ARG(waves == 4 || waves == 8);
+    const int lf = wave_frags(waves);
+    GOM_CHECK_ARG(w_planes && image && ld >= D && wave_bytes >= offset_bytes + (long)lf * FRAG && (offset_bytes % FRAG) == 0);
+    hipLaunchKernelGGL(t2_lin_image_kernel, dim3((unsigned)cdiv((long)waves * lf * 512, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)w_planes, w_plane_stride, ld, waves, (unsigned short*)((unsigned char*)image + offset_bytes),
+                       wave_bytes / 2);
     return gom_launch_status();
 }
 
 extern "C" int gom_dec_tail2_image_mlp(const void* w1_planes, long w1_plane_stride, int ld1, const void* w2_planes, long w2_plane_stride,
-                                       int ld2, int d_hidden, void* image, long wave_bytes, long offset_bytes, void* stream) {
+                                       int ld2, int d_hidden, void* image, long wave_bytes, long offset_bytes, int waves, void* stream) {
+    GOM_CHECK_ARG(waves == 4 || waves == 8);
+    const int cf = wave_frags(waves);
     GOM_CHECK_ARG(w1_planes && w2_planes && image && d_hidden > 0 && (d_hidden % HC) == 0 && ld1 >= D && ld2 >= d_hidden);
-    GOM_CHECK_ARG(wave_bytes >= offset_bytes + (long)(d_hidden / HC) * CHUNK_FRAGS * FRAG && (offset_bytes % FRAG) == 0);
-    const long total = 4L * (d_hidden / HC) * CHUNK_FRAGS * 512;
+    GOM_CHECK_ARG(wave_bytes >= offset_bytes + (long)(d_hidden / HC) * cf * FRAG && (offset_bytes % FRAG) == 0);
+    const long total = (long)waves * (d_hidden / HC) * cf * 512;
     hipLaunchKernelGGL(t2_mlp_image_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)w1_planes, w1_plane_stride, ld1, (const unsigned short*)w2_planes, w2_plane_stride, ld2,
-                       d_hidden, (unsigned short*)((unsigned char*)image + offset_bytes), wave_bytes / 2);
+                       d_hidden, waves, (unsigned short*)((unsigned char*)image + offset_bytes), wave_bytes / 2);
     return gom_launch_status();
 }
 
@@ -662,8 +702,9 @@ extern "C" int gom_dec_tail2_f32(const float* S, int lds, const float* R, int ld
                                  const float* gamma, const float* beta, float eps, const float* c_inv1, const float* c_b1,
                                  const float* c_inv2, const float* c_b2, const float* W3, const float* b3, const float* ref,
                                  const float* dim_t128, const float* q_inv1, const float* q_b1, const float* q_inv2, const float* q_b2,
-                                 float* Y, int ldy, float* new_ref, float* qpos, int ldq, int M, int* flag, void* stream) {
+                                 float* Y, int ldy, float* new_ref, float* qpos, int ldq, int M, int waves, int* flag, void* stream) {
     const bool proj = R != nullptr;
+    GOM_CHECK_ARG(waves == 4 || waves == 8);
     GOM_CHECK_ARG(S && image && w1_inv_scale && b1 && w2_inv_scale && b2 && gamma && beta && c_inv1 && c_b1 && c_inv2 && c_b2 && W3 && b3 &&
                   ref && Y && new_ref);
     GOM_CHECK_ARG(!proj || (p_inv_scale && p_bias && p_gamma && p_beta && ldr >= D && (ldr % 4) == 0 && GOM_ALIGNED16(R) &&
@@ -676,7 +717,7 @@ extern "C" int gom_dec_tail2_f32(const float* S, int lds, const float* R, int ld
     GOM_CHECK_ARG(GOM_ALIGNED16(w1_inv_scale) && GOM_ALIGNED16(b1) && GOM_ALIGNED16(w2_inv_scale) && GOM_ALIGNED16(b2) &&
                   GOM_ALIGNED16(gamma) && GOM_ALIGNED16(beta) && GOM_ALIGNED16(c_inv1) && GOM_ALIGNED16(c_b1) && GOM_ALIGNED16(c_inv2) &&
                   GOM_ALIGNED16(c_b2) && GOM_ALIGNED16(W3));
-    GOM_CHECK_ARG(wave_bytes == gom_dec_tail2_wave_bytes(D, d_hidden, proj ? 1 : 0, qpos ? 1 : 0) && 4 * wave_bytes < (1L << 31));
+    GOM_CHECK_ARG(wave_bytes == gom_dec_tail2_wave_bytes(D, d_hidden, proj ? 1 : 0, qpos ? 1 : 0, waves) && waves * wave_bytes < (1L << 31));
     if (M == 0) return GOM_OK;
     T2Args a{};
     a.X = S; a.R = R; a.img = (const unsigned char*)image;
@@ -686,21 +727,26 @@ extern "C" int gom_dec_tail2_f32(const float* S, int lds, const float* R, int ld
     a.q_s1 = q_inv1; a.q_b1 = q_b1; a.q_s2 = q_inv2; a.q_b2 = q_b2;
     a.Y = Y; a.new_ref = new_ref; a.QP = qpos; a.flag = flag;
     a.ldx = lds; a.ldr = ldr; a.ldy = ldy; a.ldq = ldq; a.M = M; a.ffn_chunks = d_hidden / HC;
-    a.wave_stride = (unsigned)wave_bytes; a.img_bytes = (unsigned)(4 * wave_bytes);
-    const void* k[4] = {(const void*)dec_tail2_kernel<false, false>, (const void*)dec_tail2_kernel<true, false>,
-                        (const void*)dec_tail2_kernel<false, true>, (const void*)dec_tail2_kernel<true, true>};
-    for (int i = 0; i < 4; ++i) {
+    a.wave_stride = (unsigned)wave_bytes; a.img_bytes = (unsigned)(waves * wave_bytes);
+    const void* k[8] = {(const void*)dec_tail2_kernel<false, false, 4>, (const void*)dec_tail2_kernel<true, false, 4>,
+                        (const void*)dec_tail2_kernel<false, true, 4>, (const void*)dec_tail2_kernel<true, true, 4>,
+                        (const void*)dec_tail2_kernel<false, false, 8>, (const void*)dec_tail2_kernel<true, false, 8>,
+                        (const void*)dec_tail2_kernel<false, true, 8>, (const void*)dec_tail2_kernel<true, true, 8>};
+    for (int i = 0; i < 8; ++i) {
         hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return GOM_ERR_HIP_BASE + (int)e;
     }
-    const dim3 grid((unsigned)cdiv(M, RB)), block(256);
+    const dim3 grid((unsigned)cdiv(M, RB)), block(64 * waves);
     hipStream_t s = (hipStream_t)stream;
-    if (proj) {
-        if (qpos) hipLaunchKernelGGL((dec_tail2_kernel<true, true>), grid, block, LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((dec_tail2_kernel<false, true>), grid, block, LDS_BYTES, s, a);
-    } else {
-        if (qpos) hipLaunchKernelGGL((dec_tail2_kernel<true, false>), grid, block, LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((dec_tail2_kernel<false, false>), grid, block, LDS_BYTES, s, a);
+#define T2_LAUNCH(NW)                                                                                            \
+    if (proj) {                                                                                                  \
+        if (qpos) hipLaunchKernelGGL((dec_tail2_kernel<true, true, NW>), grid, block, LDS_BYTES, s, a);          \
+        else hipLaunchKernelGGL((dec_tail2_kernel<false, true, NW>), grid, block, LDS_BYTES, s, a);              \
+    } else {                                                                                                     \
+        if (qpos) hipLaunchKernelGGL((dec_tail2_kernel<true, false, NW>), grid, block, LDS_BYTES, s, a);         \
+        else hipLaunchKernelGGL((dec_tail2_kernel<false, false, NW>), grid, block, LDS_BYTES, s, a);             \
     }
+    if (waves == 8) { T2_LAUNCH(8) } else { T2_LAUNCH(4) }
+#undef T2_LAUNCH
     return gom_launch_status();
 }

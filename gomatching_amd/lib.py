@@ -88,11 +88,11 @@ SIGNATURES = {
     "gom_ffn_fused_image_acc_order": (I, [P, L, I, P, P, P, L, I, I, I, P, L, P]),
     "gom_dec_tail_image_bytes": (L, [I, I, I]),
     "gom_dec_tail_f32": (I, [P, I, P, I, P, P, P, P, F, P, P, P, P, P, P, P, P, P, I, P, P, I, I, P, P]),
-    "gom_dec_tail2_wave_bytes": (L, [I, I, I, I]),
-    "gom_dec_tail2_image_lin": (I, [P, L, I, P, L, L, P]),
-    "gom_dec_tail2_image_mlp": (I, [P, L, I, P, L, I, I, P, L, L, P]),
+    "gom_dec_tail2_wave_bytes": (L, [I, I, I, I, I]),
+    "gom_dec_tail2_image_lin": (I, [P, L, I, P, L, L, I, P]),
+    "gom_dec_tail2_image_mlp": (I, [P, L, I, P, L, I, I, P, L, L, I, P]),
     "gom_dec_tail2_f32": (I, [P, I, P, I, P, L, I, P, P, P, P, F, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, I, I,
-                              P, P]),
+                              I, P, P]),
     "gom_dec_tail_lin_image_bytes": (L, []),
     "gom_dec_tail_lin_image": (I, [P, L, I, P, L, P]),
     "gom_dec_tail_proj_f32": (I, [P, I, P, I, P, I, P, P, P, P, F, P, P, P, P, F, P, P, P, P, P, P, P, P, P, I, P, P, I, I, P, P]),

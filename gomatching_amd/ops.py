@@ -905,14 +905,16 @@ class DecTail:
     fragment-linear image of the FFN block, ctrl_point_coord's two hidden layers and ref_point_head (the latter two with their
     first weight in accumulator order), plus the vectors the three epilogues need."""
 
-    def __init__(self, ffn_w, coord_w, qpos_w, dim_t, eps=1e-5, proj_w=None, form=None):
+    def __init__(self, ffn_w, coord_w, qpos_w, dim_t, eps=1e-5, proj_w=None, form=None, waves=None):
         """proj_w = (out_proj weight [256, 256], bias, norm gain, norm bias) of the cross-attention block: the launch then starts from
         the sampled rows (`dec_tail(..., residual=tgt)`).  form 2 (default where the shapes allow, `DEC_TAIL2`): the CU-cooperative
-        kernel of csrc/dec_tail2.hip (80 rows per workgroup, the waves split the output columns); form 1: csrc/dec_tail.hip."""
+        kernel of csrc/dec_tail2.hip (80 rows per workgroup, the waves split the output columns; `waves` = 4, or 8 = two per SIMD:
+        `DEC_TAIL2_WAVES`); form 1: csrc/dec_tail.hip."""
         w1, b1, w2, b2, gamma, beta = ffn_w
         if form is None:
             form = 2 if (DEC_TAIL2 and w1.shape[0] % 128 == 0) else 1
         self.form = form
+        self.waves = int(waves) if waves is not None else DEC_TAIL2_WAVES
         if form == 2:
             self._init2(ffn_w, coord_w, qpos_w, dim_t, eps, proj_w)
             return
@@ -966,32 +968,34 @@ class DecTail:
         F_, D_ = w1.shape
         assert D_ == 256 and tuple(w2.shape) == (D_, F_) and tuple(W3.shape) == (2, 256) and F_ % 128 == 0
         L = _L()
-        self.wave_bytes = {q: L.gom_dec_tail2_wave_bytes(D_, F_, 1 if proj_w is not None else 0, q) for q in (0, 1)}
+        nw = self.waves
+        self.wave_bytes = {q: L.gom_dec_tail2_wave_bytes(D_, F_, 1 if proj_w is not None else 0, q, nw) for q in (0, 1)}
         if self.wave_bytes[1] < 0:
             raise _lib_mod.GomError("decoder tail kernel (form 2) does not serve d_model %d / d_hidden %d" % (D_, F_))
         wb = self.wave_bytes[1]
-        self.image = torch.empty((4 * wb,), dtype=torch.uint8, device=w1.device)
+        self.image = torch.empty((nw * wb,), dtype=torch.uint8, device=w1.device)
         off = 0
+        blk_bytes = (256 // nw) * 1024                            # a wave's share of a 256 -> 256 layer or of a chunk of 128 hidden units
         self.proj = None
         if proj_w is not None:
             wo, bo, pg, pb = proj_w
             assert tuple(wo.shape) == (256, 256)
             so = split_weight(wo.contiguous(), kind="f16x3")
-            check(L.gom_dec_tail2_image_lin(_p(so.planes), so.planes.stride(0), so.planes.stride(1), _p(self.image), wb, off, _stream()),
+            check(L.gom_dec_tail2_image_lin(_p(so.planes), so.planes.stride(0), so.planes.stride(1), _p(self.image), wb, off, nw, _stream()),
                   "gom_dec_tail2_image_lin")
-            off += 64 * 1024
+            off += blk_bytes
             self.proj = (so.inv_scale, bo.contiguous(), pg.contiguous(), pb.contiguous())
         keep = []
         for (wa, wb_), F_blk in (((w1, w2), F_), ((c1, c2), 256), ((q1, q2), 256)):
             sa, sb = split_weight(wa.contiguous(), kind="f16x3"), split_weight(wb_.contiguous(), kind="f16x3")
             check(L.gom_dec_tail2_image_mlp(_p(sa.planes), sa.planes.stride(0), sa.planes.stride(1), _p(sb.planes), sb.planes.stride(0),
-                                            sb.planes.stride(1), F_blk, _p(self.image), wb, off, _stream()), "gom_dec_tail2_image_mlp")
-            off += (F_blk // 128) * 64 * 1024
+                                            sb.planes.stride(1), F_blk, _p(self.image), wb, off, nw, _stream()), "gom_dec_tail2_image_mlp")
+            off += (F_blk // 128) * blk_bytes
             keep.append((sa.inv_scale, sb.inv_scale))
         assert off == wb
         # the last layer's image: the same streams without ref_point_head's part, packed at the shorter stride
         wb0 = self.wave_bytes[0]
-        self.image_last = self.image.view(4, wb)[:, :wb0].contiguous().view(-1)
+        self.image_last = self.image.view(nw, wb)[:, :wb0].contiguous().view(-1)
         (self.inv1, self.inv2), (self.c_inv1, self.c_inv2), (self.q_inv1, self.q_inv2) = keep
         self.b1, self.b2, self.gamma, self.beta = b1.contiguous(), b2.contiguous(), gamma.contiguous(), beta.contiguous()
         self.c_b1, self.c_b2, self.q_b1, self.q_b2 = cb1.contiguous(), cb2.contiguous(), qb1.contiguous(), qb2.contiguous()
@@ -999,6 +1003,7 @@ class DecTail:
 
 
 DEC_TAIL2 = _switch("DEC_TAIL2")            # ... as the CU-cooperative split-N kernel (csrc/dec_tail2.hip, round 6)
+DEC_TAIL2_WAVES = 8 if _switch("DEC_TAIL2_WAVES8") else 4   # ... with eight waves per workgroup (two per SIMD) or four
 DEC_TAIL_PROJ = _switch("DEC_TAIL_PROJ")    # ... with the cross-attention's out_proj + norm_cross in front of it
 
 
@@ -1055,7 +1060,7 @@ def dec_tail(x, blk, ref, want_qpos=True, residual=None):
                                      _p(pi), _p(pb), _p(pg), _p(pbe), blk.eps, _p(blk.inv1), _p(blk.b1), _p(blk.inv2), _p(blk.b2),
                                      _p(blk.gamma), _p(blk.beta), blk.eps, _p(blk.c_inv1), _p(blk.c_b1), _p(blk.c_inv2), _p(blk.c_b2),
                                      _p(blk.W3), _p(blk.b3), _p(ref), _p(blk.dim_t), _p(blk.q_inv1), _p(blk.q_b1), _p(blk.q_inv2),
-                                     _p(blk.q_b2), _p(out), 256, _p(new_ref), _p(qpos), 256, M, _p(range_flag(x.device)), _stream()),
+                                     _p(blk.q_b2), _p(out), 256, _p(new_ref), _p(qpos), 256, M, blk.waves, _p(range_flag(x.device)), _stream()),
               "gom_dec_tail2_f32")
     elif blk.proj is None:
         check(_L().gom_dec_tail_f32(_p(x), x.stride(0) if M > 1 else 256, _p(blk.image), blk.F, _p(blk.inv2), _p(blk.b2), _p(blk.gamma),

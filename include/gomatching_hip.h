@@ -370,24 +370,26 @@ int gom_dec_tail_proj_f32(const float* S, int lds, const float* R, int ldr, cons
 /* The same tail as a CU-COOPERATIVE launch (csrc/dec_tail2.hip, round 6): a workgroup's four waves share 80 rows (held in LDS as
  * MFMA operand fragments) and split the output columns; every wave streams its quarter of the weights straight from L2.  At the
  * decoder's M = 20 000 rows: 250 workgroups = one round of the chip (gom_dec_tail_*: 157 workgroups, two row groups on the busiest
- * SIMD).  `image` = four per-wave streams of `wave_bytes` each (gom_dec_tail2_wave_bytes), filled block by block at `offset_bytes`
+ * SIMD).  `image` = `waves` per-wave streams of `wave_bytes` each (gom_dec_tail2_wave_bytes), filled block by block at `offset_bytes`
  * inside every stream: [gom_dec_tail2_image_lin(out_proj)] | gom_dec_tail2_image_mlp(FFN) | ..._mlp(ctrl_point_coord layers 1-2) |
  * [..._mlp(ref_point_head)].  S / R / p_*: R == NULL = no out_proj block (S is then tgt behind norm_cross); qpos == NULL = the last
  * layer (image without ref_point_head's part).  *_inv1 / *_b1, *_inv2 / *_b2: inverse row scales (gom_split_f16x2) and biases of each
  * block's first / second weight.  Same f16x3 accuracy / range contract and *flag as gom_dec_tail_f32; the LayerNorm statistics are
- * combined from per-wave (mean, M2) pairs (Chan), so results agree with gom_dec_tail_* to rounding, not bit for bit. */
-long gom_dec_tail2_wave_bytes(int d_model, int d_hidden, int with_proj, int with_qpos);
+ * combined from per-wave (mean, M2) pairs (Chan), so results agree with gom_dec_tail_* to rounding, not bit for bit.
+ * `waves` = 4 (one wave per SIMD; a wave owns 64 output columns) or 8 (two per SIMD, 32 columns each: one wave's epilogues and
+ * activation phases under the other's MFMAs); the image is `waves` streams and belongs to the `waves` it was built for. */
+long gom_dec_tail2_wave_bytes(int d_model, int d_hidden, int with_proj, int with_qpos, int waves);
 int gom_dec_tail2_image_lin(const void* w_planes, long w_plane_stride, int ld, void* image, long wave_bytes, long offset_bytes,
-                            void* stream);
+                            int waves, void* stream);
 int gom_dec_tail2_image_mlp(const void* w1_planes, long w1_plane_stride, int ld1, const void* w2_planes, long w2_plane_stride, int ld2,
-                            int d_hidden, void* image, long wave_bytes, long offset_bytes, void* stream);
+                            int d_hidden, void* image, long wave_bytes, long offset_bytes, int waves, void* stream);
 int gom_dec_tail2_f32(const float* S, int lds, const float* R, int ldr, const void* image, long wave_bytes, int d_hidden,
                       const float* p_inv_scale, const float* p_bias, const float* p_gamma, const float* p_beta, float p_eps,
                       const float* w1_inv_scale, const float* b1, const float* w2_inv_scale, const float* b2, const float* gamma,
                       const float* beta, float eps, const float* c_inv1, const float* c_b1, const float* c_inv2, const float* c_b2,
                       const float* W3, const float* b3, const float* ref, const float* dim_t128, const float* q_inv1,
                       const float* q_b1, const float* q_inv2, const float* q_b2, float* Y, int ldy, float* new_ref, float* qpos,
-                      int ldq, int M, int* flag, void* stream);
+                      int ldq, int M, int waves, int* flag, void* stream);
 
 /* Split-K form for convolutions with few output tiles and a long K (input_proj[3]: 3x3 s2 2048 -> 256 on res5, M = 3584,
  * K = 18432): `splits` K-slices run as separate workgroups into workspace [splits][M][Cout] fp32, a second kernel sums

@@ -47,18 +47,23 @@ def _ref64(x, ffn, coord, qpos, ref, dim_t):
     return y, new_ref, q
 
 
-@pytest.mark.parametrize("form", [2, 1])
+def _fw(code):
+    """test parameter -> DecTail keywords: 1 = csrc/dec_tail.hip, 2 = csrc/dec_tail2.hip with four waves, 28 = with eight (two per SIMD)"""
+    return {"form": 1} if code == 1 else {"form": 2, "waves": 8 if code == 28 else 4}
+
+
+@pytest.mark.parametrize("form", [28, 2, 1])
 @pytest.mark.parametrize("M,F,want", [(1, 1024, True), (33, 1024, True), (128, 64, False), (129, 1024, True), (2500, 1024, False),
                                        (20000, 1024, True), (4097, 96, True), (79, 128, True), (80, 256, False), (161, 1024, True)])
 def test_dec_tail_vs_fp64_and_four_launches(M, F, want, form):
     from gomatching_amd import ops
-    if form == 2 and F % 128:
+    if form != 1 and F % 128:
         pytest.skip("form 2 takes the hidden layer in chunks of 128 (ops.DecTail falls back to form 1)")
     x, ffn, coord, qpos, ref, dim_t = _case(M, F, seed=M + F)
     dv = lambda t: t.to(DEV)
     blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
-                      form=form)
-    assert blk.form == form
+                      **_fw(form))
+    assert blk.form == _fw(form)["form"]
     y, nref, qp = ops.dec_tail(dv(x), blk, dv(ref), want_qpos=want)
     torch.cuda.synchronize()
     ops.check_range_flag(DEV)
@@ -81,7 +86,7 @@ def test_dec_tail_vs_fp64_and_four_launches(M, F, want, form):
 
 
 @pytest.mark.parametrize("proj", [False, True])
-@pytest.mark.parametrize("form", [2, 1])
+@pytest.mark.parametrize("form", [28, 2, 1])
 def test_dec_tail_rows_are_independent_of_the_launch(form, proj):
     """Batch invariance: a row's bits do not depend on what shares its launch (tile position, tail tile, launch length) -- with and
     without the out_proj block in front (whose residual the form-1 kernel parks in Y: ADVICE r5)."""
@@ -94,7 +99,7 @@ def test_dec_tail_rows_are_independent_of_the_launch(form, proj):
           0.1 * torch.randn((256,), generator=g))
     dv = lambda t: t.to(DEV)
     blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
-                      proj_w=tuple(dv(v) for v in pw) if proj else None, form=form)
+                      proj_w=tuple(dv(v) for v in pw) if proj else None, **_fw(form))
     run = (lambda a, b: ops.dec_tail(dv(samp[a:b]).contiguous(), blk, dv(ref[a:b]).contiguous(), residual=dv(x[a:b]).contiguous())) if proj \
         else (lambda a, b: ops.dec_tail(dv(x[a:b]).contiguous(), blk, dv(ref[a:b]).contiguous()))
     full = run(0, M)
@@ -104,20 +109,20 @@ def test_dec_tail_rows_are_independent_of_the_launch(form, proj):
             assert torch.equal(u[a:b], v)
 
 
-@pytest.mark.parametrize("form", [2, 1])
+@pytest.mark.parametrize("form", [28, 2, 1])
 def test_dec_tail_flags_an_activation_beyond_fp16(form):
     from gomatching_amd import lib, ops
     x, ffn, coord, qpos, ref, dim_t = _case(64, 1024, seed=1, xscale=1e5)
     dv = lambda t: t.to(DEV)
     blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
-                      form=form)
+                      **_fw(form))
     ops.dec_tail(dv(x), blk, dv(ref))
     torch.cuda.synchronize()
     with pytest.raises(lib.GomError):
         ops.check_range_flag(DEV)
 
 
-@pytest.mark.parametrize("form", [2, 1])
+@pytest.mark.parametrize("form", [28, 2, 1])
 @pytest.mark.parametrize("M,want", [(1, True), (130, False), (2500, True), (20000, True)])
 def test_dec_tail_with_out_proj_in_front(M, want, form):
     """The launch that also takes the cross attention's out_proj + residual + norm_cross (deformable_transformer.py:406-422):
@@ -130,7 +135,7 @@ def test_dec_tail_with_out_proj_in_front(M, want, form):
     pg, pb = 1.0 + 0.2 * torch.randn((256,), generator=g), 0.1 * torch.randn((256,), generator=g)
     dv = lambda t: t.to(DEV)
     blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
-                      proj_w=(dv(wo), dv(bo), dv(pg), dv(pb)), form=form)
+                      proj_w=(dv(wo), dv(bo), dv(pg), dv(pb)), **_fw(form))
     y, nref, qp = ops.dec_tail(dv(samp), blk, dv(ref), want_qpos=want, residual=dv(x))
     torch.cuda.synchronize()
     ops.check_range_flag(DEV)

@@ -1,5 +1,6 @@
 """Schedule variants of csrc/dec_tail2.hip, built as stand-alone libraries from the same source with -D knobs and timed against
-each other (and against form 1) in alternating bursts on one GPU at the decoder's shape.
+each other (and against form 1) in alternating bursts on one GPU at the decoder's shape.  WAVES=4|8 (environment, default 8): waves
+per workgroup of the launches.
     python tools/dec_tail2_variants.py --build [name=flags ...]   (here: cross-compiles tools/exp/libdt2_<name>.so)
     python tools/dec_tail2_variants.py [M]                        (GPU box)"""
 import ctypes
@@ -42,7 +43,13 @@ def main():
           dv(0.1 * torch.randn((256,), generator=g)))
     mk = lambda form, proj: ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos],
                                         dv(dim_t), proj_w=pw if proj else None, form=form)
-    b1, b2 = mk(1, True), mk(2, True)
+    b1 = mk(1, True)
+    blocks = {4: ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
+                             proj_w=pw, form=2, waves=4),
+              8: ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
+                             proj_w=pw, form=2, waves=8)}
+    WAVES = int(os.environ.get("WAVES", 8))
+    b2 = blocks[WAVES]
     X, R = dv(x), dv(ref)
     want = ops.dec_tail(samp, b1, R, want_qpos=True, residual=X)
     libs = {}
@@ -60,7 +67,7 @@ def main():
         rc = lib.gom_dec_tail2_f32(p(samp), 256, p(X), 256, p(blk.image), blk.wave_bytes[1], blk.F, p(pi), p(pb), p(pg), p(pbe), blk.eps,
                                    p(blk.inv1), p(blk.b1), p(blk.inv2), p(blk.b2), p(blk.gamma), p(blk.beta), blk.eps, p(blk.c_inv1),
                                    p(blk.c_b1), p(blk.c_inv2), p(blk.c_b2), p(blk.W3), p(blk.b3), p(R), p(blk.dim_t), p(blk.q_inv1),
-                                   p(blk.q_b1), p(blk.q_inv2), p(blk.q_b2), p(out), 256, p(nref), p(qp), 256, M, p(flag), ops._stream())
+                                   p(blk.q_b1), p(blk.q_inv2), p(blk.q_b2), p(out), 256, p(nref), p(qp), 256, M, blk.waves, p(flag), ops._stream())
         assert rc == 0, rc
 
     def burst(fn, n=20):
@@ -87,7 +94,7 @@ def main():
         except AttributeError:
             continue
         nwg = (M + 79) // 80
-        st = torch.zeros((nwg, 4, 16), dtype=torch.int64, device="cuda")
+        st = torch.zeros((nwg, WAVES, 16), dtype=torch.int64, device="cuda")
         lib.gom_dec_tail2_set_stamps.argtypes = [ctypes.c_void_p]
         run(lib)
         torch.cuda.synchronize()
@@ -99,7 +106,7 @@ def main():
         names = ["prologue", "proj loop", "proj epilogue", "FFN loop", "FFN epilogue", "coord loop", "coord epilogue + sine", "qpos loop", "end"]
         med = t[:, :, :9].median(dim=0).values            # [wave][slot]
         print("%s: cycles since the wave's start (median over workgroups), per wave" % name)
-        prev = torch.zeros(4, dtype=torch.float64, device="cuda")
+        prev = torch.zeros(WAVES, dtype=torch.float64, device="cuda")
         for i, nm in enumerate(names):
             print("  %-24s %s   (+%s)" % (nm, ["%7.0f" % v for v in med[:, i].tolist()], ["%6.0f" % v for v in (med[:, i] - prev).tolist()]))
             prev = med[:, i]

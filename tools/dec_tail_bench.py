@@ -14,7 +14,8 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 x, ffn, coord, qpos, ref, dim_t = _case(M, 1024, seed=3)
 dv = lambda t: t.to("cuda")
 blk = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t), form=1)
-blk2 = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t), form=2)
+blk2 = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t), form=2, waves=4)
+blk8 = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t), form=2, waves=8)
 f = ops.FusedFFN(*[dv(v) for v in ffn])
 c = ops.FusedMLP2(dv(coord[0][0]), dv(coord[0][1]), dv(coord[1][0]), dv(coord[1][1]), True)
 q = ops.FusedMLP2(dv(qpos[0][0]), dv(qpos[0][1]), dv(qpos[1][0]), dv(qpos[1][1]), False)
@@ -42,7 +43,9 @@ pg, pb = dv(1.0 + 0.2 * torch.randn((256,), generator=g)), dv(0.1 * torch.randn(
 blk_p = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
                     proj_w=(wo, bo, pg, pb), form=1)
 blk_p2 = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
-                     proj_w=(wo, bo, pg, pb), form=2)
+                     proj_w=(wo, bo, pg, pb), form=2, waves=4)
+blk_p8 = ops.DecTail(tuple(dv(v) for v in ffn), [(dv(w), dv(b)) for w, b in coord], [(dv(w), dv(b)) for w, b in qpos], dv(dim_t),
+                     proj_w=(wo, bo, pg, pb), form=2, waves=8)
 pl = ops.proj_ln_block((ops.prep_weight(wo), bo), (pg, pb))
 
 
@@ -69,6 +72,18 @@ def one2_proj():
     return ops.dec_tail(samp, blk_p2, R, want_qpos=True, residual=X)
 
 
+def one8():
+    return ops.dec_tail(X, blk8, R, want_qpos=True)
+
+
+def one8_last():
+    return ops.dec_tail(X, blk8, R, want_qpos=False)
+
+
+def one8_proj():
+    return ops.dec_tail(samp, blk_p8, R, want_qpos=True, residual=X)
+
+
 def ffn_only():
     return ops.ffn_fused_ln(X, f)
 
@@ -89,9 +104,13 @@ print("max |d| tgt %.2e ref %.2e qpos %.2e" % tuple(float((u - v).abs().max()) f
 b2 = one2()
 print("form 2 vs form 1: max |d| tgt %.2e ref %.2e qpos %.2e" % tuple(float((u - v).abs().max()) for u, v in zip(b, b2)))
 print("form 2 vs form 1 with out_proj: max |d| tgt %.2e ref %.2e qpos %.2e" % tuple(float((u - v).abs().max()) for u, v in zip(one_proj(), one2_proj())))
+print("form 2, eight waves vs four: max |d| tgt %.2e ref %.2e qpos %.2e | with out_proj %.2e %.2e %.2e" % (
+    tuple(float((u - v).abs().max()) for u, v in zip(b2, one8())) + tuple(float((u - v).abs().max()) for u, v in zip(one2_proj(), one8_proj()))))
 for rnd in range(4):
     print("round %d  M = %d: four launches %.1f us | one launch %.1f us | one launch, last layer (no qpos) %.1f us | fused FFN alone %.1f us"
           " || with out_proj + norm_cross: five launches %.1f us | one launch %.1f us"
           % (rnd, M, burst(four), burst(one), burst(one_last), burst(ffn_only), burst(five), burst(one_proj)), flush=True)
     print("         form 2 (csrc/dec_tail2.hip): one launch %.1f us | last layer %.1f us | with out_proj + norm_cross %.1f us"
           % (burst(one2), burst(one2_last), burst(one2_proj)), flush=True)
+    print("         form 2, EIGHT waves (two per SIMD): one launch %.1f us | last layer %.1f us | with out_proj + norm_cross %.1f us"
+          % (burst(one8), burst(one8_last), burst(one8_proj)), flush=True)
