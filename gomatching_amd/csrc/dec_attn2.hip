@@ -540,8 +540,20 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
         __builtin_amdgcn_sched_barrier(0);
         {
             // (stage 8 sits in slot 2, stage 9 in slot 0; slot 1 held stage 7 and is free until stage 8 requests stage 10 into it)
+            // only query_pos is loaded: tgt comes back from its own fragments (hi + lo: the 22-bit value every product of sweep 1
+            // saw) -- half the lines for the texture-address unit, which bounds eight waves loading at once
             float* scratch = reinterpret_cast<float*>(smem + 1 * CHUNK_BYTES) + wave * (16 * 64);
-            rows16_to_fragments<true>(xrow, prow, scratch, lane, xf, amax, [&]() {});
+            rows16_stream<false>(prow, prow, scratch, lane, [&]() {}, [&](const int s, const f32x4 a, const f32x4 b) {
+                f32x4 xa, xb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xa[e] = ((float)xf[0][s][e] + (float)xf[1][s][e]) + a[e];
+                    xb[e] = ((float)xf[0][s][4 + e] + (float)xf[1][s][4 + e]) + b[e];
+                    amax = fmaxf(amax, fmaxf(fabsf(xa[e]), fabsf(xb[e])));
+                }
+                gom_split8_f16(xa, xb, xf[0][s], xf[1][s]);
+            });
+            asm volatile("" : "+v"(amax));
         }
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
