@@ -58,11 +58,13 @@ __device__ __forceinline__ void gom_split2_f16(float x, float y, unsigned int& h
 // the wave, so the first counted wait of the kernel covers them.  Decoder launches only (one round of one-per-CU workgroups, 200-250 of
 // them): in the encoder's and the backbone's row-resident kernels -- nine or more rounds, the image cold for the first only -- the
 // same call measured -0.5 % frames/s (same box, three alternating pairs) and is not made.
-// K loads per lane, unconditional (addresses clamped) and unrolled: the compiler can then COUNT them -- behind a loop of unknown length
-// or a branch it waits for every outstanding load at the next use of any loaded value, and the rows of the prologue would wait for the
-// image's lines (the counter is in order).  K x nthreads lines per workgroup are covered; a launch of few workgroups covers less.
+// K loads per lane, unconditional (addresses clamped), unrolled and ORDINARY: the compiler then counts them like any other load.  (A
+// loop of unknown length or a branch makes it wait for every outstanding load at the next use of any loaded value; a `volatile` load is
+// followed by a wait for ALL of them on the spot -- either way the prologue's rows wait for the image's lines, +7k cycles.)  The
+// values land in pf[]; gom_prefetch_done(pf) -- a use that generates no code -- goes where the kernel has to wait for its first
+// loads anyway.  K x nthreads lines per workgroup are covered; a launch of few workgroups covers less.
 template <int K>
-__device__ __forceinline__ void gom_prefetch_image(const void* img, unsigned bytes, unsigned tid, unsigned nthreads) {
+__device__ __forceinline__ void gom_prefetch_image(const void* img, unsigned bytes, unsigned tid, unsigned nthreads, unsigned (&pf)[K]) {
     const unsigned first = gridDim.x < 256u ? gridDim.x : 256u;
     const unsigned nsl = (first + 7) / 8, sl = (blockIdx.x < first ? blockIdx.x : 0u) / 8;
     const unsigned lines = bytes / 128;
@@ -73,8 +75,13 @@ __device__ __forceinline__ void gom_prefetch_image(const void* img, unsigned byt
         l = l < per ? l : per - 1;
         unsigned line = sl * per + l;
         line = line < lines ? line : lines - 1;
-        (void)*reinterpret_cast<const volatile unsigned*>(reinterpret_cast<const unsigned char*>(img) + (size_t)line * 128);
+        pf[k] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(img) + (size_t)line * 128);
     }
+}
+template <int K>
+__device__ __forceinline__ void gom_prefetch_done(const unsigned (&pf)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) asm volatile("" ::"v"(pf[k]));
 }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

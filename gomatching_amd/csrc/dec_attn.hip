@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
         row = (b * p.G + tq) * p.inner + pp;
     }
 
-    gom_prefetch_image<2>(p.img, (unsigned)(NST * CHUNK_BYTES), tid, 256);                  // (common.h: a one-round launch, the image cold)
+    unsigned pf[2];
+    gom_prefetch_image(p.img, (unsigned)(NST * CHUNK_BYTES), tid, 256, pf);                 // (common.h: a one-round launch, the image cold)
     const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, NST * CHUNK_BYTES, 0x00020000);
     constexpr unsigned OOB = 0x7FFF0000u;                    // beyond num_records: the DMA writes zeros (into an unused stage)
     const unsigned lane16 = lane * 16;
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_kernel(const DecArgs p) {
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gom_prefetch_done(pf);
     __syncthreads();
 
     // per stage: `base` = this lane's slice of the stage in the ring, `nsrc` / `ndst` = this wave's fragments of the next one

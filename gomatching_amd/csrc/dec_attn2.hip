@@ -323,6 +323,7 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
     half8 xf[2][8];
     auto xrow = [&](int r) { return p.X + (size_t)slot_row(r) * p.ldx; };
     auto prow = [&](int r) { return p.P + (size_t)slot_row(r) * p.ldp; };
+    unsigned pf[1];
     {
         // the ring's first two stages and the epilogue vectors are requested behind the first loads, slot 2 is the scratch
         float* scratch = reinterpret_cast<float*>(smem + 2 * CHUNK_BYTES) + wave * (16 * 64);
@@ -332,10 +333,11 @@ __global__ __launch_bounds__(512, 1) void dec_attn2_kernel(const DecArgs2 p) {
             // the whole image towards this XCD's L2 (common.h gom_prefetch_image): between the layers of a step it (1.1 - 1.5 MB, last
             // read a step ago) is in HBM, and the ring's two stages of lookahead do not cover a miss per stage (tools/
             // dec_attn2_variants.py, a 768 MB fill in front of every launch: inter + raw 76 -> 99 us, 88 with this)
-            gom_prefetch_image<1>(p.img, (unsigned)(VEC_BYTES + NST * CHUNK_BYTES), tid, 512);
+            gom_prefetch_image(p.img, (unsigned)(VEC_BYTES + NST * CHUNK_BYTES), tid, 512, pf);
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gom_prefetch_done(pf);
     __syncthreads();
     A2_T(0)
 

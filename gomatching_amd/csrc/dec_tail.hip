@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256, 1) void dec_tail_kernel(const TailArgs p) {
     constexpr int C0 = WITH_PROJ ? LIN_STAGES : 0;           // stages of the out_proj block in front of the FFN's
     const int total_chunks = C0 + p.ffn_chunks + MLP_CHUNKS + (WITH_QPOS ? MLP_CHUNKS : 0);
 
-    gom_prefetch_image<4>(p.img, (unsigned)(total_chunks * STAGE_BYTES), tid, 256);         // (common.h: a one-round launch, the image cold)
+    unsigned pf[4];
+    gom_prefetch_image(p.img, (unsigned)(total_chunks * STAGE_BYTES), tid, 256, pf);        // (common.h: a one-round launch, the image cold)
     const __amdgpu_buffer_rsrc_t rs_img =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, total_chunks * STAGE_BYTES, 0x00020000);
     auto dma_stage = [&](int c, int stage) {
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256, 1) void dec_tail_kernel(const TailArgs p) {
 
     f32x4 acc2[D / 16][2];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gom_prefetch_done(pf);
     __syncthreads();
 
     float hmax = 0.f;

@@ -214,6 +214,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dec_tail2_kernel(const T2Args p) {
     //      instruction of eight whole 128-byte lines (lane: row l & 7, 16-byte piece l >> 3) and two 8-byte LDS stores per lane ----
     {
         f32x4 v[UPW];
+        unsigned pf[NW == 8 ? 2 : 4];
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
             const int u = wave * UPW + i, rb = u >> 3, part = u & 7;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dec_tail2_kernel(const T2Args p) {
         // the whole image (3.4 MB) towards this XCD's L2: a weight group that misses stalls its wave for the trip to HBM.  BEHIND the
         // row loads (the vector-memory counter is in order: in front of them the rows wait for the image's lines, +7k cycles)
         __builtin_amdgcn_sched_barrier(0);
-        gom_prefetch_image<(NW == 8 ? 2 : 4)>(p.img, p.img_bytes, tid, 64 * NW);
+        gom_prefetch_image(p.img, p.img_bytes, tid, 64 * NW, pf);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dec_tail2_kernel(const T2Args p) {
             *reinterpret_cast<u32x2*>(dst + FRAG) = u32x2{l0, l1};
         }
         asm volatile("" : "+v"(amax));
+        gom_prefetch_done(pf);
     }
     T2_BARRIER_LDS();
     T2_STAMP(0)

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
     // alternating runs): this kernel 575 -> 572 us per launch on average, proj_ln.hip 96 -> 92 us; in a loop of its own launches
     // the kernel gains 10 % (1046 -> 944 us at M = 297k), which the step does not see.
     // a one-round launch (the decoder's two-layer perceptrons): the image, cold between the layers of a step, towards L2 first
-    if (gridDim.x <= 256) gom_prefetch_image<2>(p.img, (unsigned)(p.chunks * STAGE_BYTES), tid, 256);
+    unsigned pf[2] = {0u, 0u};
+    if (gridDim.x <= 256) gom_prefetch_image(p.img, (unsigned)(p.chunks * STAGE_BYTES), tid, 256, pf);
     if (p.stagger > 0 && blockIdx.x < 256)
         for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     const __amdgpu_buffer_rsrc_t rs_img =
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnArgs p) {
         for (int r = 0; r < RG; ++r) acc2[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gom_prefetch_done(pf);
     __syncthreads();
 
     float hmax = 0.f;                                        // largest hidden activation of this lane's rows
