@@ -96,9 +96,9 @@ intra = ops.DecAttnBlock(in_w, in_b, wo, bo, ones, zeros, False)
 inter = ops.DecAttnBlock(in_w, in_b, wo, bo, ones, zeros, True, raw=(rw, rb))
 pos = dv(torch.randn((Q, 256), generator=g))
 run("dec intra-instance block (in_proj, 8 x 32 attention over 25 points, out_proj, norm: one launch)",
-    lambda: ops.dec_attn(X, intra, 800, 25, pos=pos), 2.0 * Q * 256 * 1024, "dec_attn_kernel")
+    lambda: ops.dec_attn(X, intra, 800, 25, pos=pos), 2.0 * Q * 256 * 1024, "dec_attn2_kernel" if intra.form == 2 else "dec_attn_kernel")
 run("dec inter-instance block + cross offsets|logits (one launch)",
-    lambda: ops.dec_attn(X, inter, 200, 100, inner=25, raw_pos=pos), 2.0 * Q * 256 * (1024 + 384), "dec_attn_kernel")
+    lambda: ops.dec_attn(X, inter, 200, 100, inner=25, raw_pos=pos), 2.0 * Q * 256 * (1024 + 384), "dec_attn2_kernel" if inter.form == 2 else "dec_attn_kernel")
 del samp, X, R, pos
 k1, c4, mp, hw = 256, 1024, 256, (63, 112)
 a = dv(torch.randn(8, hw[0], hw[1], k1, generator=g).abs())

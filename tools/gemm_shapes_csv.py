@@ -7,7 +7,7 @@ trace, order = sys.argv[1], json.load(open(sys.argv[2]))
 out = sys.argv[3] if len(sys.argv) > 3 else "profiles/r02_gemm_shapes.csv"
 rows = [r for r in csv.DictReader(open(trace))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-names = ("gemm_f16x3_kernel", "gemm_k256_kernel", "proj_ln_kernel", "proj_ln2_kernel", "ffn_fused_kernel", "dec_tail_kernel", "dec_tail2_kernel", "dec_attn_kernel",
+names = ("gemm_f16x3_kernel", "gemm_k256_kernel", "proj_ln_kernel", "proj_ln2_kernel", "ffn_fused_kernel", "dec_tail_kernel", "dec_tail2_kernel", "dec_attn_kernel", "dec_attn2_kernel",
          "bneck2_kernel")
 launches = []
 for r in rows:
