@@ -69,9 +69,20 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.gom_tracker_create(0, 0.2, 1, 1, 1, 1.0, None, 0, None, 0, 1024, 8, 1024) is None           # test_len < 1
     assert L.gom_tracker_create(6, 0.2, 1, 1, 1, 1.0, None, 1, None, 0, 1024, 8, 1024) is None           # layers without weights
     # round 6: the CU-cooperative decoder tail
-    assert L.gom_dec_tail2_wave_bytes(256, 1024, 1, 1) == (64 + 12 * 64) * 1024 and L.gom_dec_tail2_wave_bytes(256, 1000, 1, 1) == -1
-    assert L.gom_dec_tail2_image_lin(p, 1, 128, p, 1 << 20, 0, None) == INVALID                          # ld < 256
-    assert L.gom_dec_tail2_image_mlp(p, 1, 256, p, 1, 256, 192, p, 1 << 20, 0, None) == INVALID           # hidden % 128 != 0
+    assert L.gom_dec_tail2_wave_bytes(256, 1024, 1, 1, 4) == (64 + 12 * 64) * 1024 and L.gom_dec_tail2_wave_bytes(256, 1000, 1, 1, 4) == -1
+    assert L.gom_dec_tail2_wave_bytes(256, 1024, 1, 1, 8) == (32 + 12 * 32) * 1024 and L.gom_dec_tail2_wave_bytes(256, 1024, 1, 1, 6) == -1   # 4 or 8 waves
+    assert L.gom_dec_tail2_image_lin(p, 1, 128, p, 1 << 20, 0, 8, None) == INVALID                       # ld < 256
+    assert L.gom_dec_tail2_image_lin(p, 1, 256, p, 1 << 20, 0, 5, None) == INVALID                       # waves
+    assert L.gom_dec_tail2_image_mlp(p, 1, 256, p, 1, 256, 192, p, 1 << 20, 0, 8, None) == INVALID        # hidden % 128 != 0
+    # round 6: the self-attention blocks on 16-token waves (same contract as gom_dec_attn_*)
+    assert L.gom_dec_attn2_image_bytes(256, 8) == (4 + 32 * 33) * 1024 and L.gom_dec_attn2_image_bytes(128, 8) == -1
+    assert L.gom_dec_attn2_raw_image_bytes() == (4 + 44 * 33) * 1024
+    assert L.gom_dec_attn2_image(p, 1, 128, p, p, p, 1, 256, p, p, p, p, 0, p, 1 << 22, None) == INVALID    # ld_in < 256
+    assert L.gom_dec_attn2_image(p, 1, 256, p, p, p, 1, 256, p, p, p, p, 0, p, 1024, None) == INVALID       # image too small
+    assert L.gom_dec_attn2_f32(p, 256, None, 0, p, 1e-5, p, 256, 4, 25, 1, 0, None, None) == INVALID        # intra without query_pos
+    assert L.gom_dec_attn2_f32(p, 256, p, 256, p, 1e-5, p, 256, 4, 33, 1, 0, None, None) == INVALID         # > 32 points
+    assert L.gom_dec_attn2_f32(p, 256, None, 0, p, 1e-5, p, 256, 4, 129, 25, 1, None, None) == INVALID      # > 128 queries
+    assert L.gom_dec_attn2_raw_f32(p, 256, p, 1e-5, p, 256, p, 256, p, 380, 4, 100, 25, None, None) == INVALID   # ldraw < 384
 
 
 def test_library_has_no_packed_fp32_instructions():
