@@ -174,3 +174,31 @@ def test_inter_block_with_offsets_and_logits_behind_it(B, nq, P, form):
     two = ops.linear(want, lin, A2=qd)
     assert float((raw - two).abs().max()) < 2e-5
     ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
+
+
+@pytest.mark.parametrize("form", FORMS)
+def test_blocks_do_not_depend_on_what_shares_the_launch(form):
+    """Batch invariance (a tracker property: the same query gives the same bits whatever else is in the clip): a group's output is
+    the same in a launch of many groups as in a launch of its own -- both forms, both blocks, the RAW form's second output too."""
+    from gomatching_amd import ops
+    g = torch.Generator().manual_seed(17)
+    w = _weights(4)
+    # intra: 37 groups of 25 points; groups 8 .. 11 alone (a whole workgroup of the eight-wave form) and group 36 alone (a tail workgroup)
+    x, pos = torch.randn(37 * 25, 256, generator=g).to(DEV), (torch.randn(37 * 25, 256, generator=g) * 0.7).to(DEV)
+    blk = _block(ops, w, False, form)
+    full = ops.dec_attn(x, blk, 37, 25, pos=pos)
+    for g0, n in ((8, 4), (36, 1), (5, 1)):
+        sub = ops.dec_attn(x[g0 * 25:(g0 + n) * 25].contiguous(), blk, n, 25, pos=pos[g0 * 25:(g0 + n) * 25].contiguous())
+        assert torch.equal(sub, full[g0 * 25:(g0 + n) * 25]), (g0, n)
+    # inter (+ offsets | logits): 3 frames x 100 queries x 5 points; frame 1 alone
+    B, nq, P = 3, 100, 5
+    x, qpos = torch.randn(B * nq * P, 256, generator=g).to(DEV), (torch.randn(B * nq * P, 256, generator=g) * 0.7).to(DEV)
+    rw = (torch.randn(384, 256, generator=g) / 16).to(DEV)
+    rb = (torch.randn(384, generator=g) * 0.1).to(DEV)
+    d = [t.to(DEV) for t in w]
+    blk = ops.DecAttnBlock(d[0], d[1], d[2], d[3], d[4], d[5], True, raw=(rw, rb), form=form)
+    out, raw = ops.dec_attn(x, blk, B * P, nq, inner=P, raw_pos=qpos)
+    one = slice(nq * P, 2 * nq * P)
+    o1, r1 = ops.dec_attn(x[one].contiguous(), blk, P, nq, inner=P, raw_pos=qpos[one].contiguous())
+    assert torch.equal(o1, out[one]) and torch.equal(r1, raw[one])
+    ops.check_range_flag(torch.device(DEV, torch.cuda.current_device()))
