@@ -122,6 +122,15 @@ __global__ __launch_bounds__(256) void msda_prep_kernel(const float* __restrict_
 // sampling-location arithmetic and the bilinear gather in ONE pass over the [Q, 384] offsets|logits rows, so
 // the [Q,8,4,4,2] locations and [Q,8,4,4] weights never exist in HBM (saves 3 x 457 MB of traffic per
 // encoder call at 8 x 37 171 tokens and one launch).  Same lane mapping as msda_fwd_kernel.
+// acc += w * v, one fused multiply-add per channel.  The fused kernels below accumulate a sample as FOUR of these with the corner
+// weights already multiplied by the sample's attention weight (round 6: at the sample's owner, once) -- 16 vector instructions per
+// sample and lane where (w1 v1 + w2 v2 + w3 v3 + w4 v4) * w (ms_deform_im2col's order, kept by msda_fwd_kernel) takes 20 and one
+// more broadcast.  The same sequence in every fused kernel: they stay bit-identical to one another.
+__device__ __forceinline__ void msda_fma4(f32x4& acc, const float w, const f32x4 v) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = fmaf(w, v[c], acc[c]);
+}
+
 template <int POINTS, bool HAS_VR>
 __global__ __launch_bounds__(256) void msda_fused_kernel(const float* __restrict__ value,
                                                          const int64_t* __restrict__ shapes,
@@ -198,13 +207,15 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float* __restrict
             const f32x4 v2 = *reinterpret_cast<const f32x4*>(vl + (r0 + xc1) * v_rs);
             const f32x4 v3 = *reinterpret_cast<const f32x4*>(vl + (r1 + xc0) * v_rs);
             const f32x4 v4 = *reinterpret_cast<const f32x4*>(vl + (r1 + xc1) * v_rs);
-            float ww = inside ? w : 0.f;
-            float w1 = (y0 && x0) ? hh * hw : 0.f, w2 = (y0 && x1) ? hh * lw : 0.f;
-            float w3 = (y1 && x0) ? lh * hw : 0.f, w4 = (y1 && x1) ? lh * lw : 0.f;
+            const float ww = inside ? w : 0.f;
+            float w1 = ((y0 && x0) ? hh * hw : 0.f) * ww, w2 = ((y0 && x1) ? hh * lw : 0.f) * ww;
+            float w3 = ((y1 && x0) ? lh * hw : 0.f) * ww, w4 = ((y1 && x1) ? lh * lw : 0.f) * ww;
             // opaque to the optimiser: otherwise it re-creates a branch around every load whose weight may be zero
-            asm volatile("" : "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(ww));
-            const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-            acc += val * ww;
+            asm volatile("" : "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4));
+            msda_fma4(acc, w1, v1);
+            msda_fma4(acc, w2, v2);
+            msda_fma4(acc, w3, v3);
+            msda_fma4(acc, w4, v4);
         }
     }
     *reinterpret_cast<f32x4*>(out + (size_t)q_global * (HEADS * CH) + m * CH + c4) = acc;
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __re
     const float Hf = (float)H, Wf = (float)W;
     const float rW = 1.f / Wf, rH = 1.f / Hf;
     const unsigned lvl = (unsigned)lsi[l];
-    float sw1[2], sw2[2], sw3[2], sw4[2], sww[2];
+    float sw1[2], sw2[2], sw3[2], sw4[2];                    // corner weights x the sample's attention weight
     unsigned so1[2], so2[2], so3[2], so4[2];                 // BYTE offsets of the four corners' head slice in the batch image
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -304,11 +315,11 @@ __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __re
         so2[t] = (r0 + xc1) * (unsigned)v_rs * 4u + head;
         so3[t] = (r1 + xc0) * (unsigned)v_rs * 4u + head;
         so4[t] = (r1 + xc1) * (unsigned)v_rs * 4u + head;
-        sww[t] = inside ? w : 0.f;
-        sw1[t] = (y0 && x0) ? hh * hw : 0.f;
-        sw2[t] = (y0 && x1) ? hh * lw : 0.f;
-        sw3[t] = (y1 && x0) ? lh * hw : 0.f;
-        sw4[t] = (y1 && x1) ? lh * lw : 0.f;
+        const float ww = inside ? w : 0.f;
+        sw1[t] = ((y0 && x0) ? hh * hw : 0.f) * ww;
+        sw2[t] = ((y0 && x1) ? hh * lw : 0.f) * ww;
+        sw3[t] = ((y1 && x0) ? lh * hw : 0.f) * ww;
+        sw4[t] = ((y1 && x1) ? lh * lw : 0.f) * ww;
     }
 
     // ---- gather part: every lane, all 16 samples, 4 channels ----
@@ -327,10 +338,11 @@ __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __re
         const f32x4 v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a2, 0, 0));
         const f32x4 v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a3, 0, 0));
         const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a4, 0, 0));
-        const float w1 = group8_read(sw1[t], o), w2 = group8_read(sw2[t], o), w3 = group8_read(sw3[t], o),
-                    w4 = group8_read(sw4[t], o), ww = group8_read(sww[t], o);
-        const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-        acc += val * ww;
+        const float w1 = group8_read(sw1[t], o), w2 = group8_read(sw2[t], o), w3 = group8_read(sw3[t], o), w4 = group8_read(sw4[t], o);
+        msda_fma4(acc, w1, v1);
+        msda_fma4(acc, w2, v2);
+        msda_fma4(acc, w3, v3);
+        msda_fma4(acc, w4, v4);
     }
     *reinterpret_cast<f32x4*>(out + (size_t)q_global * (HEADS * CH) + m * CH + k * 4) = acc;
 }
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
     // ---- owner part of every octet group: the lane-distributed kernel's, plus the window test and the LDS address ----
     // (straight-line code over the ITERS groups: no branch in here or in the level loops, so that the scheduler can overlap the
     // groups' loads, swizzles and LDS reads -- a wave has at most one partner on its SIMD to hide latency behind)
-    float sw1[ITERS][2], sw2[ITERS][2], sw3[ITERS][2], sw4[ITERS][2], sww[ITERS][2];
+    float sw1[ITERS][2], sw2[ITERS][2], sw3[ITERS][2], sw4[ITERS][2];   // corner weights x the sample's attention weight
     unsigned pk[ITERS][2];                                   // LDS byte address of corner (yc0, xc0) | dx << 20 | dy << 21
     unsigned go1[GLV ? ITERS : 1][2], go2[GLV ? ITERS : 1][2], go3[GLV ? ITERS : 1][2], go4[GLV ? ITERS : 1][2];   // GLV: global corner offsets
     f32x4 acc[ITERS];
@@ -482,11 +494,11 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
         SO##2 = (r0 + xc1) * (unsigned)v_rs * 4u + head;                                                          \
         SO##3 = (r1 + xc0) * (unsigned)v_rs * 4u + head;                                                          \
         SO##4 = (r1 + xc1) * (unsigned)v_rs * 4u + head;                                                          \
-        sww[IT][T] = inside ? w : 0.f;                                                                            \
-        sw1[IT][T] = (y0 && x0) ? hh * hw : 0.f;                                                                  \
-        sw2[IT][T] = (y0 && x1) ? hh * lw : 0.f;                                                                  \
-        sw3[IT][T] = (y1 && x0) ? lh * hw : 0.f;                                                                  \
-        sw4[IT][T] = (y1 && x1) ? lh * lw : 0.f;                                                                  \
+        const float ww_ = inside ? w : 0.f;                                                                       \
+        sw1[IT][T] = ((y0 && x0) ? hh * hw : 0.f) * ww_;                                                          \
+        sw2[IT][T] = ((y0 && x1) ? hh * lw : 0.f) * ww_;                                                          \
+        sw3[IT][T] = ((y1 && x0) ? lh * hw : 0.f) * ww_;                                                          \
+        sw4[IT][T] = ((y1 && x1) ? lh * lw : 0.f) * ww_;                                                          \
         /* a sample outside the map carries weight 0: any finite line serves (the kernels above read the map's corner there) */ \
         OK = !inside || l < GLV || (yc0 >= my0 && yc1 <= my1 && xc0 >= mx0 && xc1 <= mx1);                        \
         const bool use = inside && OK; /* (an address inside the buffer in every case) */                         \
@@ -563,19 +575,18 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
                 for (int u = 0; u < NB; ++u) any_fast = any_fast || fast[half + u];
                 if (!any_fast) continue;
                 unsigned word[NB];
-                float w1[NB], w2[NB], w3[NB], w4[NB], ww[NB];
+                float w1[NB], w2[NB], w3[NB], w4[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const int it = half + u;
                     // (opaque: a ds_swizzle is not a memory operation, and without this the compiler computes the swizzles of ALL
                     // levels in front of the first barrier -- 1500 live values, 3.6 KB of scratch per lane)
-                    asm volatile("" : "+v"(pk[it][t]), "+v"(sw1[it][t]), "+v"(sw2[it][t]), "+v"(sw3[it][t]), "+v"(sw4[it][t]), "+v"(sww[it][t]));
+                    asm volatile("" : "+v"(pk[it][t]), "+v"(sw1[it][t]), "+v"(sw2[it][t]), "+v"(sw3[it][t]), "+v"(sw4[it][t]));
                     word[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, pk[it][t]), o));
                     w1[u] = bcast(sw1[it][t], o);
                     w2[u] = bcast(sw2[it][t], o);
                     w3[u] = bcast(sw3[it][t], o);
                     w4[u] = bcast(sw4[it][t], o);
-                    ww[u] = bcast(sww[it][t], o);
                 }
                 f32x4 v1[NB], v2[NB], v3[NB], v4[NB];
 #pragma unroll
@@ -593,8 +604,10 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const f32x4 val = w1[u] * v1[u] + w2[u] * v2[u] + w3[u] * v3[u] + w4[u] * v4[u];
-                    acc[half + u] += val * ww[u];
+                    msda_fma4(acc[half + u], w1[u], v1[u]);
+                    msda_fma4(acc[half + u], w2[u], v2[u]);
+                    msda_fma4(acc[half + u], w3[u], v3[u]);
+                    msda_fma4(acc[half + u], w4[u], v4[u]);
                 }
                 __builtin_amdgcn_sched_barrier(0);           // (keeps the scheduler from hoisting later batches' loads: spills)
             }
@@ -622,12 +635,12 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
                 for (int u = 0; u < NB; ++u) any_fast = any_fast || fast[half + u];
                 if (!any_fast) continue;
                 unsigned a1[NB], a2[NB], a3[NB], a4[NB];
-                float w1[NB], w2[NB], w3[NB], w4[NB], ww[NB];
+                float w1[NB], w2[NB], w3[NB], w4[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const int it = half + u;
                     asm volatile("" : "+v"(go1[it][t]), "+v"(go2[it][t]), "+v"(go3[it][t]), "+v"(go4[it][t]));
-                    asm volatile("" : "+v"(sw1[it][t]), "+v"(sw2[it][t]), "+v"(sw3[it][t]), "+v"(sw4[it][t]), "+v"(sww[it][t]));
+                    asm volatile("" : "+v"(sw1[it][t]), "+v"(sw2[it][t]), "+v"(sw3[it][t]), "+v"(sw4[it][t]));
                     a1[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, go1[it][t]), o)) + mine;
                     a2[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, go2[it][t]), o)) + mine;
                     a3[u] = __builtin_bit_cast(unsigned, bcast(__builtin_bit_cast(float, go3[it][t]), o)) + mine;
@@ -636,7 +649,6 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
                     w2[u] = bcast(sw2[it][t], o);
                     w3[u] = bcast(sw3[it][t], o);
                     w4[u] = bcast(sw4[it][t], o);
-                    ww[u] = bcast(sww[it][t], o);
                 }
                 f32x4 v1[NB], v2[NB], v3[NB], v4[NB];
 #pragma unroll
@@ -648,8 +660,10 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const f32x4 val = w1[u] * v1[u] + w2[u] * v2[u] + w3[u] * v3[u] + w4[u] * v4[u];
-                    acc[half + u] += val * ww[u];
+                    msda_fma4(acc[half + u], w1[u], v1[u]);
+                    msda_fma4(acc[half + u], w2[u], v2[u]);
+                    msda_fma4(acc[half + u], w3[u], v3[u]);
+                    msda_fma4(acc[half + u], w4[u], v4[u]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -719,9 +733,11 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
                 const f32x4 v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a3, 0, 0));
                 const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a4, 0, 0));
                 const float w1 = group8_read(sw1[it][t], o), w2 = group8_read(sw2[it][t], o), w3 = group8_read(sw3[it][t], o),
-                            w4 = group8_read(sw4[it][t], o), ww = group8_read(sww[it][t], o);
-                const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-                r += val * ww;
+                            w4 = group8_read(sw4[it][t], o);
+                msda_fma4(r, w1, v1);
+                msda_fma4(r, w2, v2);
+                msda_fma4(r, w3, v3);
+                msda_fma4(r, w4, v4);
             }
             acc[it] = r;
         }
