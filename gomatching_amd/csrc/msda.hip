@@ -562,6 +562,8 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
     auto bcast = [](float v, int owner) { return group8_read(v, owner); };
     auto level_samples = [&](auto LEVC, const unsigned char* buf) {
         constexpr int lev = decltype(LEVC)::value;
+        typedef __attribute__((address_space(3))) f32x4 LdsF4;
+        const unsigned mine_lds = mine + (unsigned)(size_t)buf;   // (a flat LDS address: its low word is the LDS offset)
         const unsigned row_bytes = (unsigned)wwd[lev] * 128u;
 #pragma unroll
         for (int pnt = 0; pnt < POINTS; ++pnt) {
@@ -591,16 +593,18 @@ __global__ __launch_bounds__(256, 2) void msda_window_kernel(const float* __rest
                 f32x4 v1[NB], v2[NB], v3[NB], v4[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const unsigned a1 = (word[u] & 0xFFFFFu) + mine;
+                    const unsigned a1 = (word[u] & 0xFFFFFu) + mine_lds;
                     const unsigned dx = (word[u] >> 20) & 1u, dy = (word[u] >> 21) & 1u;
                     unsigned a2 = a1 + dx * 128u, a3 = a1 + dy * row_bytes, a4 = a3 + dx * 128u;
                     // opaque: otherwise the compiler branches around the reads whose address may equal another one's (dx = 0 or
                     // dy = 0 at the map's edge) -- 600 branches in this kernel, exec-masked paths per lane group
                     asm volatile("" : "+v"(a2), "+v"(a3), "+v"(a4));
-                    v1[u] = *reinterpret_cast<const f32x4*>(buf + a1);
-                    v2[u] = *reinterpret_cast<const f32x4*>(buf + a2);
-                    v3[u] = *reinterpret_cast<const f32x4*>(buf + a3);
-                    v4[u] = *reinterpret_cast<const f32x4*>(buf + a4);
+                    // (absolute LDS addresses -- the window's offset rides in `mine_lds`: as `buf + a` behind the opaque asm the
+                    // compiler spends one v_add_u32 per read on a base it cannot fold, 4 of ~30 vector instructions per sample)
+                    v1[u] = *reinterpret_cast<const LdsF4*>((size_t)a1);
+                    v2[u] = *reinterpret_cast<const LdsF4*>((size_t)a2);
+                    v3[u] = *reinterpret_cast<const LdsF4*>((size_t)a3);
+                    v4[u] = *reinterpret_cast<const LdsF4*>((size_t)a4);
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
