@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float* __restrict
 // corner weights, the attention weight and the four corner ELEMENT OFFSETS once, and the eight lanes then read each sample's
 // nine values from its owner with ds_swizzle (the LDS crossbar: no VALU issue, no memory).  Per-channel arithmetic is the
 // kernel above's, value for value: softmax numerators by the same expf, their sum in the same ascending order (every lane
-// collects the sixteen numerators by swizzle and adds them itself), w1*v1 + w2*v2 + w3*v3 + w4*v4 times the sample's weight.
+// collects the sixteen numerators by swizzle and adds them itself); from round 6 on a sample is accumulated as four fused
+// multiply-adds with corner weights that already carry the sample's attention weight (msda_fma4 above), in every fused kernel.
 // Corner loads are buffer loads with 32-bit byte offsets from the batch image (a level map holds < 2^29 floats).
 __device__ __forceinline__ float group8_read(float v, int owner) {      // value of lane (lane & ~7) | owner, owner a constant
     // ds_swizzle bit-mask mode: lane' = ((lane & and_mask) | or_mask) ^ xor_mask inside each half-wave of 32
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void msda_fused_lanes_kernel(const float* __re
 //     lane -- the lane-distributed kernel's layout with the eight heads of a wave replaced by eight queries), 4 such octet
 //     groups per wave = 128 queries per tile;
 //   * the per-sample arithmetic is the lane-distributed kernel's, instruction for instruction (softmax, location, the four
-//     corner weights, `(w1 v1 + w2 v2 + w3 v3 + w4 v4) * w` accumulated in sample order), so results are BIT-IDENTICAL;
+//     corner weights x the attention weight, four fused multiply-adds per sample in sample order), so results are BIT-IDENTICAL;
 //   * levels are processed one after the other through one LDS buffer (fill level l, barrier, its four samples of every query);
 //     the accumulation order l = 0..3, p = 0..3 is the kernels' above;
 //   * a sample whose clamped corners are not all inside the window makes its wave's octet group (8 queries) take the global-
